@@ -1,0 +1,1138 @@
+/*
+ * ivp_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See ivp_oracle.h.
+ *
+ * Scalar, one-trajectory-per-call restatement of the reference's explicit RK path.
+ * Build with -ffp-contract=off: the reference (Rust) never contracts a*b+c into an FMA, and
+ * every expression below keeps the reference's left-to-right association so that the
+ * arithmetic is the same IEEE-754 operation sequence.
+ *
+ * Citations are file:line in the reference tree.
+ */
+#include "ivp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Step-controller power function
+ * ---------------------------------------------------------------------------------------- */
+
+static inline uint64_t d2bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double bits2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
+/* Portable exp2(e*log2(x)) for x >= 0: only IEEE +,-,*,/, fma, rint and bit moves, so a device
+ * restatement of the same operation sequence gives the same bits.  A few ulp accurate, which a
+ * step-size factor does not notice. */
+double orc_detpow(double x, double e)
+{
+    if (e == 0.0) return 1.0;
+    if (x != x || e != e) return x + e;
+    if (x < 0.0) return NAN;
+    if (x == 0.0) return e > 0.0 ? 0.0 : INFINITY;
+    if (x == INFINITY) return e > 0.0 ? INFINITY : 0.0;
+
+    int k = 0;
+    uint64_t u = d2bits(x);
+    if ((u >> 52) == 0) { /* subnormal */
+        x *= 0x1p54;
+        u = d2bits(x);
+        k = -54;
+    }
+    int ex = (int)(u >> 52) - 1023;
+    uint64_t mant = u & 0x000FFFFFFFFFFFFFull;
+    double m;
+    if (mant > 0x6A09E667F3BCDull) { /* m > sqrt(2): use m/2 in [sqrt(1/2), 1) */
+        m = bits2d(mant | 0x3FE0000000000000ull);
+        ex += 1;
+    } else {
+        m = bits2d(mant | 0x3FF0000000000000ull);
+    }
+    k += ex;
+
+    /* ln(m) = 2 atanh(t), t = (m-1)/(m+1), |t| <= 0.1716 */
+    double t = (m - 1.0) / (m + 1.0);
+    double z = t * t;
+    double p = 1.0 / 25.0;
+    p = fma(p, z, 1.0 / 23.0);
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    double lnm = (2.0 * t) * p;
+    double l2 = fma(lnm, 0x1.71547652b82fep+0 /* 1/ln2 */, (double)k);
+    double w = e * l2;
+
+    if (w >= 1024.0) return INFINITY;
+    if (w <= -1022.0) return 0.0;
+    double kd = rint(w);
+    double r = w - kd;
+    double v = r * 0x1.62e42fefa39efp-1; /* ln2 */
+    double q = 1.0 / 87178291200.0; /* 1/14! */
+    q = fma(q, v, 1.0 / 6227020800.0);
+    q = fma(q, v, 1.0 / 479001600.0);
+    q = fma(q, v, 1.0 / 39916800.0);
+    q = fma(q, v, 1.0 / 3628800.0);
+    q = fma(q, v, 1.0 / 362880.0);
+    q = fma(q, v, 1.0 / 40320.0);
+    q = fma(q, v, 1.0 / 5040.0);
+    q = fma(q, v, 1.0 / 720.0);
+    q = fma(q, v, 1.0 / 120.0);
+    q = fma(q, v, 1.0 / 24.0);
+    q = fma(q, v, 1.0 / 6.0);
+    q = fma(q, v, 0.5);
+    q = fma(q, v, 1.0);
+    q = fma(q, v, 1.0);
+    int ki = (int)kd;
+    double scale = bits2d((uint64_t)(ki + 1023) << 52);
+    return q * scale;
+}
+
+#ifdef ORC_DETPOW
+#define ORC_POW(x, e) orc_detpow((x), (e))
+int orc_uses_detpow(void) { return 1; }
+#else
+#define ORC_POW(x, e) pow((x), (e))
+int orc_uses_detpow(void) { return 0; }
+#endif
+
+/* Rust f64::signum: 1.0 for +0.0 and positives, -1.0 for -0.0 and negatives, NaN for NaN. */
+static inline double rs_signum(double v) { return v != v ? v : copysign(1.0, v); }
+
+/* ------------------------------------------------------------------------------------------
+ * Built-in right-hand sides
+ * ---------------------------------------------------------------------------------------- */
+
+static void rhs_decay(double x, const double *y, double *d, const double *p)
+{   /* examples/exponential_decay.rs:11 */
+    (void)x;
+    d[0] = -p[0] * y[0];
+}
+static void rhs_sho(double x, const double *y, double *d, const double *p)
+{   /* tests/common.rs:5-8 */
+    (void)x; (void)p;
+    d[0] = y[1];
+    d[1] = -y[0];
+}
+static void rhs_vdp(double x, const double *y, double *d, const double *p)
+{   /* benches/benchmark.py:22-27 */
+    (void)x;
+    double mu = p[0];
+    d[0] = y[1];
+    d[1] = mu * (1.0 - y[0] * y[0]) * y[1] - y[0];
+}
+static void rhs_cr3bp(double t, const double *s, double *d, const double *p)
+{   /* examples/cr3bp.rs:24-35 */
+    (void)t;
+    double mu = p[0];
+    double x = s[0], y = s[1], z = s[2], vx = s[3], vy = s[4], vz = s[5];
+    double a = x + mu;
+    double b = x - 1.0 + mu;
+    double r1 = sqrt(a * a + y * y + z * z);
+    double r2 = sqrt(b * b + y * y + z * z);
+    double r13 = r1 * r1 * r1; /* powi(3) */
+    double r23 = r2 * r2 * r2;
+    d[0] = vx;
+    d[1] = vy;
+    d[2] = vz;
+    d[3] = x + 2.0 * vy - (1.0 - mu) * (x + mu) / r13 - mu * (x - 1.0 + mu) / r23;
+    d[4] = y - 2.0 * vx - (1.0 - mu) * y / r13 - mu * y / r23;
+    d[5] = -(1.0 - mu) * z / r13 - mu * z / r23;
+}
+static void rhs_lorenz(double t, const double *s, double *d, const double *p)
+{   /* benches/benchmark.py:30-37 */
+    (void)t;
+    double sigma = p[0], rho = p[1], beta = p[2];
+    double x = s[0], y = s[1], z = s[2];
+    d[0] = sigma * (y - x);
+    d[1] = x * (rho - z) - y;
+    d[2] = x * y - beta * z;
+}
+static void rhs_zero(double t, const double *s, double *d, const double *p)
+{   /* tests/ivp.rs:14-18 */
+    (void)t; (void)s; (void)p;
+    d[0] = 0.0; d[1] = 0.0; d[2] = 0.0;
+}
+static void rhs_rational(double t, const double *y, double *d, const double *p)
+{   /* tests/test_helpers.py:23-25 */
+    (void)p;
+    d[0] = y[1] / t;
+    d[1] = y[1] * (y[0] + 2.0 * y[1] - 1.0) / (t * (y[0] - 1.0));
+}
+static void rhs_exp2(double t, const double *y, double *d, const double *p)
+{   /* tests/ivp.rs:293-297 */
+    (void)t; (void)p;
+    d[0] = y[0];
+    d[1] = y[1];
+}
+
+orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *np_out)
+{
+    static const struct { orc_ode_fn f; int n, np; } tab[ORC_RHS_COUNT] = {
+        {rhs_decay, 1, 1}, {rhs_sho, 2, 0}, {rhs_vdp, 2, 1}, {rhs_cr3bp, 6, 1},
+        {rhs_lorenz, 3, 3}, {rhs_zero, 3, 0}, {rhs_rational, 2, 0}, {rhs_exp2, 2, 0},
+    };
+    if (rhs_id < 0 || rhs_id >= ORC_RHS_COUNT) return NULL;
+    if (n_out) *n_out = tab[rhs_id].n;
+    if (np_out) *np_out = tab[rhs_id].np;
+    return tab[rhs_id].f;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Tolerance (src/methods/mod.rs:104-214): Index returns the scalar for any i.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { const double *v; int len; } tol_t;
+static inline double tol_at(const tol_t *t, int i) { return t->len == 1 ? t->v[0] : t->v[i]; }
+
+/* ------------------------------------------------------------------------------------------
+ * Dense interpolants
+ * ---------------------------------------------------------------------------------------- */
+static void interp_dopri5(double xi, double *yi, const double *cont, int n, double xold, double h)
+{   /* dopri5.rs:467-478 */
+    double theta = (xi - xold) / h;
+    double theta1 = 1.0 - theta;
+    for (int i = 0; i < n; i++) {
+        yi[i] = cont[i]
+              + theta * (cont[n + i]
+                         + theta1 * (cont[2 * n + i] + theta * (cont[3 * n + i] + theta1 * cont[4 * n + i])));
+    }
+}
+static void interp_dop853(double xi, double *yi, const double *cont, int n, double xold, double h)
+{   /* dop853.rs:659-670 */
+    double s = (xi - xold) / h;
+    double s1 = 1.0 - s;
+    for (int i = 0; i < n; i++) {
+        double conpar = cont[4 * n + i] + s * (cont[5 * n + i] + s1 * (cont[6 * n + i] + s * cont[7 * n + i]));
+        yi[i] = cont[i] + s * (cont[n + i] + s1 * (cont[2 * n + i] + s * (cont[3 * n + i] + s1 * conpar)));
+    }
+}
+static void interp_rk23(double xi, double *yi, const double *cont, int n, double xold, double h)
+{   /* rk23.rs:313-321 */
+    double xc = (xi - xold) / h;
+    double x2 = xc * xc;
+    double x3 = x2 * xc;
+    for (int i = 0; i < n; i++) {
+        yi[i] = cont[i] + h * (cont[n + i] * xc + cont[2 * n + i] * x2 + cont[3 * n + i] * x3);
+    }
+}
+static int ncoef_of(int method)
+{   /* options.rs:34-43 */
+    return method == ORC_DOPRI5 ? 5 : method == ORC_DOP853 ? 8 : 4;
+}
+static void interp_any(int method, double xi, double *yi, const double *cont, int n, double xold, double h)
+{
+    if (method == ORC_DOPRI5) interp_dopri5(xi, yi, cont, n, xold, h);
+    else if (method == ORC_DOP853) interp_dop853(xi, yi, cont, n, xold, h);
+    else interp_rk23(xi, yi, cont, n, xold, h);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DefaultSolOut (src/solve/solout.rs) without events: dense collection, t_eval sampling,
+ * accepted-step recording with first_step enforcement.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int method, n;
+    const double *t_eval; int n_eval; /* n_eval < 0: None */
+    size_t next_idx;
+    double tol;
+    size_t len, cap; double *t; double *y;
+    int collect_dense;
+    size_t nseg, segcap; double *seg_cont, *seg_xold, *seg_h;
+    int has_first_step; double first_step;
+    double x0;
+    int first_output_done;
+} solout_t;
+
+static void so_push(solout_t *s, double t, const double *y)
+{
+    if (s->len == s->cap) {
+        s->cap = s->cap ? 2 * s->cap : 64;
+        s->t = (double *)realloc(s->t, s->cap * sizeof(double));
+        s->y = (double *)realloc(s->y, s->cap * (size_t)s->n * sizeof(double));
+    }
+    s->t[s->len] = t;
+    memcpy(s->y + s->len * (size_t)s->n, y, (size_t)s->n * sizeof(double));
+    s->len++;
+}
+
+/* Returns 0 = Continue (the only flag DefaultSolOut produces without events). */
+static int so_call(solout_t *s, double xold, double x, const double *y,
+                   const double *cont /* NULL = no interpolant */, double h)
+{
+    int n = s->n;
+    /* solout.rs:141-146 */
+    if (s->collect_dense && x != xold && cont) {
+        if (h != 0.0) {
+            int nc = ncoef_of(s->method) * n;
+            if (s->nseg == s->segcap) {
+                s->segcap = s->segcap ? 2 * s->segcap : 64;
+                s->seg_cont = (double *)realloc(s->seg_cont, s->segcap * (size_t)nc * sizeof(double));
+                s->seg_xold = (double *)realloc(s->seg_xold, s->segcap * sizeof(double));
+                s->seg_h = (double *)realloc(s->seg_h, s->segcap * sizeof(double));
+            }
+            memcpy(s->seg_cont + s->nseg * (size_t)nc, cont, (size_t)nc * sizeof(double));
+            s->seg_xold[s->nseg] = xold;
+            s->seg_h[s->nseg] = h;
+            s->nseg++;
+        }
+    }
+
+    double yi[64];
+    if (s->n_eval >= 0) {
+        /* Mode 1, solout.rs:344-386 */
+        size_t i = s->next_idx;
+        size_t ne = (size_t)s->n_eval;
+        if (fabs(xold - x) <= s->tol) {
+            while (i < ne && fabs(s->t_eval[i] - x) <= s->tol) {
+                so_push(s, s->t_eval[i], y);
+                i++;
+            }
+        } else {
+            int forward = x > xold;
+            if (forward) {
+                while (i < ne && s->t_eval[i] <= x + s->tol) {
+                    if (s->t_eval[i] >= xold - s->tol) {
+                        interp_any(s->method, s->t_eval[i], yi, cont, n, xold, h);
+                        so_push(s, s->t_eval[i], yi);
+                    }
+                    i++;
+                }
+            } else {
+                while (i < ne && s->t_eval[i] >= x - s->tol) {
+                    if (s->t_eval[i] <= xold + s->tol) {
+                        interp_any(s->method, s->t_eval[i], yi, cont, n, xold, h);
+                        so_push(s, s->t_eval[i], yi);
+                    }
+                    i++;
+                }
+            }
+        }
+        s->next_idx = i;
+    } else {
+        /* Mode 2, solout.rs:387-428 */
+        if (s->has_first_step) {
+            if (!s->first_output_done && fabs(xold - x) > s->tol) {
+                double direction = rs_signum(x - xold);
+                double target = s->x0 + direction * s->first_step;
+                if (direction * (x - target) >= -s->tol) {
+                    if (cont) {
+                        interp_any(s->method, target, yi, cont, n, xold, h);
+                        so_push(s, target, yi);
+                        s->first_output_done = 1;
+                    }
+                    if (fabs(x - target) > s->tol) so_push(s, x, y);
+                    return 0;
+                } else {
+                    return 0;
+                }
+            }
+        }
+        if (s->len == 0 || fabs(s->t[s->len - 1] - x) > s->tol) so_push(s, x, y);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * hinit (src/methods/mod.rs:217-281)
+ * ---------------------------------------------------------------------------------------- */
+static double hinit(orc_ode_fn f, const double *p, int n, double x, const double *y, double posneg,
+                    const double *f0, double *f1, double *y1, int iord, double hmax,
+                    const tol_t *atol, const tol_t *rtol)
+{
+    double dnf = 0.0, dny = 0.0;
+    for (int i = 0; i < n; i++) {
+        double sk = tol_at(atol, i) + tol_at(rtol, i) * fabs(y[i]);
+        dnf += (f0[i] / sk) * (f0[i] / sk);
+        dny += (y[i] / sk) * (y[i] / sk);
+    }
+    double h;
+    if (dnf <= 1e-10 || dny <= 1e-10) h = 1.0e-6;
+    else h = sqrt(dny / dnf) * 0.01;
+    if (h > fabs(hmax)) h = fabs(hmax);
+    h = fabs(h) * rs_signum(posneg);
+
+    for (int i = 0; i < n; i++) y1[i] = y[i] + h * f0[i];
+    f(x + h, y1, f1, p);
+
+    double der2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        double sk = tol_at(atol, i) + tol_at(rtol, i) * fabs(y[i]);
+        double df = (f1[i] - f0[i]) / sk;
+        der2 += df * df;
+    }
+    der2 = sqrt(der2) / fabs(h);
+    double der12 = fmax(fabs(der2), sqrt(dnf));
+    double h1;
+    if (der12 <= 1.0e-15) h1 = fmax(1.0e-6, fabs(h) * 1.0e-3);
+    else h1 = ORC_POW(0.01 / der12, 1.0 / (double)iord);
+    /* mod.rs:279: min(|h|, 100|h|, h1, hmax) -- the 100|h| term is dead but kept as written */
+    double hf = fmin(fmin(fmin(fabs(h), 100.0 * fabs(h)), h1), fabs(hmax));
+    return fabs(hf) * rs_signum(posneg);
+}
+
+typedef struct {
+    double h; int status;
+    uint64_t nfev, nstep, naccpt, nrejct;
+} int_result;
+
+/* ------------------------------------------------------------------------------------------
+ * DOPRI5 (src/methods/dopri5.rs)
+ * ---------------------------------------------------------------------------------------- */
+static int dopri5_solve(orc_ode_fn f, const double *p, int n, double x0, const double *y0, double xend,
+                        const tol_t *rtol, const tol_t *atol, const orc_options *opt, solout_t *so,
+                        int_result *res, double *y_final, double *x_final)
+{
+    /* tableau, dopri5.rs:482-520 */
+    const double C2 = 0.2, C3 = 0.3, C4 = 0.8, C5 = 8.0 / 9.0;
+    const double A21 = 0.2;
+    const double A31 = 3.0 / 40.0, A32 = 9.0 / 40.0;
+    const double A41 = 44.0 / 45.0, A42 = -56.0 / 15.0, A43 = 32.0 / 9.0;
+    const double A51 = 19372.0 / 6561.0, A52 = -25360.0 / 2187.0, A53 = 64448.0 / 6561.0, A54 = -212.0 / 729.0;
+    const double A61 = 9017.0 / 3168.0, A62 = -355.0 / 33.0, A63 = 46732.0 / 5247.0, A64 = 49.0 / 176.0,
+                 A65 = -5103.0 / 18656.0;
+    const double A71 = 35.0 / 384.0, A73 = 500.0 / 1113.0, A74 = 125.0 / 192.0, A75 = -2187.0 / 6784.0,
+                 A76 = 11.0 / 84.0;
+    const double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, E5 = -17253.0 / 339200.0,
+                 E6 = 22.0 / 525.0, E7 = -1.0 / 40.0;
+    const double D1 = -12715105075.0 / 11282082432.0, D3 = 87487479700.0 / 32700410799.0,
+                 D4 = -10690763975.0 / 1880347072.0, D5 = 701980252875.0 / 199316789632.0,
+                 D6 = -1453857185.0 / 822651844.0, D7 = 69997945.0 / 29380423.0;
+
+    /* struct defaults, dopri5.rs:34-72; solve_ivp only overrides max_step/first_step/max_steps */
+    const double uround = 2.3e-16, safety = 0.9, scale_min = 0.2, scale_max = 10.0, beta = 0.04;
+    const uint64_t nstiff = 1000;
+    const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE; /* dopri5.rs:184-189 */
+
+    double x = x0;
+    double *w = (double *)malloc((size_t)n * (8 + 5) * sizeof(double));
+    double *y = w, *k1 = w + n, *k2 = w + 2 * n, *k3 = w + 3 * n, *k4 = w + 4 * n, *k5 = w + 5 * n,
+           *k6 = w + 6 * n, *y1 = w + 7 * n, *cont = w + 8 * n;
+    memcpy(y, y0, (size_t)n * sizeof(double));
+    memset(k1, 0, (size_t)n * 12 * sizeof(double));
+
+    const double facc1 = 1.0 / scale_min, facc2 = 1.0 / scale_max;
+    const double h_max = opt->has_max_step ? opt->max_step : fabs(xend - x); /* dopri5.rs:180 */
+    double facold = 1e-4;
+    int last = 0, reject = 0;
+    int nonstiff = 0, iasti = 0;
+    double hlamb = 0.0;
+    uint64_t nfev = 0, nstep = 0, naccpt = 0, nrejct = 0, attempts = 0;
+    double xold = x;
+    int status;
+    const double expo1 = 0.2 - beta * 0.75;
+    const double posneg = rs_signum(xend - x);
+
+    f(x, y, k1, p);
+    nfev += 1;
+    double h;
+    if (opt->has_first_step) h = fabs(opt->first_step) * posneg;
+    else { nfev += 1; h = hinit(f, p, n, x, y, posneg, k1, k2, k3, 5, h_max, atol, rtol); }
+
+    so_call(so, xold, x, y, NULL, 0.0);
+
+    for (;;) {
+        if (nstep > nmax) { status = ORC_NEED_LARGER_NMAX; break; }
+        if (0.1 * fabs(h) <= fabs(x) * uround) { status = ORC_STEP_SIZE_TOO_SMALL; break; }
+        if (opt->attempt_guard && attempts >= opt->attempt_guard) { status = ORC_NEED_LARGER_NMAX; break; }
+        if ((x + 1.01 * h - xend) * posneg > 0.0) { h = xend - x; last = 1; }
+        nstep += 1;
+        attempts += 1;
+
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * A21 * k1[i];
+        f(x + C2 * h, y1, k2, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A31 * k1[i] + A32 * k2[i]);
+        f(x + C3 * h, y1, k3, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]);
+        f(x + C4 * h, y1, k4, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]);
+        f(x + C5 * h, y1, k5, p);
+        for (int i = 0; i < n; i++)
+            y1[i] = y[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]);
+        double xph = x + h;
+        f(xph, y1, k6, p);
+        for (int i = 0; i < n; i++)
+            y1[i] = y[i] + h * (A71 * k1[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+        f(xph, y1, k2, p);
+        nfev += 6;
+
+        /* dense block 4 (always: struct default dense_output = true, dopri5.rs:329-334) */
+        for (int i = 0; i < n; i++)
+            cont[4 * n + i] = h * (D1 * k1[i] + D3 * k3[i] + D4 * k4[i] + D5 * k5[i] + D6 * k6[i] + D7 * k2[i]);
+
+        for (int i = 0; i < n; i++)
+            k4[i] = (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k2[i]) * h;
+
+        double err = 0.0;
+        for (int i = 0; i < n; i++) {
+            double sk = tol_at(atol, i) + tol_at(rtol, i) * fmax(fabs(y[i]), fabs(y1[i]));
+            err += (k4[i] / sk) * (k4[i] / sk);
+        }
+        err = sqrt(err / (double)n);
+
+        double fac11 = ORC_POW(err, expo1);
+        double fac = fac11 / ORC_POW(facold, beta);
+        fac = fmax(facc2, fmin(facc1, fac / safety));
+        double hnew = h / fac;
+
+        if (err <= 1.0) {
+            facold = fmax(err, 1.0e-4);
+            naccpt += 1;
+
+            if ((naccpt % nstiff == 0) || (iasti > 0)) { /* dopri5.rs:364-391 */
+                double stnum = 0.0, stden = 0.0;
+                for (int i = 0; i < n; i++) {
+                    double d1 = k2[i] - k6[i];
+                    double ysti = y[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]);
+                    double d2 = y1[i] - ysti;
+                    stnum += d1 * d1;
+                    stden += d2 * d2;
+                }
+                if (stden > 0.0) hlamb = fabs(h) * sqrt(stnum / stden);
+                if (hlamb > 3.25) {
+                    nonstiff = 0;
+                    iasti += 1;
+                    if (iasti == 15) { status = ORC_PROBABLY_STIFF; break; }
+                } else {
+                    nonstiff += 1;
+                    if (nonstiff == 6) iasti = 0;
+                }
+            }
+
+            for (int i = 0; i < n; i++) { /* dopri5.rs:394-403 */
+                double ydiff = y1[i] - y[i];
+                double bspl = h * k1[i] - ydiff;
+                cont[i] = y[i];
+                cont[n + i] = ydiff;
+                cont[2 * n + i] = bspl;
+                cont[3 * n + i] = -h * k2[i] + ydiff - bspl;
+            }
+
+            memcpy(k1, k2, (size_t)n * sizeof(double));
+            memcpy(y, y1, (size_t)n * sizeof(double));
+            xold = x;
+            x = xph;
+
+            so_call(so, xold, x, y, cont, h);
+
+            if (last) { h = hnew; status = ORC_SUCCESS; break; }
+            if (fabs(hnew) > fabs(h_max)) hnew = posneg * fabs(h_max);
+            if (reject) { hnew = posneg * fmin(fabs(hnew), fabs(h)); reject = 0; }
+        } else {
+            hnew = h / fmin(facc1, fac11 / safety);
+            reject = 1;
+            if (naccpt > 1) nrejct += 1;
+            last = 0;
+        }
+        h = hnew;
+    }
+
+    res->h = h; res->status = status;
+    res->nfev = nfev; res->nstep = nstep; res->naccpt = naccpt; res->nrejct = nrejct;
+    memcpy(y_final, y, (size_t)n * sizeof(double));
+    *x_final = x;
+    free(w);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DOP853 (src/methods/dop853.rs)
+ * ---------------------------------------------------------------------------------------- */
+static int dop853_solve(orc_ode_fn f, const double *p, int n, double x0, const double *y0, double xend,
+                        const tol_t *rtol, const tol_t *atol, const orc_options *opt, solout_t *so,
+                        int_result *res, double *y_final, double *x_final)
+{
+    /* tableau, dop853.rs:674-848 (Hairer's DOP853 coefficients) */
+    const double C2 = 0.526001519587677318785587544488e-01, C3 = 0.789002279381515978178381316732e-01,
+                 C4 = 0.118350341907227396726757197510e+00, C5 = 0.281649658092772603273242802490e+00,
+                 C6 = 0.333333333333333333333333333333e+00, C7 = 0.25e+00,
+                 C8 = 0.307692307692307692307692307692e+00, C9 = 0.651282051282051282051282051282e+00,
+                 C10 = 0.6e+00, C11 = 0.857142857142857142857142857142e+00, C14 = 0.1e+00, C15 = 0.2e+00,
+                 C16 = 7.777777777777778e-1;
+    const double A21 = 5.26001519587677318785587544488e-2;
+    const double A31 = 1.97250569845378994544595329183e-2, A32 = 5.91751709536136983633785987549e-2;
+    const double A41 = 2.95875854768068491816892993775e-2, A43 = 8.87627564304205475450678981324e-2;
+    const double A51 = 2.41365134159266685502369798665e-1, A53 = -8.84549479328286085344864962717e-1,
+                 A54 = 9.24834003261792003115737966543e-1;
+    const double A61 = 3.7037037037037037037037037037e-2, A64 = 1.70828608729473871279604482173e-1,
+                 A65 = 1.25467687566822425016691814123e-1;
+    const double A71 = 3.7109375e-2, A74 = 1.70252211019544039314978060272e-1,
+                 A75 = 6.02165389804559606850219397283e-2, A76 = -1.7578125e-2;
+    const double A81 = 3.70920001185047927108779319836e-2, A84 = 1.70383925712239993810214054705e-1,
+                 A85 = 1.07262030446373284651809199168e-1, A86 = -1.53194377486244017527936158236e-2,
+                 A87 = 8.27378916381402288758473766002e-3;
+    const double A91 = 6.24110958716075717114429577812e-1, A94 = -3.36089262944694129406857109825e0,
+                 A95 = -8.68219346841726006818189891453e-1, A96 = 2.75920996994467083049415600797e1,
+                 A97 = 2.01540675504778934086186788979e1, A98 = -4.34898841810699588477366255144e1;
+    const double A101 = 4.77662536438264365890433908527e-1, A104 = -2.48811461997166764192642586468e0,
+                 A105 = -5.90290826836842996371446475743e-1, A106 = 2.12300514481811942347288949897e1,
+                 A107 = 1.52792336328824235832596922938e1, A108 = -3.32882109689848629194453265587e1,
+                 A109 = -2.03312017085086261358222928593e-2;
+    const double A111 = -9.3714243008598732571704021658e-1, A114 = 5.18637242884406370830023853209e0,
+                 A115 = 1.09143734899672957818500254654e0, A116 = -8.14978701074692612513997267357e0,
+                 A117 = -1.85200656599969598641566180701e1, A118 = 2.27394870993505042818970056734e1,
+                 A119 = 2.49360555267965238987089396762e0, A1110 = -3.0467644718982195003823669022e0;
+    const double A121 = 2.27331014751653820792359768449e0, A124 = -1.05344954667372501984066689879e1,
+                 A125 = -2.00087205822486249909675718444e0, A126 = -1.79589318631187989172765950534e1,
+                 A127 = 2.79488845294199600508499808837e1, A128 = -2.85899827713502369474065508674e0,
+                 A129 = -8.87285693353062954433549289258e0, A1210 = 1.23605671757943030647266201528e1,
+                 A1211 = 6.43392746015763530355970484046e-1;
+    const double B1 = 5.42937341165687622380535766363e-2, B6 = 4.45031289275240888144113950566e0,
+                 B7 = 1.89151789931450038304281599044e0, B8 = -5.8012039600105847814672114227e0,
+                 B9 = 3.1116436695781989440891606237e-1, B10 = -1.52160949662516078556178806805e-1,
+                 B11 = 2.01365400804030348374776537501e-1, B12 = 4.47106157277725905176885569043e-2;
+    const double BH1 = 0.244094488188976377952755905512e+00, BH2 = 0.733846688281611857341361741547e+00,
+                 BH3 = 0.220588235294117647058823529412e-01;
+    const double ER1 = 0.1312004499419488073250102996e-01, ER6 = -0.1225156446376204440720569753e+01,
+                 ER7 = -0.4957589496572501915214079952e+00, ER8 = 0.1664377182454986536961530415e+01,
+                 ER9 = -0.3503288487499736816886487290e+00, ER10 = 0.3341791187130174790297318841e+00,
+                 ER11 = 0.8192320648511571246570742613e-01, ER12 = -0.2235530786388629525884427845e-01;
+    const double A141 = 5.61675022830479523392909219681e-2, A147 = 2.53500210216624811088794765333e-1,
+                 A148 = -2.46239037470802489917441475441e-1, A149 = -1.24191423263816360469010140626e-1,
+                 A1410 = 1.5329179827876569731206322685e-1, A1411 = 8.20105229563468988491666602057e-3,
+                 A1412 = 7.56789766054569976138603589584e-3, A1413 = -8.298e-3;
+    const double A151 = 3.18346481635021405060768473261e-2, A156 = 2.83009096723667755288322961402e-2,
+                 A157 = 5.35419883074385676223797384372e-2, A158 = -5.49237485713909884646569340306e-2,
+                 A1511 = -1.08347328697249322858509316994e-4, A1512 = 3.82571090835658412954920192323e-4,
+                 A1513 = -3.40465008687404560802977114492e-4, A1514 = 1.41312443674632500278074618366e-1;
+    const double A161 = -4.28896301583791923408573538692e-1, A166 = -4.69762141536116384314449447206e0,
+                 A167 = 7.68342119606259904184240953878e0, A168 = 4.06898981839711007970213554331e0,
+                 A169 = 3.56727187455281109270669543021e-1, A1613 = -1.39902416515901462129418009734e-3,
+                 A1614 = 2.9475147891527723389556272149e0, A1615 = -9.15095847217987001081870187138e0;
+    const double D41 = -0.84289382761090128651353491142e+01, D46 = 0.56671495351937776962531783590e+00,
+                 D47 = -0.30689499459498916912797304727e+01, D48 = 0.23846676565120698287728149680e+01,
+                 D49 = 0.21170345824450282767155149946e+01, D410 = -0.87139158377797299206789907490e+00,
+                 D411 = 0.22404374302607882758541771650e+01, D412 = 0.63157877876946881815570249290e+00,
+                 D413 = -0.88990336451333310820698117400e-01, D414 = 0.18148505520854727256656404962e+02,
+                 D415 = -0.91946323924783554000451984436e+01, D416 = -0.44360363875948939664310572000e+01;
+    const double D51 = 0.10427508642579134603413151009e+02, D56 = 0.24228349177525818288430175319e+03,
+                 D57 = 0.16520045171727028198505394887e+03, D58 = -0.37454675472269020279518312152e+03,
+                 D59 = -0.22113666853125306036270938578e+02, D510 = 0.77334326684722638389603898808e+01,
+                 D511 = -0.30674084731089398182061213626e+02, D512 = -0.93321305264302278729567221706e+01,
+                 D513 = 0.15697238121770843886131091075e+02, D514 = -0.31139403219565177677282850411e+02,
+                 D515 = -0.93529243588444783865713862664e+01, D516 = 0.35816841486394083752465898540e+02;
+    const double D61 = 0.19985053242002433820987653617e+02, D66 = -0.38703730874935176555105901742e+03,
+                 D67 = -0.18917813819516756882830838328e+03, D68 = 0.52780815920542364900561016686e+03,
+                 D69 = -0.11573902539959630126141871134e+02, D610 = 0.68812326946963000169666922661e+01,
+                 D611 = -0.10006050966910838403183860980e+01, D612 = 0.77771377980534432092869265740e+00,
+                 D613 = -0.27782057523535084065932004339e+01, D614 = -0.60196695231264120758267380846e+02,
+                 D615 = 0.84320405506677161018159903784e+02, D616 = 0.11992291136182789328035130030e+02;
+    const double D71 = -0.25693933462703749003312586129e+02, D76 = -0.15418974869023643374053993627e+03,
+                 D77 = -0.23152937917604549567536039109e+03, D78 = 0.35763911791061412378285349910e+03,
+                 D79 = 0.93405324183624310003907691704e+02, D710 = -0.37458323136451633156875139351e+02,
+                 D711 = 0.10409964950896230045147246184e+03, D712 = 0.29840293426660503123344363579e+02,
+                 D713 = -0.43533456590011143754432175058e+02, D714 = 0.96324553959188282948394950600e+02,
+                 D715 = -0.39177261675615439165231486172e+02, D716 = -0.14972683625798562581422125276e+03;
+
+    /* struct defaults, dop853.rs:34-63 */
+    const double uround = 2.3e-16, safety = 0.9, scale_min = 0.333, scale_max = 6.0, beta = 0.0;
+    const uint64_t nstiff = 1000;
+    const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE;
+
+    double x = x0;
+    double *w = (double *)malloc((size_t)n * (12 + 8) * sizeof(double));
+    double *y = w, *y1 = w + n, *k1 = w + 2 * n, *k2 = w + 3 * n, *k3 = w + 4 * n, *k4 = w + 5 * n,
+           *k5 = w + 6 * n, *k6 = w + 7 * n, *k7 = w + 8 * n, *k8 = w + 9 * n, *k9 = w + 10 * n,
+           *k10 = w + 11 * n, *cont = w + 12 * n;
+    memcpy(y, y0, (size_t)n * sizeof(double));
+    memset(y1, 0, (size_t)n * 19 * sizeof(double));
+
+    const double facc1 = 1.0 / scale_min, facc2 = 1.0 / scale_max;
+    const double h_max = opt->has_max_step ? fabs(opt->max_step) : fabs(xend - x); /* dop853.rs:172-175 */
+    int nonstiff = 0, iasti = 0;
+    double facold = 1e-4, hlamb = 0.0;
+    int last = 0, reject = 0;
+    uint64_t nfev = 0, nstep = 0, naccpt = 0, nrejct = 0, attempts = 0;
+    double xold = x;
+    const double expo1 = 1.0 / 8.0 - beta * 0.2;
+    int status;
+    const double posneg = rs_signum(xend - x);
+
+    f(x, y, k1, p);
+    nfev += 1;
+    double h;
+    if (opt->has_first_step) h = fabs(opt->first_step) * posneg;
+    else { nfev += 1; h = hinit(f, p, n, x, y, posneg, k1, k2, y1, 8, h_max, atol, rtol); }
+
+    so_call(so, xold, x, y, NULL, 0.0);
+
+    for (;;) {
+        if (nstep > nmax) { status = ORC_NEED_LARGER_NMAX; break; }
+        if (0.1 * fabs(h) <= fabs(x) * uround) { status = ORC_STEP_SIZE_TOO_SMALL; break; }
+        if (opt->attempt_guard && attempts >= opt->attempt_guard) { status = ORC_NEED_LARGER_NMAX; break; }
+        if ((x + 1.01 * h - xend) * posneg > 0.0) { h = xend - x; last = 1; }
+        nstep += 1;
+        attempts += 1;
+
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * A21 * k1[i];
+        f(x + C2 * h, y1, k2, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A31 * k1[i] + A32 * k2[i]);
+        f(x + C3 * h, y1, k3, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A41 * k1[i] + A43 * k3[i]);
+        f(x + C4 * h, y1, k4, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A51 * k1[i] + A53 * k3[i] + A54 * k4[i]);
+        f(x + C5 * h, y1, k5, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A61 * k1[i] + A64 * k4[i] + A65 * k5[i]);
+        f(x + C6 * h, y1, k6, p);
+        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A71 * k1[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+        f(x + C7 * h, y1, k7, p);
+        for (int i = 0; i < n; i++)
+            y1[i] = y[i] + h * (A81 * k1[i] + A84 * k4[i] + A85 * k5[i] + A86 * k6[i] + A87 * k7[i]);
+        f(x + C8 * h, y1, k8, p);
+        for (int i = 0; i < n; i++)
+            y1[i] = y[i] + h * (A91 * k1[i] + A94 * k4[i] + A95 * k5[i] + A96 * k6[i] + A97 * k7[i] + A98 * k8[i]);
+        f(x + C9 * h, y1, k9, p);
+        for (int i = 0; i < n; i++)
+            y1[i] = y[i] + h * (A101 * k1[i] + A104 * k4[i] + A105 * k5[i] + A106 * k6[i] + A107 * k7[i]
+                                + A108 * k8[i] + A109 * k9[i]);
+        f(x + C10 * h, y1, k10, p);
+        for (int i = 0; i < n; i++)
+            y1[i] = y[i] + h * (A111 * k1[i] + A114 * k4[i] + A115 * k5[i] + A116 * k6[i] + A117 * k7[i]
+                                + A118 * k8[i] + A119 * k9[i] + A1110 * k10[i]);
+        f(x + C11 * h, y1, k2, p);
+        double xph = x + h;
+        for (int i = 0; i < n; i++)
+            y1[i] = y[i] + h * (A121 * k1[i] + A124 * k4[i] + A125 * k5[i] + A126 * k6[i] + A127 * k7[i]
+                                + A128 * k8[i] + A129 * k9[i] + A1210 * k10[i] + A1211 * k2[i]);
+        f(xph, y1, k3, p);
+        nfev += 11;
+
+        for (int i = 0; i < n; i++) {
+            k4[i] = B1 * k1[i] + B6 * k6[i] + B7 * k7[i] + B8 * k8[i] + B9 * k9[i] + B10 * k10[i]
+                  + B11 * k2[i] + B12 * k3[i];
+            k5[i] = y[i] + h * k4[i];
+        }
+
+        double err = 0.0, err2 = 0.0;
+        for (int i = 0; i < n; i++) {
+            double sk = tol_at(atol, i) + tol_at(rtol, i) * fmax(fabs(y[i]), fabs(k5[i]));
+            double erri = k4[i] - BH1 * k1[i] - BH2 * k9[i] - BH3 * k3[i];
+            double q = erri / sk;
+            err2 += q * q; /* powi(2) */
+            erri = ER1 * k1[i] + ER6 * k6[i] + ER7 * k7[i] + ER8 * k8[i] + ER9 * k9[i] + ER10 * k10[i]
+                 + ER11 * k2[i] + ER12 * k3[i];
+            q = erri / sk;
+            err += q * q;
+        }
+        double deno = err + 0.01 * err2;
+        if (deno <= 0.0) deno = 1.0;
+        err = fabs(h) * err * sqrt(1.0 / ((double)n * deno));
+
+        double fac11 = ORC_POW(err, expo1);
+        double fac = fac11 / ORC_POW(facold, beta);
+        fac = fmax(facc2, fmin(facc1, fac / safety));
+        double hnew = h / fac;
+
+        if (err <= 1.0) {
+            facold = fmax(err, 1.0e-4);
+            naccpt += 1;
+            f(xph, k5, k4, p);
+            nfev += 1;
+
+            if ((naccpt % nstiff == 0) || (iasti > 0)) { /* dop853.rs:447-472 */
+                double stnum = 0.0, stden = 0.0;
+                for (int i = 0; i < n; i++) {
+                    double d1 = k4[i] - k3[i];
+                    double d2 = k5[i] - y1[i];
+                    stnum += d1 * d1;
+                    stden += d2 * d2;
+                }
+                if (stden > 0.0) hlamb = fabs(h) * sqrt(stnum / stden);
+                if (hlamb > 6.1) {
+                    nonstiff = 0;
+                    iasti += 1;
+                    if (iasti == 15) { status = ORC_PROBABLY_STIFF; break; }
+                } else {
+                    nonstiff += 1;
+                    if (nonstiff == 6) iasti = 0;
+                }
+            }
+
+            /* dense output, always on (struct default), dop853.rs:476-592 */
+            for (int i = 0; i < n; i++) {
+                cont[i] = y[i];
+                double ydiff = k5[i] - y[i];
+                cont[n + i] = ydiff;
+                double bspl = h * k1[i] - ydiff;
+                cont[2 * n + i] = bspl;
+                cont[3 * n + i] = ydiff - h * k4[i] - bspl;
+                cont[4 * n + i] = D41 * k1[i] + D46 * k6[i] + D47 * k7[i] + D48 * k8[i] + D49 * k9[i]
+                                + D410 * k10[i] + D411 * k2[i] + D412 * k3[i];
+                cont[5 * n + i] = D51 * k1[i] + D56 * k6[i] + D57 * k7[i] + D58 * k8[i] + D59 * k9[i]
+                                + D510 * k10[i] + D511 * k2[i] + D512 * k3[i];
+                cont[6 * n + i] = D61 * k1[i] + D66 * k6[i] + D67 * k7[i] + D68 * k8[i] + D69 * k9[i]
+                                + D610 * k10[i] + D611 * k2[i] + D612 * k3[i];
+                cont[7 * n + i] = D71 * k1[i] + D76 * k6[i] + D77 * k7[i] + D78 * k8[i] + D79 * k9[i]
+                                + D710 * k10[i] + D711 * k2[i] + D712 * k3[i];
+            }
+            for (int i = 0; i < n; i++)
+                y1[i] = y[i] + h * (A141 * k1[i] + A147 * k7[i] + A148 * k8[i] + A149 * k9[i] + A1410 * k10[i]
+                                    + A1411 * k2[i] + A1412 * k3[i] + A1413 * k4[i]);
+            f(x + C14 * h, y1, k10, p);
+            for (int i = 0; i < n; i++)
+                y1[i] = y[i] + h * (A151 * k1[i] + A156 * k6[i] + A157 * k7[i] + A158 * k8[i] + A1511 * k2[i]
+                                    + A1512 * k3[i] + A1513 * k4[i] + A1514 * k10[i]);
+            f(x + C15 * h, y1, k2, p);
+            for (int i = 0; i < n; i++)
+                y1[i] = y[i] + h * (A161 * k1[i] + A166 * k6[i] + A167 * k7[i] + A168 * k8[i] + A169 * k9[i]
+                                    + A1613 * k4[i] + A1614 * k10[i] + A1615 * k2[i]);
+            f(x + C16 * h, y1, k3, p);
+            nfev += 3;
+            for (int i = 0; i < n; i++) {
+                cont[4 * n + i] = h * (cont[4 * n + i] + D413 * k4[i] + D414 * k10[i] + D415 * k2[i] + D416 * k3[i]);
+                cont[5 * n + i] = h * (cont[5 * n + i] + D513 * k4[i] + D514 * k10[i] + D515 * k2[i] + D516 * k3[i]);
+                cont[6 * n + i] = h * (cont[6 * n + i] + D613 * k4[i] + D614 * k10[i] + D615 * k2[i] + D616 * k3[i]);
+                cont[7 * n + i] = h * (cont[7 * n + i] + D713 * k4[i] + D714 * k10[i] + D715 * k2[i] + D716 * k3[i]);
+            }
+
+            memcpy(k1, k4, (size_t)n * sizeof(double));
+            memcpy(y, k5, (size_t)n * sizeof(double));
+            xold = x;
+            x = xph;
+
+            so_call(so, xold, x, y, cont, h);
+
+            if (last) { h = hnew; status = ORC_SUCCESS; break; }
+            if (fabs(hnew) > fabs(h_max)) hnew = posneg * fabs(h_max);
+            if (reject) { hnew = posneg * fmin(fabs(hnew), fabs(h)); reject = 0; }
+        } else {
+            hnew = h / fmin(facc1, fac11 / safety);
+            reject = 1;
+            if (naccpt > 1) nrejct += 1;
+            last = 0;
+        }
+        h = hnew;
+    }
+
+    res->h = h; res->status = status;
+    res->nfev = nfev; res->nstep = nstep; res->naccpt = naccpt; res->nrejct = nrejct;
+    memcpy(y_final, y, (size_t)n * sizeof(double));
+    *x_final = x;
+    free(w);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * RK23 (src/methods/rk23.rs)
+ * ---------------------------------------------------------------------------------------- */
+static int rk23_solve(orc_ode_fn f, const double *p, int n, double x0, const double *y0, double xend,
+                      const tol_t *rtol, const tol_t *atol, const orc_options *opt, solout_t *so,
+                      int_result *res, double *y_final, double *x_final)
+{
+    /* tableau, rk23.rs:325-347 */
+    const double C2 = 0.5, C3 = 0.75, A21 = 0.5, A32 = 0.75;
+    const double B1 = 2.0 / 9.0, B2 = 1.0 / 3.0, B3 = 4.0 / 9.0;
+    const double E1 = 5.0 / 72.0, E2 = -1.0 / 12.0, E3 = -1.0 / 9.0, E4 = 1.0 / 8.0;
+    const double D21 = -4.0 / 3.0, D22 = 1.0, D23 = 4.0 / 3.0, D24 = -1.0;
+    const double D31 = 5.0 / 9.0, D32 = -2.0 / 3.0, D33 = -8.0 / 9.0, D34 = 1.0;
+
+    /* struct defaults, rk23.rs:16-36 */
+    const double safety = 0.9, scale_min = 0.2, scale_max = 10.0;
+    const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE;
+    const double error_exponent = -1.0 / 3.0;
+
+    double x = x0;
+    const double hmax = opt->has_max_step ? fabs(opt->max_step) : fabs(xend - x); /* rk23.rs:135 */
+    double *w = (double *)malloc((size_t)n * (7 + 4) * sizeof(double));
+    double *y = w, *k1 = w + n, *k2 = w + 2 * n, *k3 = w + 3 * n, *k4 = w + 4 * n, *yt = w + 5 * n,
+           *ye = w + 6 * n, *cont = w + 7 * n;
+    memcpy(y, y0, (size_t)n * sizeof(double));
+    memset(k1, 0, (size_t)n * 10 * sizeof(double));
+    uint64_t nfev = 0, nstep = 0, naccpt = 0, nrejct = 0, attempts = 0;
+    int status = ORC_SUCCESS;
+    double xold = x;
+    const double posneg = rs_signum(xend - x);
+
+    f(x, y, k1, p);
+    nfev += 1;
+    double h;
+    if (opt->has_first_step) h = fabs(opt->first_step) * posneg;
+    else { nfev += 1; h = hinit(f, p, n, x, y, posneg, k1, k2, k3, 3, hmax, atol, rtol); }
+
+    so_call(so, xold, x, y, NULL, 0.0);
+
+    for (;;) {
+        if (nstep >= nmax) { status = ORC_NEED_LARGER_NMAX; break; }
+        if (opt->attempt_guard && attempts >= opt->attempt_guard) { status = ORC_NEED_LARGER_NMAX; break; }
+        attempts += 1;
+        if ((x + h - xend) * posneg > 0.0) h = xend - x;
+
+        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A21 * k1[i];
+        f(x + C2 * h, yt, k2, p);
+        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A32 * k2[i];
+        f(x + C3 * h, yt, k3, p);
+        for (int i = 0; i < n; i++) yt[i] = y[i] + h * (B1 * k1[i] + B2 * k2[i] + B3 * k3[i]);
+        f(x + h, yt, k4, p);
+        nfev += 3;
+
+        for (int i = 0; i < n; i++) ye[i] = h * (E1 * k1[i] + E2 * k2[i] + E3 * k3[i] + E4 * k4[i]);
+        double err = 0.0;
+        for (int i = 0; i < n; i++) {
+            double tol = tol_at(atol, i) + tol_at(rtol, i) * fmax(fabs(yt[i]), fabs(y[i]));
+            double q = ye[i] / tol;
+            err += q * q;
+        }
+        err = sqrt(err / (double)n);
+
+        if (err <= 1.0) {
+            nstep += 1;
+            naccpt += 1;
+            memcpy(ye, y, (size_t)n * sizeof(double));
+            memcpy(y, yt, (size_t)n * sizeof(double));
+            xold = x;
+            x += h;
+
+            /* dense (struct default true and solout is Some), rk23.rs:248-255 */
+            memcpy(cont, ye, (size_t)n * sizeof(double));
+            for (int i = 0; i < n; i++) {
+                cont[n + i] = k1[i];
+                cont[2 * n + i] = D21 * k1[i] + D22 * k2[i] + D23 * k3[i] + D24 * k4[i];
+                cont[3 * n + i] = D31 * k1[i] + D32 * k2[i] + D33 * k3[i] + D34 * k4[i];
+            }
+            so_call(so, xold, x, y, cont, h);
+            memcpy(k1, k4, (size_t)n * sizeof(double)); /* ControlFlag::Continue arm, rk23.rs:281-284 */
+
+            h *= fmax(fmin(safety * ORC_POW(err, error_exponent), scale_max), scale_min);
+            if (fabs(h) > hmax) h = hmax * posneg;
+            if (x == xend) break;
+        } else {
+            nrejct += 1;
+            h *= fmax(fmin(safety * ORC_POW(err, error_exponent), 1.0), scale_min);
+        }
+    }
+
+    res->h = h; res->status = status;
+    res->nfev = nfev; res->nstep = nstep; res->naccpt = naccpt; res->nrejct = nrejct;
+    memcpy(y_final, y, (size_t)n * sizeof(double));
+    *x_final = x;
+    free(w);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * solve_ivp (src/solve/solve_ivp.rs:99-313)
+ * ---------------------------------------------------------------------------------------- */
+static void constant_solution(orc_solution *sol, int method, int n, double x0, const double *y0)
+{   /* ContinuousOutput::constant, cont.rs:32-64 */
+    int nc = ncoef_of(method);
+    sol->has_dense = 1;
+    sol->ncoef = nc;
+    sol->nseg = 1;
+    sol->seg_cont = (double *)calloc((size_t)(nc * n > 0 ? nc * n : 1), sizeof(double));
+    for (int i = 0; i < n; i++) sol->seg_cont[i] = y0[i];
+    sol->seg_xold = (double *)malloc(sizeof(double));
+    sol->seg_h = (double *)malloc(sizeof(double));
+    sol->seg_xold[0] = x0;
+    sol->seg_h[0] = 1e-15;
+}
+
+static int solve_core(orc_ode_fn f, const double *params, int n, double x0, double xend, const double *y0,
+                      const orc_options *opt, orc_solution *sol, double *y_final, double *x_final)
+{
+    memset(sol, 0, sizeof(*sol));
+    sol->n = n;
+    sol->ncoef = ncoef_of(opt->method);
+    if (n > 64) return ORC_ERR_BAD_ARGUMENT;
+    if (opt->method < ORC_RK23 || opt->method > ORC_DOP853) return ORC_ERR_BAD_ARGUMENT;
+
+    if (fabs(xend - x0) < 1e-15) { /* solve_ivp.rs:110-145 */
+        if (opt->n_eval >= 0) {
+            size_t m = 0;
+            for (int i = 0; i < opt->n_eval; i++) if (fabs(opt->t_eval[i] - x0) < 1e-12) m++;
+            sol->t = (double *)malloc((m ? m : 1) * sizeof(double));
+            sol->y = (double *)malloc((m ? m : 1) * (size_t)(n ? n : 1) * sizeof(double));
+            size_t k = 0;
+            for (int i = 0; i < opt->n_eval; i++) if (fabs(opt->t_eval[i] - x0) < 1e-12) {
+                sol->t[k] = opt->t_eval[i];
+                memcpy(sol->y + k * (size_t)n, y0, (size_t)n * sizeof(double));
+                k++;
+            }
+            sol->len = m;
+        } else {
+            sol->t = (double *)malloc(sizeof(double));
+            sol->y = (double *)malloc((size_t)(n ? n : 1) * sizeof(double));
+            sol->t[0] = x0;
+            memcpy(sol->y, y0, (size_t)n * sizeof(double));
+            sol->len = 1;
+        }
+        if (opt->dense_output) constant_solution(sol, opt->method, n, x0, y0);
+        sol->status = ORC_SUCCESS;
+        if (y_final) memcpy(y_final, y0, (size_t)n * sizeof(double));
+        if (x_final) *x_final = x0;
+        return ORC_OK;
+    }
+    if (n == 0) { /* solve_ivp.rs:148-176 */
+        size_t m = opt->n_eval >= 0 ? (size_t)opt->n_eval : 2;
+        sol->t = (double *)malloc((m ? m : 1) * sizeof(double));
+        sol->y = (double *)malloc(sizeof(double));
+        if (opt->n_eval >= 0) memcpy(sol->t, opt->t_eval, m * sizeof(double));
+        else { sol->t[0] = x0; sol->t[1] = xend; }
+        sol->len = m;
+        if (opt->dense_output) constant_solution(sol, opt->method, 0, x0, y0);
+        sol->status = ORC_SUCCESS;
+        if (x_final) *x_final = x0;
+        return ORC_OK;
+    }
+
+    tol_t rtol = {opt->rtol, opt->rtol_len}, atol = {opt->atol, opt->atol_len};
+    /* Tolerance::Vector with the wrong length panics in the reference (mod.rs:156-161 / index OOB) */
+    if ((rtol.len != 1 && rtol.len != n) || (atol.len != 1 && atol.len != n))
+        return ORC_ERR_TOLERANCE_SIZE_MISMATCH;
+
+    solout_t so;
+    memset(&so, 0, sizeof(so));
+    so.method = opt->method; so.n = n;
+    so.t_eval = opt->t_eval; so.n_eval = opt->n_eval;
+    so.tol = 1e-12;
+    so.collect_dense = opt->dense_output;
+    so.has_first_step = opt->has_first_step; so.first_step = opt->first_step;
+    so.x0 = x0;
+
+    int_result r;
+    double yf[64], xf = x0;
+    int rc;
+    if (opt->method == ORC_DOPRI5) rc = dopri5_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
+    else if (opt->method == ORC_DOP853) rc = dop853_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
+    else rc = rk23_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
+    if (rc != ORC_OK) {
+        free(so.t); free(so.y); free(so.seg_cont); free(so.seg_xold); free(so.seg_h);
+        return rc;
+    }
+    sol->len = so.len; sol->t = so.t; sol->y = so.y;
+    sol->nfev = r.nfev; sol->njev = 0; sol->nlu = 0;
+    sol->nstep = r.nstep; sol->naccpt = r.naccpt; sol->nrejct = r.nrejct;
+    sol->status = r.status;
+    sol->h_next = r.h;
+    if (opt->dense_output) {
+        sol->has_dense = 1;
+        sol->nseg = so.nseg; sol->seg_cont = so.seg_cont; sol->seg_xold = so.seg_xold; sol->seg_h = so.seg_h;
+    } else {
+        free(so.seg_cont); free(so.seg_xold); free(so.seg_h);
+    }
+    if (y_final) memcpy(y_final, yf, (size_t)n * sizeof(double));
+    if (x_final) *x_final = xf;
+    return ORC_OK;
+}
+
+int orc_solve_ivp(orc_ode_fn f, const double *params, int n, double x0, double xend,
+                  const double *y0, const orc_options *opt, orc_solution *sol)
+{
+    return solve_core(f, params, n, x0, xend, y0, opt, sol, NULL, NULL);
+}
+
+void orc_solution_free(orc_solution *sol)
+{
+    free(sol->t); free(sol->y); free(sol->seg_cont); free(sol->seg_xold); free(sol->seg_h);
+    memset(sol, 0, sizeof(*sol));
+}
+
+/* ContinuousOutput::find_segment, cont.rs:100-117 */
+static long find_segment(const orc_solution *sol, double t)
+{
+    const double tol = 1e-12;
+    for (size_t s = 0; s < sol->nseg; s++) {
+        double a = sol->seg_xold[s], b = sol->seg_xold[s] + sol->seg_h[s];
+        double left = fmin(a, b), right = fmax(a, b);
+        if (t >= left - tol && t <= right + tol) return (long)s;
+    }
+    return -1;
+}
+
+int orc_solution_eval(const orc_solution *sol, int method, double t, double *out)
+{   /* Solution::sol, solution.rs:25-47 */
+    if (!sol->has_dense || sol->nseg == 0) return -1;
+    double start = sol->seg_xold[0];
+    double end = sol->seg_xold[sol->nseg - 1] + sol->seg_h[sol->nseg - 1];
+    double lo = fmin(start, end), hi = fmax(start, end);
+    if (t < lo || t > hi) return -2;
+    long s = find_segment(sol, t);
+    if (s < 0) return -2;
+    interp_any(method, t, out, sol->seg_cont + (size_t)s * sol->ncoef * sol->n, sol->n, sol->seg_xold[s], sol->seg_h[s]);
+    return 0;
+}
+
+int orc_solution_eval_extrapolate(const orc_solution *sol, int method, double t, double *out)
+{   /* cont.rs:119-153 */
+    if (!sol->has_dense || sol->nseg == 0) return -1;
+    long s = find_segment(sol, t);
+    if (s < 0) {
+        size_t L = sol->nseg - 1;
+        double fl = fmin(sol->seg_xold[0], sol->seg_xold[0] + sol->seg_h[0]);
+        double lr = fmax(sol->seg_xold[L], sol->seg_xold[L] + sol->seg_h[L]);
+        if (t < fl) s = 0;
+        else if (t > lr) s = (long)L;
+        else return -2;
+    }
+    interp_any(method, t, out, sol->seg_cont + (size_t)s * sol->ncoef * sol->n, sol->n, sol->seg_xold[s], sol->seg_h[s]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Batch driver
+ * ---------------------------------------------------------------------------------------- */
+int64_t orc_batch_solve(int rhs_id, size_t B, const double *y0, const double *params,
+                        const double *t0, int t0_len, const double *t1, int t1_len,
+                        const orc_options *opt, int threads,
+                        double *y_end, double *t_end, int32_t *status,
+                        uint64_t *nfev, uint64_t *nstep, uint64_t *naccpt, uint64_t *nrejct,
+                        double *h_next, double *y_eval, int32_t *n_filled)
+{
+    int n = 0, np = 0;
+    orc_ode_fn f = orc_builtin_rhs(rhs_id, &n, &np);
+    if (!f) return ORC_ERR_BAD_ARGUMENT;
+    int64_t total = 0;
+    int err = 0;
+    (void)threads;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : total)
+#endif
+    for (long long b = 0; b < (long long)B; b++) {
+        double y0b[8], pb[4], yf[8], xf;
+        for (int i = 0; i < n; i++) y0b[i] = y0[(size_t)i * B + (size_t)b];
+        for (int i = 0; i < np; i++) pb[i] = params[(size_t)i * B + (size_t)b];
+        double a = t0_len == 1 ? t0[0] : t0[b];
+        double e = t1_len == 1 ? t1[0] : t1[b];
+        orc_solution s;
+        int rc = solve_core(f, pb, n, a, e, y0b, opt, &s, yf, &xf);
+        if (rc != ORC_OK) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            err = rc;
+            continue;
+        }
+        for (int i = 0; i < n; i++) y_end[(size_t)i * B + (size_t)b] = yf[i];
+        t_end[b] = xf;
+        status[b] = s.status;
+        if (nfev) nfev[b] = s.nfev;
+        if (nstep) nstep[b] = s.nstep;
+        if (naccpt) naccpt[b] = s.naccpt;
+        if (nrejct) nrejct[b] = s.nrejct;
+        if (h_next) h_next[b] = s.h_next;
+        if (y_eval && opt->n_eval > 0) {
+            size_t m = s.len < (size_t)opt->n_eval ? s.len : (size_t)opt->n_eval;
+            for (size_t k = 0; k < m; k++)
+                for (int i = 0; i < n; i++)
+                    y_eval[(k * (size_t)n + (size_t)i) * B + (size_t)b] = s.y[k * (size_t)n + (size_t)i];
+            if (n_filled) n_filled[b] = (int32_t)m;
+        }
+        total += (int64_t)s.naccpt;
+        orc_solution_free(&s);
+    }
+    if (err) return err;
+    return total;
+}

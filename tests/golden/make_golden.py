@@ -1,0 +1,123 @@
+"""Generates tests/golden/*.json.  Run once in the authoring container:  python tests/golden/make_golden.py
+
+Why SciPy: the reference (Rust crate ivp 0.5.1) cannot be compiled or imported here (no cargo /
+rustc / maturin; `import ivp` -> ModuleNotFoundError) and its test-suite holds no golden
+step-sequence vectors.  SciPy 1.15.3 is an INDEPENDENT implementation that
+shares the published Butcher tableaux (Dormand-Prince 5(4), Hairer's DOP853, Bogacki-Shampine) and
+dense-output polynomials with the reference, so it pins
+
+  (a) one-step results for a fixed step size h (stage arithmetic + tableau, independent of the
+      step-size controller, which differs between SciPy and the reference),
+  (b) the dense-output polynomial inside that step,
+  (c) high-accuracy "truth" end states (DOP853, rtol=atol=1e-13) for the BASELINE workloads.
+
+Only data (inputs and expected outputs) is stored; no reference source text.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+from scipy.integrate import DOP853, RK23, RK45, solve_ivp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from ivp_amd import workloads  # noqa: E402
+
+
+def sho(t, y):
+    return [y[1], -y[0]]
+
+
+def vdp(t, y, mu=1.0):
+    return [y[1], mu * (1.0 - y[0] * y[0]) * y[1] - y[0]]
+
+
+def cr3bp(t, s, mu):
+    x, y, z, vx, vy, vz = s
+    r1 = np.sqrt((x + mu) ** 2 + y * y + z * z)
+    r2 = np.sqrt((x - 1.0 + mu) ** 2 + y * y + z * z)
+    return [vx, vy, vz,
+            x + 2.0 * vy - (1.0 - mu) * (x + mu) / r1 ** 3 - mu * (x - 1.0 + mu) / r2 ** 3,
+            y - 2.0 * vx - (1.0 - mu) * y / r1 ** 3 - mu * y / r2 ** 3,
+            -(1.0 - mu) * z / r1 ** 3 - mu * z / r2 ** 3]
+
+
+def lorenz(t, s, sigma=10.0, rho=28.0, beta=8.0 / 3.0):
+    x, y, z = s
+    return [sigma * (y - x), x * (rho - z) - y, x * y - beta * z]
+
+
+def rational(t, y):
+    return [y[1] / t, y[1] * (y[0] + 2 * y[1] - 1) / (t * (y[0] - 1))]
+
+
+def one_step_cases():
+    cases = []
+    probs = [
+        ("sho", sho, (), 0.0, [1.0, 0.0], 0.05),
+        ("sho", sho, (), 0.0, [1.0, 0.0], -0.03),
+        ("vdp", lambda t, y: vdp(t, y, 1.0), (1.0,), 0.0, [2.0, 0.0], 0.02),
+        ("cr3bp", lambda t, y: cr3bp(t, y, workloads.ARENSTORF_MU), (workloads.ARENSTORF_MU,), 0.0,
+         [0.994, 0.0, 0.0, 0.0, workloads.ARENSTORF_VY0, 0.0], 1e-4),
+        ("lorenz", lorenz, (10.0, 28.0, 8.0 / 3.0), 0.0, [1.0, 1.0, 1.0], 0.01),
+        ("rational", rational, (), 5.0, [1 / 3, 2 / 9], 0.25),
+    ]
+    thetas = [0.0, 0.1, 0.37, 0.5, 0.9, 1.0]
+    for name, f, params, t0, y0, h in probs:
+        for mname, cls in (("RK23", RK23), ("DOPRI5", RK45), ("DOP853", DOP853)):
+            t_bound = t0 + 100.0 * np.sign(h)
+            # loose tolerance so that the first attempt (h = first_step) is accepted by SciPy
+            s = cls(f, t0, y0, t_bound, first_step=abs(h), rtol=1e-2, atol=1e-2)
+            s.step()
+            assert abs((s.t - t0) - h) < 1e-15, (name, mname, s.t - t0, h)
+            d = s.dense_output()
+            cases.append({
+                "rhs": name, "params": list(params), "method": mname, "t0": t0, "y0": list(map(float, y0)),
+                "h": h, "y1": list(map(float, s.y)),
+                "dense_t": [t0 + th * h for th in thetas],
+                "dense_y": [list(map(float, d(t0 + th * h))) for th in thetas],
+            })
+    return cases
+
+
+def truth_cases(nsub=32):
+    out = {}
+    y0, p, t0, t1 = workloads.cr3bp_batch(256)
+    ys = []
+    for b in range(nsub):
+        mu = float(p[0, b])
+        r = solve_ivp(lambda t, y: cr3bp(t, y, mu), (t0, t1), y0[:, b], method="DOP853", rtol=1e-13, atol=1e-13)
+        assert r.success
+        ys.append(list(map(float, r.y[:, -1])))
+        print("cr3bp truth", b, r.nfev, flush=True)
+    out["cr3bp"] = {"seed": 20260102, "B": 256, "subset": nsub, "t1": t1, "y_end": ys}
+    y0, p, t0, t1v = workloads.vdp_batch(256)
+    ys = []
+    for b in range(nsub):
+        r = solve_ivp(lambda t, y: vdp(t, y, 1.0), (t0, float(t1v[b])), y0[:, b], method="DOP853", rtol=1e-13, atol=1e-13)
+        assert r.success
+        ys.append(list(map(float, r.y[:, -1])))
+    out["vdp"] = {"seed": 20260103, "B": 256, "subset": nsub, "y_end": ys}
+    # short-horizon CR3BP (non-chaotic regime): t1 = 2.0
+    y0, p, t0, _ = workloads.cr3bp_batch(256)
+    ys = []
+    for b in range(nsub):
+        mu = float(p[0, b])
+        r = solve_ivp(lambda t, y: cr3bp(t, y, mu), (t0, 2.0), y0[:, b], method="DOP853", rtol=1e-13, atol=1e-13)
+        ys.append(list(map(float, r.y[:, -1])))
+    out["cr3bp_short"] = {"seed": 20260102, "B": 256, "subset": nsub, "t1": 2.0, "y_end": ys}
+    # Lorenz benchmark problem (benches/benchmark.py:129-137) to t=5 (before chaos eats 1e-13)
+    r = solve_ivp(lorenz, (0.0, 5.0), [1.0, 1.0, 1.0], method="DOP853", rtol=1e-13, atol=1e-13)
+    out["lorenz"] = {"t1": 5.0, "y_end": list(map(float, r.y[:, -1]))}
+    return out
+
+
+if __name__ == "__main__":
+    import scipy
+    meta = {"scipy": scipy.__version__, "numpy": np.__version__}
+    with open(os.path.join(HERE, "scipy_one_step.json"), "w") as fh:
+        json.dump({"meta": meta, "cases": one_step_cases()}, fh, indent=1)
+    with open(os.path.join(HERE, "scipy_truth.json"), "w") as fh:
+        json.dump({"meta": meta, "truth": truth_cases()}, fh, indent=1)
+    print("wrote fixtures")

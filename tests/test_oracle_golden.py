@@ -1,0 +1,111 @@
+"""Pins the CPU oracle against the committed SciPy fixtures (tests/golden/, made by make_golden.py)
+and against closed-form solutions.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ivp_amd import workloads
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as fh:
+        return json.load(fh)
+
+
+ONE_STEP = _load("scipy_one_step.json")["cases"]
+TRUTH = _load("scipy_truth.json")["truth"]
+
+
+@pytest.mark.parametrize("case", ONE_STEP, ids=lambda c: f"{c['rhs']}-{c['method']}-h{c['h']}")
+def test_one_step_matches_scipy_tableau(case):
+    """Same published tableau => the first accepted step with h = first_step must agree with SciPy's
+    stepper to rounding, independent of either step-size controller."""
+    t0, h = case["t0"], case["h"]
+    s = O.solve_ivp(case["rhs"], t0, t0 + 100.0 * np.sign(h), case["y0"], params=case["params"],
+                    method=case["method"], rtol=1e-2, atol=1e-2, first_step=abs(h), max_steps=1,
+                    dense_output=True)
+    # max_steps=1: DOPRI5/DOP853 stop once total > nmax, RK23 once total >= nmax; first record is x0
+    assert s.naccpt >= 1
+    assert abs(s.t[1] - (t0 + h)) <= 1e-15 * max(1.0, abs(t0 + h))
+    y1 = np.asarray(case["y1"])
+    np.testing.assert_allclose(s.y[1], y1, rtol=2e-14, atol=1e-15)
+    # dense output polynomial inside the step (Hairer's contd5/contd8 and the cubic of RK23)
+    for td, yd in zip(case["dense_t"], case["dense_y"]):
+        got = s.sol(td)
+        np.testing.assert_allclose(got, np.asarray(yd), rtol=5e-13, atol=5e-14)
+
+
+def test_truth_cr3bp_dop853_tight():
+    """Oracle DOP853 at rtol 1e-12 lands within 1e-6 of SciPy DOP853@1e-13 after one Arenstorf period
+    (the orbit amplifies errors ~1e5x)."""
+    y0, p, t0, t1 = workloads.cr3bp_batch(256)
+    n = TRUTH["cr3bp"]["subset"]
+    r = O.solve_batch("cr3bp", y0[:, :n], p[:, :n], t0, t1, method="DOP853", rtol=1e-12, atol=1e-14)
+    assert (r["status"] == 0).all()
+    err = np.abs(r["y_end"].T - np.asarray(TRUTH["cr3bp"]["y_end"])).max()
+    assert err < 1e-6, err
+
+
+def test_truth_cr3bp_short_horizon_all_methods():
+    y0, p, t0, _ = workloads.cr3bp_batch(256)
+    n = TRUTH["cr3bp_short"]["subset"]
+    truth = np.asarray(TRUTH["cr3bp_short"]["y_end"])
+    for method, rtol, bound in (("RK23", 1e-8, 1e-5), ("DOPRI5", 1e-10, 1e-7), ("DOP853", 1e-12, 1e-9)):
+        r = O.solve_batch("cr3bp", y0[:, :n], p[:, :n], t0, 2.0, method=method, rtol=rtol, atol=rtol * 1e-2)
+        assert (r["status"] == 0).all()
+        err = np.abs(r["y_end"].T - truth).max()
+        assert err < bound, (method, err)
+
+
+def test_truth_vdp_dop853():
+    y0, p, t0, t1 = workloads.vdp_batch(256)
+    n = TRUTH["vdp"]["subset"]
+    r = O.solve_batch("vdp", y0[:, :n], p[:, :n], t0, t1[:n], method="DOP853", rtol=1e-8, atol=1e-10)
+    assert (r["status"] == 0).all()
+    err = np.abs(r["y_end"].T - np.asarray(TRUTH["vdp"]["y_end"])).max()
+    assert err < 1e-5, err
+    assert (r["t_end"] == t1[:n]).all()
+
+
+def test_truth_lorenz():
+    s = O.solve_ivp("lorenz", 0.0, 5.0, [1.0, 1.0, 1.0], params=[10.0, 28.0, 8.0 / 3.0],
+                    method="DOP853", rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(s.y[-1], TRUTH["lorenz"]["y_end"], rtol=0, atol=1e-8)
+
+
+def test_c1_exponential_decay_readme_and_example():
+    # README.md:74,93-101 configuration (BASELINE C1)
+    s = O.solve_ivp("decay", 0.0, 10.0, [1.0], params=[0.5], method="DOPRI5", rtol=1e-6, atol=1e-9)
+    assert s.status == 0 and s.t[0] == 0.0 and s.t[-1] == 10.0
+    assert abs(s.y[-1, 0] - np.exp(-5.0)) < 1e-6
+    # examples/exponential_decay.rs:16-26
+    te = np.arange(11.0)
+    s = O.solve_ivp("decay", 0.0, 10.0, [10.0], params=[0.5], method="DOPRI5", rtol=1e-8, atol=1e-10, t_eval=te)
+    assert (s.t == te).all()
+    assert np.abs(s.y[:, 0] - 10.0 * np.exp(-0.5 * te)).max() < 1e-6
+
+
+def test_detpow_close_to_libm_pow():
+    rng = np.random.default_rng(7)
+    xs = np.exp(rng.uniform(-60, 20, 4000))
+    for e in (0.17, 0.04, 0.125, -1.0 / 3.0, 0.2, 1.0 / 3.0, 1.0 / 8.0):
+        got = np.array([O.detpow(x, e) for x in xs])
+        np.testing.assert_allclose(got, xs ** e, rtol=8e-15)
+    assert O.detpow(0.0, 0.17) == 0.0 and O.detpow(0.0, -1 / 3) == np.inf
+    assert O.detpow(3.0, 0.0) == 1.0 and np.isnan(O.detpow(np.nan, 0.17))
+    assert O.detpow(np.inf, 0.17) == np.inf and O.detpow(np.inf, -0.3) == 0.0
+
+
+def test_detpow_build_tracks_libm_build():
+    """The two oracle builds differ only by a few-ulp step-size factor: same step counts and
+    end states equal to ~1e-12 on a smooth problem."""
+    for m in ("RK23", "DOPRI5", "DOP853"):
+        a = O.solve_ivp("sho", 0.0, 6.0, [1.0, 0.0], method=m, rtol=1e-7, atol=1e-9)
+        b = O.solve_ivp("sho", 0.0, 6.0, [1.0, 0.0], method=m, rtol=1e-7, atol=1e-9, detpow=True)
+        assert (a.naccpt, a.nrejct, a.nfev) == (b.naccpt, b.nrejct, b.nfev)
+        np.testing.assert_allclose(a.y[-1], b.y[-1], rtol=0, atol=1e-12)
