@@ -1,0 +1,226 @@
+/*
+ * ivp_hip.h -- C ABI of libivp_hip.so: the MI355X (gfx950) batched explicit Runge-Kutta integrator.
+ *
+ * This is the drop-in boundary for ONE path of the Rust crate Ryan-D-Gast/ivp 0.5.1: the explicit
+ * RK stepping core (DOPRI5 / DOP853 / RK23 stage evaluation, weighted error norm, step-size
+ * controller, initial-step heuristic) behind solve_ivp().  The reference has no C ABI of its own
+ * (its only exported symbol is the PyO3 module init, src/python/mod.rs:26); the entry points below
+ * are what a `#[link(name = "ivp_hip")] extern "C"` block in the crate would bind -- see
+ * INTEGRATION.md for that binding.  Each declaration cites the reference interface it replaces
+ * (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types;
+ *   - all state is struct-of-arrays: component c of trajectory b lives at a[c*B + b];
+ *   - a "trajectory" is one reference solve_ivp() call; a batch is B independent calls;
+ *   - whole-call validation failures are returned as negative codes (the reference's
+ *     Err(Error::Config(..)) values, src/error.rs:18-60); per-trajectory integration failures are
+ *     reported only in status[b] (the reference's Ok(..) with a non-success Status,
+ *     src/methods/dopri5.rs:268-277); nothing throws or aborts across this boundary;
+ *   - the library never falls back to a CPU path: without a usable HIP device every compute entry
+ *     point returns IVP_ERR_NO_DEVICE.
+ */
+#ifndef IVP_HIP_H
+#define IVP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVP_HIP_ABI_VERSION 1
+
+/* Method: same order as `enum Method`, src/solve/options.rs:14-27. Only the explicit adaptive RK
+ * methods are on the accelerated path; the others return IVP_ERR_UNSUPPORTED_METHOD. */
+typedef enum {
+    IVP_RK23 = 0,
+    IVP_DOPRI5 = 1, /* "RK45" */
+    IVP_DOP853 = 2,
+    IVP_RK4 = 3,
+    IVP_RADAU = 4,
+    IVP_BDF = 5
+} ivp_method_t;
+
+/* Status: same order as `enum Status`, src/status.rs:4-19. */
+typedef enum {
+    IVP_STATUS_SUCCESS = 0,
+    IVP_STATUS_USER_INTERRUPT = 1,
+    IVP_STATUS_NEED_LARGER_NMAX = 2,
+    IVP_STATUS_STEP_SIZE_TOO_SMALL = 3,
+    IVP_STATUS_PROBABLY_STIFF = 4,
+    IVP_STATUS_SINGULAR_MATRIX = 5,
+    IVP_STATUS_POOR_CONVERGENCE = 6
+} ivp_status_t;
+
+/* Return codes. The negative config codes map 1:1 onto `enum ConfigError`, src/error.rs:18-60. */
+typedef enum {
+    IVP_OK = 0,
+    IVP_ERR_MUST_BE_POSITIVE = -1,        /* ConfigError::MustBePositive       */
+    IVP_ERR_OUT_OF_RANGE = -2,            /* ConfigError::OutOfRange           */
+    IVP_ERR_NEGATIVE_TOLERANCE = -3,      /* ConfigError::NegativeTolerance    */
+    IVP_ERR_TOLERANCE_SIZE_MISMATCH = -4, /* ConfigError::ToleranceSizeMismatch (a panic in the reference, src/methods/mod.rs:156-161) */
+    IVP_ERR_INVALID_STEP_SIZE = -5,       /* ConfigError::InvalidStepSize      */
+    IVP_ERR_INVALID_SCALE_FACTORS = -6,   /* ConfigError::InvalidScaleFactors  */
+    IVP_ERR_BAD_ARGUMENT = -100,          /* NULL pointer, unknown rhs id, n mismatch ...            */
+    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RK4 / RADAU / BDF: not on the accelerated path          */
+    IVP_ERR_NO_DEVICE = -102,             /* no HIP device: there is deliberately no CPU fallback    */
+    IVP_ERR_HIP = -103,                   /* a HIP runtime call failed; see ivp_last_error_string()  */
+    IVP_ERR_JIT = -104                    /* hiprtc compilation of a user RHS failed                 */
+} ivp_error_t;
+
+/* Right-hand sides that ship as device functors: the `impl IVP for ..` blocks of the reference's
+ * examples, tests and benchmark (trait IVP::ode, src/ivp.rs:27-29). User-defined systems are
+ * compiled at run time from a HIP source snippet with ivp_rhs_compile(). */
+typedef enum {
+    IVP_RHS_DECAY = 0,    /* y' = -k y                 p={k}           n=1  examples/exponential_decay.rs:9-13 */
+    IVP_RHS_SHO = 1,      /* y0'=y1, y1'=-y0                           n=2  tests/common.rs:3-9                */
+    IVP_RHS_VDP = 2,      /* Van der Pol               p={mu}          n=2  benches/benchmark.py:22-27         */
+    IVP_RHS_CR3BP = 3,    /* restricted 3-body         p={mu}          n=6  examples/cr3bp.rs:23-36            */
+    IVP_RHS_LORENZ = 4,   /* Lorenz                    p={sigma,rho,beta} n=3  benches/benchmark.py:30-37      */
+    IVP_RHS_ZERO = 5,     /* y' = 0                                    n=3  tests/ivp.rs:11-19                 */
+    IVP_RHS_RATIONAL = 6, /* SciPy "rational" problem                  n=2  tests/test_helpers.py:23-25        */
+    IVP_RHS_EXP2 = 7,     /* y' = y                                    n=2  tests/ivp.rs:291-298               */
+    IVP_RHS_BUILTIN_COUNT = 8,
+    IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */
+} ivp_rhs_id_t;
+
+/* The device-side analogue of `impl IVP for T` (src/ivp.rs:27-121). */
+typedef struct {
+    int32_t rhs_id;   /* ivp_rhs_id_t */
+    int32_t n;        /* state dimension (must match the functor's) */
+    int32_t n_params; /* per-trajectory parameters (the fields of the user's struct, e.g. CR3BP{mu}) */
+    void *jit;        /* ivp_rhs_compile() handle when rhs_id == IVP_RHS_JIT, else NULL */
+} ivp_problem_t;
+
+/* Floating-point mode of the kernels. */
+typedef enum {
+    IVP_FP_STRICT = 0, /* no FMA contraction, reference expression order: bit-comparable with a CPU
+                          restatement of the reference (Rust never contracts a*b+c) */
+    IVP_FP_FAST = 1    /* FMA contraction and reciprocal sharing inside the RHS: ~1e-16 relative
+                          differences per operation, faster */
+} ivp_fp_mode_t;
+
+/* Mirrors `struct Options` (src/solve/options.rs:75-123) field by field for the fields the explicit
+ * RK path reads; the remaining fields (jac_storage, mass_storage, nind1-3, min_step) belong to
+ * RADAU/BDF only. Fill with ivp_options_default() first. */
+typedef struct {
+    int32_t method;         /* ivp_method_t; Options.method, default DOPRI5 */
+    double rtol;            /* Options.rtol scalar form, default 1e-3 */
+    double atol;            /* Options.atol scalar form, default 1e-6 */
+    const double *rtol_vec; /* optional per-component rtol[n] (Tolerance::Vector), host pointer */
+    const double *atol_vec; /* optional per-component atol[n], host pointer */
+    int32_t rtol_vec_len;   /* must equal n when rtol_vec != NULL */
+    int32_t atol_vec_len;
+    uint64_t max_steps;     /* Options.max_steps; 0 = None = unlimited (src/solve/solve_ivp.rs:218) */
+    const double *t_eval;   /* Options.t_eval: shared output grid, host pointer, or NULL = None */
+    int64_t n_eval;         /* number of t_eval points (ignored when t_eval == NULL) */
+    int32_t has_first_step; /* Options.first_step is Some(..) */
+    double first_step;
+    int32_t has_max_step;   /* Options.max_step is Some(..) */
+    double max_step;
+    int32_t dense_output;   /* Options.dense_output: record per-step interpolants (needs max_log > 0) */
+    /* ---- knobs that exist only on the GPU path ---- */
+    int32_t fp_mode;        /* ivp_fp_mode_t, default IVP_FP_STRICT */
+    int32_t chunk_attempts; /* step attempts per kernel launch between compactions; 0 = auto */
+    uint32_t max_log;       /* capacity (per trajectory) of the accepted-step log t_log/y_log and of the
+                               dense-segment log; 0 = do not record (end state only) */
+    int32_t profile;        /* 1: time every kernel launch with HIP events (see ivp_run_stats_t) */
+} ivp_options_t;
+
+/* Per-trajectory results: `struct Solution` (src/solve/solution.rs:7-20) + IntegrationResult.h
+ * (src/methods/mod.rs:30-39), struct-of-arrays over the batch. Any pointer may be NULL = not wanted.
+ * For ivp_batch_solve() these are host pointers, for ivp_batch_solve_device() device pointers. */
+typedef struct {
+    double *y_end;      /* [n][B]  state at t_end (Solution.y.last())                           */
+    double *t_end;      /* [B]     final x (xend on Success)                                    */
+    int32_t *status;    /* [B]     ivp_status_t                                                 */
+    uint64_t *nfev;     /* [B]     Solution.nfev  (njev = nlu = 0 on this path)                 */
+    uint64_t *nstep;    /* [B]     Solution.nstep                                               */
+    uint64_t *naccpt;   /* [B]     Solution.naccpt                                              */
+    uint64_t *nrejct;   /* [B]     Solution.nrejct                                              */
+    double *h_next;     /* [B]     IntegrationResult.h: the step the controller would try next  */
+    /* t_eval mode (Options.t_eval = Some): Solution.t/y hold the sampled points, in order */
+    double *y_eval;     /* [n_eval][n][B]  k-th emitted sample of trajectory b                  */
+    int32_t *eval_idx;  /* [n_eval][B]     index into t_eval of the k-th emitted sample         */
+    int32_t *n_filled;  /* [B]             number of emitted samples                            */
+    /* accepted-step mode (Options.t_eval = None, max_log > 0): Solution.t/y, capped at max_log */
+    double *t_log;      /* [max_log][B]                                                         */
+    double *y_log;      /* [max_log][n][B]                                                      */
+    uint32_t *n_log;    /* [B]  number of records the reference would hold (may exceed max_log) */
+    /* dense_output: ContinuousOutput segments (src/solve/cont.rs:9-28), capped at max_log      */
+    double *seg_cont;   /* [max_log][ncoef*n][B]  ncoef = Method::coeffs_per_state (options.rs:34-43) */
+    double *seg_xold;   /* [max_log][B]                                                         */
+    double *seg_h;      /* [max_log][B]                                                         */
+    uint32_t *n_seg;    /* [B]                                                                  */
+} ivp_batch_result_t;
+
+/* What the last solve on a context did (filled when options.profile == 1). */
+typedef struct {
+    uint32_t launches;          /* stepping-kernel launches (chunks)                     */
+    uint32_t init_launches;
+    double step_kernel_ms;      /* sum of HIP-event durations of the stepping kernels    */
+    double init_kernel_ms;
+    double total_ms;            /* first launch -> last kernel done, on the stream       */
+    uint64_t total_accepted;    /* sum over the batch of naccpt                          */
+    uint64_t total_attempts;    /* sum over the batch of step attempts                   */
+    uint64_t lane_attempt_slots;/* sum over launches of (lanes launched x attempts the wave ran): divergence accounting */
+} ivp_run_stats_t;
+
+typedef struct ivp_ctx ivp_ctx_t;
+
+/* Library / device queries. */
+int ivp_abi_version(void);
+int ivp_device_count(void);
+
+/* A context owns the device scratch of one (device, stream) pair; it is not thread-safe, distinct
+ * contexts may be used concurrently (the reference is re-entrant and single-threaded per call,
+ * src/ivp.rs:27). */
+int ivp_ctx_create(ivp_ctx_t **ctx, int device);
+void ivp_ctx_destroy(ivp_ctx_t *ctx);
+const char *ivp_last_error_string(const ivp_ctx_t *ctx);
+int ivp_ctx_get_stats(const ivp_ctx_t *ctx, ivp_run_stats_t *stats);
+
+/* Options::builder().build() defaults (src/solve/options.rs:75-123). */
+void ivp_options_default(ivp_options_t *opt);
+
+/* Dimension lookup for built-in right-hand sides. */
+int ivp_rhs_dims(int32_t rhs_id, int32_t *n, int32_t *n_params);
+
+/*
+ * B independent solve_ivp() calls (src/solve/solve_ivp.rs:99-108:
+ *   solve_ivp(f, x0, xend, y0, options) -> Result<Solution, Error>), host buffers.
+ *   y0[n][B], params[n_params][B] (may be NULL when n_params == 0),
+ *   t0/t1: [B] when *_len == B, or a single shared value when *_len == 1.
+ * Returns IVP_OK or a negative ivp_error_t.
+ */
+int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0,
+                    const double *params, const double *t0, size_t t0_len, const double *t1,
+                    size_t t1_len, const ivp_options_t *opt, ivp_batch_result_t *out);
+
+/*
+ * Same, with every array argument (y0, params, t0, t1 and all `out` members) already resident in
+ * device memory; work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and the
+ * call returns after the stream has drained the integration (it has to poll the active count).
+ * opt->t_eval / rtol_vec / atol_vec stay host pointers.  y_end may alias y0.
+ */
+int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0,
+                           const double *params, const double *t0, size_t t0_len, const double *t1,
+                           size_t t1_len, const ivp_options_t *opt, ivp_batch_result_t *out,
+                           void *hip_stream);
+
+/*
+ * User-defined right-hand side: the device-side `impl IVP for T { fn ode(..) }` (src/ivp.rs:29).
+ * `ode_source` is HIP device code defining
+ *     __device__ void ode(double x, const double* y, double* dydx, const double* p);
+ * for state dimension n and n_params parameters; it is compiled with hiprtc for the context's
+ * device and instantiates the same stepping kernels as the built-ins.  Free with ivp_rhs_free().
+ */
+int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, void **handle);
+void ivp_rhs_free(void *handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVP_HIP_H */

@@ -1,0 +1,19 @@
+"""ivp_amd -- MI355X-native batched explicit Runge-Kutta IVP integrator.
+
+Drop-in for the explicit-RK stepping path of the Rust crate Ryan-D-Gast/ivp (DOPRI5 / DOP853 / RK23
+behind ``solve_ivp``): hand-written HIP kernels for gfx950 behind a C ABI (include/ivp_hip.h), this
+package being the host-side mirror of the reference's ``solve_ivp`` / ``IVP`` / ``Options`` surface.
+"""
+from .api import (  # noqa: F401
+    BUILTIN, CR3BP, BatchSolution, ConfigError, Context, ContinuousOutput, DeviceIVP, Exp2, ExponentialDecay,
+    FpMode, InterpolationError, IVP, IvpError, Lorenz, Method, Options, Rational, SHO, Solution, Status,
+    VanDerPol, ZeroRhs, default_context, solve_ivp, solve_ivp_batch,
+)
+from . import workloads  # noqa: F401
+
+__all__ = [
+    "BUILTIN", "CR3BP", "BatchSolution", "ConfigError", "Context", "ContinuousOutput", "DeviceIVP", "Exp2",
+    "ExponentialDecay", "FpMode", "InterpolationError", "IVP", "IvpError", "Lorenz", "Method", "Options",
+    "Rational", "SHO", "Solution", "Status", "VanDerPol", "ZeroRhs", "default_context", "solve_ivp",
+    "solve_ivp_batch", "workloads",
+]

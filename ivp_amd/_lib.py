@@ -1,0 +1,115 @@
+"""ctypes binding of libivp_hip.so (the C ABI in include/ivp_hip.h).
+
+The library is built in-tree by ``ivp_amd/csrc/Makefile`` (hipcc, gfx950).  There is no Python or
+CPU fallback: if the shared object is missing or no HIP device is present, every compute entry
+point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libivp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class ProblemT(C.Structure):
+    _fields_ = [("rhs_id", C.c_int32), ("n", C.c_int32), ("n_params", C.c_int32), ("jit", C.c_void_p)]
+
+
+class OptionsT(C.Structure):
+    _fields_ = [
+        ("method", C.c_int32),
+        ("rtol", C.c_double), ("atol", C.c_double),
+        ("rtol_vec", c_double_p), ("atol_vec", c_double_p),
+        ("rtol_vec_len", C.c_int32), ("atol_vec_len", C.c_int32),
+        ("max_steps", C.c_uint64),
+        ("t_eval", c_double_p), ("n_eval", C.c_int64),
+        ("has_first_step", C.c_int32), ("first_step", C.c_double),
+        ("has_max_step", C.c_int32), ("max_step", C.c_double),
+        ("dense_output", C.c_int32),
+        ("fp_mode", C.c_int32), ("chunk_attempts", C.c_int32), ("max_log", C.c_uint32), ("profile", C.c_int32),
+    ]
+
+
+class BatchResultT(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in (
+        "y_end", "t_end", "status", "nfev", "nstep", "naccpt", "nrejct", "h_next",
+        "y_eval", "eval_idx", "n_filled", "t_log", "y_log", "n_log",
+        "seg_cont", "seg_xold", "seg_h", "n_seg")]
+
+
+class RunStatsT(C.Structure):
+    _fields_ = [
+        ("launches", C.c_uint32), ("init_launches", C.c_uint32),
+        ("step_kernel_ms", C.c_double), ("init_kernel_ms", C.c_double), ("total_ms", C.c_double),
+        ("total_accepted", C.c_uint64), ("total_attempts", C.c_uint64), ("lane_attempt_slots", C.c_uint64),
+    ]
+
+
+# every symbol include/ivp_hip.h declares
+EXPORTS = (
+    "ivp_abi_version", "ivp_device_count", "ivp_ctx_create", "ivp_ctx_destroy", "ivp_last_error_string",
+    "ivp_ctx_get_stats", "ivp_options_default", "ivp_rhs_dims", "ivp_batch_solve", "ivp_batch_solve_device",
+    "ivp_rhs_compile", "ivp_rhs_free",
+)
+
+ERRORS = {
+    0: "IVP_OK", -1: "IVP_ERR_MUST_BE_POSITIVE", -2: "IVP_ERR_OUT_OF_RANGE", -3: "IVP_ERR_NEGATIVE_TOLERANCE",
+    -4: "IVP_ERR_TOLERANCE_SIZE_MISMATCH", -5: "IVP_ERR_INVALID_STEP_SIZE", -6: "IVP_ERR_INVALID_SCALE_FACTORS",
+    -100: "IVP_ERR_BAD_ARGUMENT", -101: "IVP_ERR_UNSUPPORTED_METHOD", -102: "IVP_ERR_NO_DEVICE",
+    -103: "IVP_ERR_HIP", -104: "IVP_ERR_JIT",
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libivp_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C ivp_amd/csrc` (or __graft_entry__.build()). "
+            "ivp_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.ivp_abi_version.restype = C.c_int
+    L.ivp_device_count.restype = C.c_int
+    L.ivp_ctx_create.restype = C.c_int
+    L.ivp_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.ivp_ctx_destroy.restype = None
+    L.ivp_ctx_destroy.argtypes = [C.c_void_p]
+    L.ivp_last_error_string.restype = C.c_char_p
+    L.ivp_last_error_string.argtypes = [C.c_void_p]
+    L.ivp_ctx_get_stats.restype = C.c_int
+    L.ivp_ctx_get_stats.argtypes = [C.c_void_p, C.POINTER(RunStatsT)]
+    L.ivp_options_default.restype = None
+    L.ivp_options_default.argtypes = [C.POINTER(OptionsT)]
+    L.ivp_rhs_dims.restype = C.c_int
+    L.ivp_rhs_dims.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    solve_args = [C.c_void_p, C.POINTER(ProblemT), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                  C.c_void_p, C.c_size_t, C.POINTER(OptionsT), C.POINTER(BatchResultT)]
+    L.ivp_batch_solve.restype = C.c_int
+    L.ivp_batch_solve.argtypes = solve_args
+    L.ivp_batch_solve_device.restype = C.c_int
+    L.ivp_batch_solve_device.argtypes = solve_args + [C.c_void_p]
+    L.ivp_rhs_compile.restype = C.c_int
+    L.ivp_rhs_compile.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.ivp_rhs_free.restype = None
+    L.ivp_rhs_free.argtypes = [C.c_void_p]
+    _lib = L
+    return L

@@ -1,0 +1,619 @@
+"""Host-side mirror of the reference's solve_ivp()/IVP/Options surface for the GPU path.
+
+Names, argument meaning, defaults and error behaviour follow the Rust crate Ryan-D-Gast/ivp 0.5.1
+(file:line citations are relative to the reference tree):
+
+* ``Method``   -- ``enum Method`` and ``From<&str>``            src/solve/options.rs:13-73
+* ``Options``  -- ``struct Options`` builder defaults           src/solve/options.rs:75-123
+* ``Status``   -- ``enum Status``                               src/status.rs:4-26
+* ``IVP``      -- ``trait IVP`` (the RHS becomes device code)   src/ivp.rs:27-121
+* ``Solution`` -- ``struct Solution`` + sol/sol_many/sol_span   src/solve/solution.rs:7-97
+* ``ContinuousOutput``                                          src/solve/cont.rs:9-153
+* ``solve_ivp``                                                 src/solve/solve_ivp.rs:99-313
+
+Everything numeric runs in libivp_hip.so on the GPU; this module only marshals buffers, maps error
+codes to exceptions and post-processes logged steps/segments on the host (the reference's
+ContinuousOutput is host-side post-processing too).  ``solve_ivp_batch`` is the batched entry point
+the reference does not have: B independent solve_ivp() calls advanced in lock-step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+
+
+# ------------------------------------------------------------------------------------------------
+# enums / errors
+# ------------------------------------------------------------------------------------------------
+class Method(enum.IntEnum):
+    """src/solve/options.rs:13-27 (same discriminant order)."""
+    RK23 = 0
+    DOPRI5 = 1
+    DOP853 = 2
+    RK4 = 3
+    RADAU = 4
+    BDF = 5
+
+    @staticmethod
+    def from_str(s: str) -> "Method":
+        """``impl From<&str> for Method`` (options.rs:61-73): RK45 == DOPRI5, unknown => DOPRI5."""
+        return {
+            "RK23": Method.RK23, "DOPRI5": Method.DOPRI5, "RK45": Method.DOPRI5, "DOP853": Method.DOP853,
+            "RK4": Method.RK4, "RADAU": Method.RADAU, "RADAU5": Method.RADAU, "BDF": Method.BDF, "BDF15": Method.BDF,
+        }.get(str(s).upper(), Method.DOPRI5)
+
+    def coeffs_per_state(self) -> int:
+        """options.rs:34-43."""
+        return {Method.RK4: 4, Method.RK23: 4, Method.DOPRI5: 5, Method.DOP853: 8, Method.RADAU: 4, Method.BDF: 7}[self]
+
+
+class Status(enum.IntEnum):
+    """src/status.rs:4-19."""
+    Success = 0
+    UserInterrupt = 1
+    NeedLargerNMax = 2
+    StepSizeTooSmall = 3
+    ProbablyStiff = 4
+    SingularMatrix = 5
+    PoorConvergence = 6
+
+    def is_success(self) -> bool:
+        return self in (Status.Success, Status.UserInterrupt)
+
+
+class FpMode(enum.IntEnum):
+    STRICT = 0
+    FAST = 1
+
+
+class IvpError(Exception):
+    """``enum Error`` (src/error.rs:7-14)."""
+
+
+class ConfigError(IvpError):
+    """``Error::Config(ConfigError)`` (src/error.rs:18-60); ``code`` is the C ABI value."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_lib.ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class InterpolationError(IvpError):
+    """``Error::Interpolation`` (src/error.rs:72-80)."""
+
+
+# ------------------------------------------------------------------------------------------------
+# IVP: device right-hand sides
+# ------------------------------------------------------------------------------------------------
+class IVP:
+    """Device-side analogue of ``trait IVP`` (src/ivp.rs:27-121).
+
+    A problem is a device functor id (or a JIT handle) plus the values of the user's struct fields,
+    passed per trajectory as ``params``.
+    """
+    rhs_id: int = -1
+    n: int = 0
+    n_params: int = 0
+
+    def params(self) -> Sequence[float]:
+        return ()
+
+    def n_events(self) -> int:  # events are not on the accelerated path
+        return 0
+
+
+@dataclass
+class ExponentialDecay(IVP):  # examples/exponential_decay.rs:5-14
+    k: float = 0.5
+    rhs_id = 0; n = 1; n_params = 1
+    def params(self): return (self.k,)
+
+
+@dataclass
+class SHO(IVP):  # tests/common.rs:3-9
+    rhs_id = 1; n = 2; n_params = 0
+
+
+@dataclass
+class VanDerPol(IVP):  # benches/benchmark.py:22-27
+    mu: float = 1.0
+    rhs_id = 2; n = 2; n_params = 1
+    def params(self): return (self.mu,)
+
+
+@dataclass
+class CR3BP(IVP):  # examples/cr3bp.rs:9-37
+    mu: float = 0.012277471
+    rhs_id = 3; n = 6; n_params = 1
+    def params(self): return (self.mu,)
+
+    def jacobi_constant(self, s):  # examples/cr3bp.rs:14-20
+        x, y, z, vx, vy, vz = s
+        r1 = np.sqrt((x + self.mu) ** 2 + y * y + z * z)
+        r2 = np.sqrt((x - 1.0 + self.mu) ** 2 + y * y + z * z)
+        u = 0.5 * (x * x + y * y) + (1.0 - self.mu) / r1 + self.mu / r2
+        return 2.0 * u - (vx * vx + vy * vy + vz * vz)
+
+
+@dataclass
+class Lorenz(IVP):  # benches/benchmark.py:30-37
+    sigma: float = 10.0
+    rho: float = 28.0
+    beta: float = 8.0 / 3.0
+    rhs_id = 4; n = 3; n_params = 3
+    def params(self): return (self.sigma, self.rho, self.beta)
+
+
+@dataclass
+class ZeroRhs(IVP):  # tests/ivp.rs:11-19
+    rhs_id = 5; n = 3; n_params = 0
+
+
+@dataclass
+class Rational(IVP):  # tests/test_helpers.py:23-25
+    rhs_id = 6; n = 2; n_params = 0
+
+
+@dataclass
+class Exp2(IVP):  # tests/ivp.rs:291-298
+    rhs_id = 7; n = 2; n_params = 0
+
+
+BUILTIN = {"decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
+           "zero": ZeroRhs, "rational": Rational, "exp2": Exp2}
+
+
+class DeviceIVP(IVP):
+    """User-defined system: the device-side ``impl IVP for T { fn ode(&self, x, y, dydx) }``.
+
+    ``source`` is HIP device code defining
+    ``__device__ void ode(double x, const double* y, double* dydx, const double* p)``;
+    ``params`` are the values of the struct's fields (``p[...]`` inside ``ode``).
+    """
+    rhs_id = 1000
+
+    def __init__(self, source: str, n: int, params: Sequence[float] = (), ctx: "Context" = None):
+        self.source = source
+        self.n = int(n)
+        self._params = tuple(float(v) for v in params)
+        self.n_params = len(self._params)
+        self._ctx = ctx or default_context()
+        h = C.c_void_p()
+        rc = self._ctx.lib.ivp_rhs_compile(self._ctx.handle, source.encode(), self.n, self.n_params, C.byref(h))
+        if rc != 0:
+            raise ConfigError(rc, self._ctx.last_error())
+        self.handle = h
+
+    def params(self):
+        return self._params
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._ctx.lib.ivp_rhs_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# Options
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Options:
+    """``Options::builder()...build()`` (src/solve/options.rs:75-123) for the explicit-RK fields, plus
+    the knobs that exist only on the GPU path."""
+    method: Union[Method, str] = Method.DOPRI5
+    rtol: Union[float, Sequence[float]] = 1e-3
+    atol: Union[float, Sequence[float]] = 1e-6
+    max_steps: Optional[int] = None
+    t_eval: Optional[Sequence[float]] = None
+    first_step: Optional[float] = None
+    max_step: Optional[float] = None
+    min_step: Optional[float] = None      # RADAU/BDF only in the reference; ignored by explicit RK
+    dense_output: bool = False
+    # GPU-only
+    fp_mode: FpMode = FpMode.STRICT
+    chunk_attempts: int = 0
+    max_log: int = 0
+    profile: bool = False
+
+    def _c(self, n: int, keep: list) -> _lib.OptionsT:
+        o = _lib.OptionsT()
+        _lib.load().ivp_options_default(C.byref(o))
+        m = self.method if isinstance(self.method, Method) else Method.from_str(self.method)
+        o.method = int(m)
+        for name in ("rtol", "atol"):
+            v = getattr(self, name)
+            if np.isscalar(v):
+                setattr(o, name, float(v))
+            else:
+                arr = np.ascontiguousarray(v, dtype=np.float64)
+                keep.append(arr)
+                setattr(o, name + "_vec", arr.ctypes.data_as(_lib.c_double_p))
+                setattr(o, name + "_vec_len", arr.size)
+        if self.max_steps is not None:
+            if self.max_steps <= 0:
+                # XXX::solve(): nmax == 0 => Err(Config(MustBePositive)) (dopri5.rs:183-189)
+                raise ConfigError(-1, "invalid max_steps: 0 (must be > 0)")
+            o.max_steps = int(self.max_steps)
+        if self.t_eval is not None:
+            te = np.ascontiguousarray(self.t_eval, dtype=np.float64)
+            keep.append(te)
+            o.t_eval = te.ctypes.data_as(_lib.c_double_p) if te.size else C.cast(C.pointer(C.c_double(0.0)), _lib.c_double_p)
+            o.n_eval = te.size
+        if self.first_step is not None:
+            o.has_first_step, o.first_step = 1, float(self.first_step)
+        if self.max_step is not None:
+            o.has_max_step, o.max_step = 1, float(self.max_step)
+        o.dense_output = int(bool(self.dense_output))
+        o.fp_mode = int(self.fp_mode)
+        o.chunk_attempts = int(self.chunk_attempts)
+        o.max_log = int(self.max_log)
+        o.profile = int(bool(self.profile))
+        return o
+
+    @property
+    def method_enum(self) -> Method:
+        return self.method if isinstance(self.method, Method) else Method.from_str(self.method)
+
+
+# ------------------------------------------------------------------------------------------------
+# Context
+# ------------------------------------------------------------------------------------------------
+class Context:
+    """One ``ivp_ctx_t``: device scratch for one (device, stream) pair. Not thread-safe."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.ivp_ctx_create(C.byref(h), int(device))
+        if rc != 0:
+            raise IvpError(f"ivp_ctx_create(device={device}) failed: {_lib.ERRORS.get(rc, rc)} "
+                           "(libivp_hip needs a HIP device; there is no CPU fallback)")
+        self.handle = h
+        self.device = device
+
+    def last_error(self) -> str:
+        return self.lib.ivp_last_error_string(self.handle).decode(errors="replace")
+
+    def stats(self) -> dict:
+        s = _lib.RunStatsT()
+        self.lib.ivp_ctx_get_stats(self.handle, C.byref(s))
+        return {k: getattr(s, k) for k, _ in _lib.RunStatsT._fields_}
+
+    def close(self):
+        if self.handle:
+            self.lib.ivp_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ------------------------------------------------------------------------------------------------
+# Dense output (host post-processing of the logged segments)
+# ------------------------------------------------------------------------------------------------
+def _interpolate(method: Method, xi: float, cont: np.ndarray, n: int, xold: float, h: float) -> np.ndarray:
+    """dopri5.rs:467-478, dop853.rs:659-670, rk23.rs:313-321 (same association)."""
+    c = cont.reshape(-1, n)
+    if method == Method.DOPRI5:
+        th = (xi - xold) / h
+        th1 = 1.0 - th
+        return c[0] + th * (c[1] + th1 * (c[2] + th * (c[3] + th1 * c[4])))
+    if method == Method.DOP853:
+        s = (xi - xold) / h
+        s1 = 1.0 - s
+        conpar = c[4] + s * (c[5] + s1 * (c[6] + s * c[7]))
+        return c[0] + s * (c[1] + s1 * (c[2] + s * (c[3] + s1 * conpar)))
+    xc = (xi - xold) / h
+    x2 = xc * xc
+    x3 = x2 * xc
+    return c[0] + h * (c[1] * xc + c[2] * x2 + c[3] * x3)
+
+
+class ContinuousOutput:
+    """``struct ContinuousOutput`` (src/solve/cont.rs:9-153)."""
+
+    def __init__(self, method: Method, n_states: int, seg_cont: np.ndarray, seg_xold: np.ndarray, seg_h: np.ndarray):
+        keep = seg_h != 0.0  # from_segments filters h == 0 (cont.rs:23)
+        self.method = method
+        self.n_states = n_states
+        self.cont = seg_cont[keep]
+        self.xold = seg_xold[keep]
+        self.h = seg_h[keep]
+
+    @staticmethod
+    def constant(method: Method, x0: float, y0: np.ndarray) -> "ContinuousOutput":
+        n = len(y0)
+        cont = np.zeros((1, method.coeffs_per_state() * n))
+        cont[0, :n] = y0
+        return ContinuousOutput(method, n, cont, np.array([x0]), np.array([1e-15]))
+
+    def t_span(self):
+        if len(self.h) == 0:
+            return None
+        return float(self.xold[0]), float(self.xold[-1] + self.h[-1])
+
+    def _find(self, t: float) -> Optional[int]:
+        tol = 1e-12
+        a, b = self.xold, self.xold + self.h
+        left, right = np.minimum(a, b), np.maximum(a, b)
+        hit = np.nonzero((t >= left - tol) & (t <= right + tol))[0]
+        return int(hit[0]) if hit.size else None
+
+    def evaluate(self, t: float) -> Optional[np.ndarray]:
+        s = self._find(t)
+        if s is None:
+            return None
+        return _interpolate(self.method, t, self.cont[s], self.n_states, self.xold[s], self.h[s])
+
+    def evaluate_many(self, ts) -> List[Optional[np.ndarray]]:
+        return [self.evaluate(t) for t in ts]
+
+    def evaluate_extrapolate(self, t: float) -> Optional[np.ndarray]:
+        if len(self.h) == 0:
+            return None
+        s = self._find(t)
+        if s is None:
+            first_left = min(self.xold[0], self.xold[0] + self.h[0])
+            last_right = max(self.xold[-1], self.xold[-1] + self.h[-1])
+            if t < first_left:
+                s = 0
+            elif t > last_right:
+                s = len(self.h) - 1
+            else:
+                return None
+        return _interpolate(self.method, t, self.cont[s], self.n_states, self.xold[s], self.h[s])
+
+
+# ------------------------------------------------------------------------------------------------
+# Solution
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Solution:
+    """``struct Solution`` (src/solve/solution.rs:7-20); ``y`` is time-major ``[len(t), n]``."""
+    t: np.ndarray
+    y: np.ndarray
+    t_events: list
+    y_events: list
+    nfev: int
+    njev: int
+    nlu: int
+    nstep: int
+    naccpt: int
+    nrejct: int
+    status: Status
+    continuous_sol: Optional[ContinuousOutput] = None
+    h_next: float = 0.0
+
+    def sol(self, t: float) -> np.ndarray:  # solution.rs:25-47
+        dense = self.continuous_sol
+        if dense is None or dense.t_span() is None:
+            raise InterpolationError("NotEnabled")
+        start, end = dense.t_span()
+        lo, hi = min(start, end), max(start, end)
+        if t < lo or t > hi:
+            raise InterpolationError(f"OutOfRange t={t} [{start}, {end}]")
+        out = dense.evaluate(t)
+        if out is None:
+            raise InterpolationError(f"OutOfRange t={t} [{start}, {end}]")
+        return out
+
+    def sol_many(self, ts) -> np.ndarray:  # solution.rs:51-69
+        return np.array([self.sol(t) for t in ts])
+
+    def sol_span(self):  # solution.rs:72-74
+        return None if self.continuous_sol is None else self.continuous_sol.t_span()
+
+    def iter(self):  # solution.rs:77-79
+        return zip(self.t, self.y)
+
+    def __iter__(self):
+        return self.iter()
+
+
+@dataclass
+class BatchSolution:
+    """Struct-of-arrays result of B independent solve_ivp() calls (host numpy or device torch arrays)."""
+    y_end: object
+    t_end: object
+    status: object
+    nfev: object
+    nstep: object
+    naccpt: object
+    nrejct: object
+    h_next: object
+    y_eval: object = None
+    eval_idx: object = None
+    n_filled: object = None
+    t_log: object = None
+    y_log: object = None
+    n_log: object = None
+    seg_cont: object = None
+    seg_xold: object = None
+    seg_h: object = None
+    n_seg: object = None
+    stats: dict = field(default_factory=dict)
+
+
+# ------------------------------------------------------------------------------------------------
+# solve
+# ------------------------------------------------------------------------------------------------
+def _problem_c(f: IVP) -> _lib.ProblemT:
+    p = _lib.ProblemT()
+    p.rhs_id, p.n, p.n_params = int(f.rhs_id), int(f.n), int(f.n_params)
+    p.jit = getattr(f, "handle", None)
+    return p
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ctx: Context = None,
+                    out: BatchSolution = None) -> BatchSolution:
+    """B independent ``solve_ivp(f, t0[b], t1[b], y0[:, b], options)`` calls on the GPU.
+
+    ``y0``: ``[n, B]`` float64, numpy (host path: staged through the library) or a CUDA torch tensor
+    (zero-copy device path on torch's current stream).  ``params``: ``[n_params, B]`` per-trajectory
+    values of the problem struct's fields; defaults to ``f.params()`` broadcast over the batch.
+    ``t0`` / ``t1``: scalars or ``[B]`` arrays of the same kind as ``y0``.
+    """
+    options = options or Options()
+    on_device = _is_torch(y0)
+    if on_device:
+        import torch
+        xp_zeros = lambda shape, dt: torch.zeros(shape, dtype=dt, device=y0.device)
+        f64, i32, u64, u32 = torch.float64, torch.int32, torch.int64, torch.int32
+        if y0.dtype != torch.float64 or not y0.is_contiguous():
+            raise ValueError("y0 must be a contiguous float64 tensor [n, B]")
+        ptr = lambda a: None if a is None else C.c_void_p(a.data_ptr())
+        as_arr = lambda v: (v if _is_torch(v) else torch.as_tensor(np.atleast_1d(np.asarray(v, dtype=np.float64)), device=y0.device))
+        dev_index = y0.device.index or 0
+        ctx = ctx or default_context(dev_index)
+    else:
+        y0 = np.ascontiguousarray(y0, dtype=np.float64)
+        xp_zeros = lambda shape, dt: np.zeros(shape, dtype=dt)
+        f64, i32, u64, u32 = np.float64, np.int32, np.uint64, np.uint32
+        ptr = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        as_arr = lambda v: np.atleast_1d(np.ascontiguousarray(v, dtype=np.float64))
+        ctx = ctx or default_context(0)
+    if y0.ndim != 2 or y0.shape[0] != f.n:
+        raise ValueError(f"y0 must have shape [n={f.n}, B], got {tuple(y0.shape)}")
+    B = int(y0.shape[1])
+    n = f.n
+    if f.n_params:
+        if params is None:
+            pv = np.repeat(np.asarray(f.params(), dtype=np.float64)[:, None], B, axis=1)
+            params = as_arr(pv) if not on_device else __import__("torch").as_tensor(pv, device=y0.device)
+        elif not on_device:
+            params = np.ascontiguousarray(params, dtype=np.float64)
+        if tuple(params.shape) != (f.n_params, B):
+            raise ValueError(f"params must have shape [{f.n_params}, {B}]")
+        if on_device and not params.is_contiguous():
+            params = params.contiguous()
+    else:
+        params = None
+    t0a, t1a = as_arr(t0), as_arr(t1)
+    t0_len, t1_len = int(t0a.shape[0]), int(t1a.shape[0])
+
+    keep: list = []
+    copt = options._c(n, keep)
+    method = options.method_enum
+    ne = 0 if options.t_eval is None else len(options.t_eval)
+    ml = int(options.max_log)
+    nc = method.coeffs_per_state() * n if method in (Method.RK23, Method.DOPRI5, Method.DOP853) else 0
+
+    res = out or BatchSolution(
+        y_end=xp_zeros((n, B), f64), t_end=xp_zeros((B,), f64), status=xp_zeros((B,), i32),
+        nfev=xp_zeros((B,), u64), nstep=xp_zeros((B,), u64), naccpt=xp_zeros((B,), u64),
+        nrejct=xp_zeros((B,), u64), h_next=xp_zeros((B,), f64))
+    if options.t_eval is not None and res.y_eval is None:
+        res.y_eval = xp_zeros((max(ne, 1), n, B), f64)
+        res.eval_idx = xp_zeros((max(ne, 1), B), i32)
+        res.n_filled = xp_zeros((B,), i32)
+    if options.t_eval is None and ml > 0 and res.t_log is None:
+        res.t_log = xp_zeros((ml, B), f64)
+        res.y_log = xp_zeros((ml, n, B), f64)
+        res.n_log = xp_zeros((B,), u32)
+    if options.dense_output and ml > 0 and res.seg_cont is None:
+        res.seg_cont = xp_zeros((ml, nc, B), f64)
+        res.seg_xold = xp_zeros((ml, B), f64)
+        res.seg_h = xp_zeros((ml, B), f64)
+        res.n_seg = xp_zeros((B,), u32)
+
+    r = _lib.BatchResultT()
+    for name, _ in _lib.BatchResultT._fields_:
+        setattr(r, name, ptr(getattr(res, name)))
+    prob = _problem_c(f)
+    if on_device:
+        import torch
+        stream = C.c_void_p(torch.cuda.current_stream(y0.device).cuda_stream)
+        rc = ctx.lib.ivp_batch_solve_device(ctx.handle, C.byref(prob), B, ptr(y0), ptr(params), ptr(t0a), t0_len,
+                                            ptr(t1a), t1_len, C.byref(copt), C.byref(r), stream)
+    else:
+        rc = ctx.lib.ivp_batch_solve(ctx.handle, C.byref(prob), B, ptr(y0), ptr(params), ptr(t0a), t0_len,
+                                     ptr(t1a), t1_len, C.byref(copt), C.byref(r))
+    if rc != 0:
+        raise ConfigError(rc, ctx.last_error())
+    if options.profile:
+        res.stats = ctx.stats()
+    return res
+
+
+def solve_ivp(f: IVP, x0: float, xend: float, y0: Sequence[float], options: Options = None,
+              ctx: Context = None) -> Solution:
+    """``solve_ivp(&f, x0, xend, &y0, options) -> Result<Solution, Error>`` (solve_ivp.rs:99-108) for
+    one trajectory, executed by the GPU kernels (a batch of one).  ``Err(..)`` becomes an exception."""
+    options = options or Options()
+    method = options.method_enum
+    y0 = np.asarray(y0, dtype=np.float64)
+    n = y0.size
+    n_events = f.n_events()
+    if n == 0 or abs(xend - x0) < 1e-15:
+        # Degenerate cases never reach an integrator in the reference either (solve_ivp.rs:110-176):
+        # pure host bookkeeping, no arithmetic of the path.
+        if abs(xend - x0) < 1e-15:
+            if options.t_eval is not None:
+                t = np.array([te for te in options.t_eval if abs(te - x0) < 1e-12], dtype=np.float64)
+            else:
+                t = np.array([x0])
+        else:
+            t = np.asarray(options.t_eval, dtype=np.float64) if options.t_eval is not None else np.array([x0, xend])
+        y = np.repeat(y0[None, :], len(t), axis=0) if n else np.zeros((len(t), 0))
+        cs = ContinuousOutput.constant(method, x0, y0) if options.dense_output else None
+        return Solution(t=t, y=y, t_events=[[] for _ in range(n_events)], y_events=[[] for _ in range(n_events)],
+                        nfev=0, njev=0, nlu=0, nstep=0, naccpt=0, nrejct=0, status=Status.Success, continuous_sol=cs)
+    if n != f.n:
+        raise ValueError(f"y0 has {n} components, problem has {f.n}")
+
+    need_log = options.t_eval is None or options.dense_output
+    cap = options.max_log or (4096 if need_log else 0)
+    while True:
+        o = Options(**{**options.__dict__, "max_log": cap})
+        pr = np.asarray(f.params(), dtype=np.float64).reshape(f.n_params, 1) if f.n_params else None
+        r = solve_ivp_batch(f, x0, xend, y0.reshape(n, 1), pr, o, ctx)
+        used = 0
+        if r.n_log is not None:
+            used = max(used, int(r.n_log[0]))
+        if r.n_seg is not None:
+            used = max(used, int(r.n_seg[0]))
+        if used <= cap or not need_log:
+            break
+        cap = int(used * 1.25) + 16  # the log overflowed: rerun with room for every accepted step
+    if options.t_eval is not None:
+        m = int(r.n_filled[0])
+        te = np.asarray(options.t_eval, dtype=np.float64)
+        t = te[r.eval_idx[:m, 0]] if m else np.zeros(0)
+        y = r.y_eval[:m, :, 0].copy()
+    else:
+        m = int(r.n_log[0])
+        t = r.t_log[:m, 0].copy()
+        y = r.y_log[:m, :, 0].copy()
+    cs = None
+    if options.dense_output:
+        ns = int(r.n_seg[0])
+        cs = ContinuousOutput(method, n, r.seg_cont[:ns, :, 0].copy(), r.seg_xold[:ns, 0].copy(), r.seg_h[:ns, 0].copy())
+    return Solution(t=t, y=y, t_events=[[] for _ in range(n_events)], y_events=[[] for _ in range(n_events)],
+                    nfev=int(r.nfev[0]), njev=0, nlu=0, nstep=int(r.nstep[0]), naccpt=int(r.naccpt[0]),
+                    nrejct=int(r.nrejct[0]), status=Status(int(r.status[0])), continuous_sol=cs,
+                    h_next=float(r.h_next[0]))

@@ -1,0 +1,482 @@
+// ivp_capi.cpp -- host side of libivp_hip.so: the C ABI declared in include/ivp_hip.h.
+//
+// What lives here: option validation (the reference's Err(Error::Config) values), device scratch
+// management, the launch loop (init kernel, then chunks of step attempts with on-device compaction
+// of the still-running set) and result plumbing.  No arithmetic of the integration happens on the
+// host, and there is no CPU fallback: without a HIP device every compute entry point fails.
+#include "../../include/ivp_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ivp_jit.h"
+#include "ivp_kargs.h"
+#include "rk_launch.h"
+
+namespace {
+
+struct RhsDim { int n, p; };
+const RhsDim kRhsDims[IVP_RHS_BUILTIN_COUNT] = {{1, 1}, {2, 0}, {2, 1}, {6, 1}, {3, 3}, {3, 0}, {2, 0}, {2, 0}};
+
+int ncoef_of(int method) { return method == IVP_DOPRI5 ? 5 : method == IVP_DOP853 ? 8 : 4; }
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct ivp_ctx {
+    int device = 0;
+    std::string err;
+    // scratch (device)
+    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval;
+    DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
+    DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
+    // staging for the host-pointer entry point
+    DevBuf st_y0, st_params, st_t0, st_t1;
+    DevBuf st_out[18];
+    uint32_t *pinned = nullptr;  // host-pinned: active count + misc
+    std::vector<hipEvent_t> events;
+    ivp_run_stats_t stats{};
+};
+
+namespace {
+
+int fail(ivp_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail((ctx), IVP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Options validation: the checks XXX::solve() makes before integrating
+// (dopri5.rs:143-198, dop853.rs:135-193, rk23.rs:102-129) for the fields solve_ivp() can set, plus
+// the Tolerance length rule (mod.rs:156-161).
+int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_options_t *opt, int *n_out, int *p_out)
+{
+    if (!prob || !opt) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "null problem/options");
+    int n, p;
+    if (prob->rhs_id == IVP_RHS_JIT) {
+        if (!prob->jit) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "IVP_RHS_JIT without a handle");
+        ivp_jit_dims(prob->jit, &n, &p);
+    } else if (prob->rhs_id >= 0 && prob->rhs_id < IVP_RHS_BUILTIN_COUNT) {
+        n = kRhsDims[prob->rhs_id].n;
+        p = kRhsDims[prob->rhs_id].p;
+    } else {
+        return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown rhs_id %d", prob->rhs_id);
+    }
+    if (prob->n != n || prob->n_params != p)
+        return fail(ctx, IVP_ERR_BAD_ARGUMENT, "problem dims (n=%d,p=%d) do not match rhs (n=%d,p=%d)", prob->n, prob->n_params, n, p);
+    if (n < 1 || n > IVP_MAX_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
+    if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
+    if (opt->method == IVP_RK4 || opt->method == IVP_RADAU || opt->method == IVP_BDF)
+        return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "method %d is not on the accelerated explicit-RK path", opt->method);
+    if (opt->method < IVP_RK23 || opt->method > IVP_DOP853) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown method %d", opt->method);
+    if (opt->rtol_vec && opt->rtol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "rtol: expected %d, got %d", n, opt->rtol_vec_len);
+    if (opt->atol_vec && opt->atol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "atol: expected %d, got %d", n, opt->atol_vec_len);
+    if (opt->t_eval && opt->n_eval < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative n_eval");
+    if (opt->t_eval && opt->n_eval > 0x7FFFFFFFll) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "n_eval too large");
+    if (opt->fp_mode != IVP_FP_STRICT && opt->fp_mode != IVP_FP_FAST) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown fp_mode");
+    if (opt->chunk_attempts < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative chunk_attempts");
+    *n_out = n;
+    *p_out = p;
+    return IVP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivp_abi_version(void) { return IVP_HIP_ABI_VERSION; }
+
+int ivp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ivp_ctx_create(ivp_ctx_t **out, int device)
+{
+    if (!out) return IVP_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return IVP_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return IVP_ERR_BAD_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return IVP_ERR_HIP;
+    ivp_ctx *c = new ivp_ctx();
+    c->device = device;
+    if (hipHostMalloc((void **)&c->pinned, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return IVP_ERR_HIP;
+    }
+    *out = c;
+    return IVP_OK;
+}
+
+void ivp_ctx_destroy(ivp_ctx_t *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval,
+                      &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
+                      &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
+                      &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1};
+    for (DevBuf *b : bufs) b->release();
+    for (DevBuf &b : c->st_out) b.release();
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    delete c;
+}
+
+const char *ivp_last_error_string(const ivp_ctx_t *c) { return c ? c->err.c_str() : "no context"; }
+
+int ivp_ctx_get_stats(const ivp_ctx_t *c, ivp_run_stats_t *s)
+{
+    if (!c || !s) return IVP_ERR_BAD_ARGUMENT;
+    *s = c->stats;
+    return IVP_OK;
+}
+
+void ivp_options_default(ivp_options_t *o)
+{   // Options::builder().build(), src/solve/options.rs:75-123
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->method = IVP_DOPRI5;
+    o->rtol = 1e-3;
+    o->atol = 1e-6;
+    o->fp_mode = IVP_FP_STRICT;
+}
+
+int ivp_rhs_dims(int32_t rhs_id, int32_t *n, int32_t *np)
+{
+    if (rhs_id < 0 || rhs_id >= IVP_RHS_BUILTIN_COUNT) return IVP_ERR_BAD_ARGUMENT;
+    if (n) *n = kRhsDims[rhs_id].n;
+    if (np) *np = kRhsDims[rhs_id].p;
+    return IVP_OK;
+}
+
+int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0, const double *params,
+                           const double *t0, size_t t0_len, const double *t1, size_t t1_len, const ivp_options_t *opt,
+                           ivp_batch_result_t *out, void *hip_stream)
+{
+    if (!ctx) return IVP_ERR_BAD_ARGUMENT;
+    ctx->err.clear();
+    int n = 0, np = 0;
+    int rc = validate(ctx, prob, B, opt, &n, &np);
+    if (rc != IVP_OK) return rc;
+    if (!y0 || !t0 || !t1 || !out) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "null y0/t0/t1/out");
+    if (np > 0 && !params) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
+    if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+
+    const bool want_eval = opt->t_eval != nullptr;
+    const bool want_log = !want_eval && opt->max_log > 0 && out->t_log && out->y_log;
+    const bool want_dense = opt->dense_output && opt->max_log > 0 && out->seg_cont && out->seg_xold && out->seg_h;
+    const bool full = want_eval || want_log || want_dense;
+    if (want_eval && opt->n_eval > 0 && !out->y_eval) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t_eval given but out.y_eval is NULL");
+    if (opt->dense_output && !want_dense) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "dense_output needs max_log > 0 and seg_cont/seg_xold/seg_h");
+
+    IvpKArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.B = (uint32_t)B;
+    a.y0 = y0;
+    a.params = params;
+    a.t0 = t0;
+    a.t1 = t1;
+    a.t0_stride = t0_len == 1 ? 0u : 1u;
+    a.t1_stride = t1_len == 1 ? 0u : 1u;
+    for (int i = 0; i < IVP_MAX_N; ++i) {
+        a.rtol[i] = (opt->rtol_vec && i < n) ? opt->rtol_vec[i] : opt->rtol;
+        a.atol[i] = (opt->atol_vec && i < n) ? opt->atol_vec[i] : opt->atol;
+    }
+    a.first_step = opt->first_step;
+    a.max_step = opt->max_step;
+    a.has_first_step = opt->has_first_step ? 1 : 0;
+    a.has_max_step = opt->has_max_step ? 1 : 0;
+    a.nmax = opt->max_steps ? opt->max_steps : UINT64_MAX;  // None => usize::MAX, solve_ivp.rs:218
+
+    // ---- state / result arrays: the caller's buffers where given, context scratch otherwise ----
+#define BIND(field, userptr, scratch, bytes)                                   \
+    do {                                                                       \
+        if (userptr) a.field = userptr;                                        \
+        else {                                                                 \
+            HIP_TRY(ctx, ctx->scratch.reserve(bytes));                         \
+            a.field = (decltype(a.field))ctx->scratch.p;                       \
+        }                                                                      \
+    } while (0)
+    BIND(y, out->y_end, sc_y, sizeof(double) * n * B);
+    BIND(x, out->t_end, sc_x, sizeof(double) * B);
+    BIND(h, out->h_next, sc_h, sizeof(double) * B);
+    BIND(status, out->status, sc_status, sizeof(int32_t) * B);
+    BIND(nfev, out->nfev, sc_nfev, sizeof(uint64_t) * B);
+    BIND(nstep, out->nstep, sc_nstep, sizeof(uint64_t) * B);
+    BIND(naccpt, out->naccpt, sc_naccpt, sizeof(uint64_t) * B);
+    BIND(nrejct, out->nrejct, sc_nrejct, sizeof(uint64_t) * B);
+    HIP_TRY(ctx, ctx->k1.reserve(sizeof(double) * n * B));
+    HIP_TRY(ctx, ctx->facold.reserve(sizeof(double) * B));
+    HIP_TRY(ctx, ctx->hlamb.reserve(sizeof(double) * B));
+    HIP_TRY(ctx, ctx->flags.reserve(sizeof(uint32_t) * B));
+    HIP_TRY(ctx, ctx->perm[0].reserve(sizeof(uint32_t) * B));
+    HIP_TRY(ctx, ctx->perm[1].reserve(sizeof(uint32_t) * B));
+    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 4));
+    a.k1 = (double *)ctx->k1.p;
+    a.facold = (double *)ctx->facold.p;
+    a.hlamb = (double *)ctx->hlamb.p;
+    a.flags = (uint32_t *)ctx->flags.p;
+
+    a.n_eval = -1;
+    if (full) {
+        if (want_eval) {
+            a.n_eval = (int32_t)opt->n_eval;
+            HIP_TRY(ctx, ctx->teval.reserve(sizeof(double) * std::max<int64_t>(opt->n_eval, 1)));
+            if (opt->n_eval > 0)
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->teval.p, opt->t_eval, sizeof(double) * opt->n_eval, hipMemcpyHostToDevice, s));
+            a.t_eval = (const double *)ctx->teval.p;
+            a.y_eval = out->y_eval;
+            a.eval_idx = out->eval_idx;
+        }
+        BIND(n_filled, out->n_filled, sc_n_filled, sizeof(int32_t) * B);
+        BIND(n_log, out->n_log, sc_n_log, sizeof(uint32_t) * B);
+        BIND(n_seg, out->n_seg, sc_n_seg, sizeof(uint32_t) * B);
+        HIP_TRY(ctx, ctx->sc_next_idx.reserve(sizeof(int32_t) * B));
+        HIP_TRY(ctx, ctx->sc_t_last.reserve(sizeof(double) * B));
+        a.next_idx = (int32_t *)ctx->sc_next_idx.p;
+        a.t_last = (double *)ctx->sc_t_last.p;
+        a.max_log = (want_log || want_dense) ? opt->max_log : 0;
+        if (want_log) {
+            a.t_log = out->t_log;
+            a.y_log = out->y_log;
+        }
+        a.collect_dense = want_dense ? 1 : 0;
+        a.seg_cont = out->seg_cont;
+        a.seg_xold = out->seg_xold;
+        a.seg_h = out->seg_h;
+    }
+#undef BIND
+
+    const bool profile = opt->profile != 0;
+    ctx->stats = ivp_run_stats_t{};
+    if (profile) {
+        HIP_TRY(ctx, ctx->slot.reserve(sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->slot.p, 0, sizeof(unsigned long long), s));
+        a.slot_counter = (unsigned long long *)ctx->slot.p;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 4, s));
+
+    auto launch = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast : ivp_launch_strict;
+    const bool jit = prob->rhs_id == IVP_RHS_JIT;
+    auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
+        if (jit) return ivp_jit_launch(prob->jit, what, opt->method, opt->fp_mode, full, ka, lanes, s);
+        return launch(what, opt->method, prob->rhs_id, full, ka, lanes, s);
+    };
+
+    size_t ev_used = 0;
+    auto ev = [&](void) -> hipEvent_t {
+        if (ev_used == ctx->events.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ctx->events.push_back(e);
+        }
+        return ctx->events[ev_used++];
+    };
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> step_ev;
+    hipEvent_t ev_t0 = nullptr, ev_init1 = nullptr, ev_end = nullptr;
+
+    // ---- init: f0, hinit / first_step, initial SolOut call ----
+    a.chunk = 0;
+    a.perm_in = nullptr;
+    a.count_in = nullptr;
+    a.perm_out = nullptr;
+    a.count_out = nullptr;
+    if (profile) { ev_t0 = ev(); HIP_TRY(ctx, hipEventRecord(ev_t0, s)); }
+    HIP_TRY(ctx, do_launch(IVP_LAUNCH_INIT, a, (uint32_t)B));
+    if (profile) { ev_init1 = ev(); HIP_TRY(ctx, hipEventRecord(ev_init1, s)); }
+    ctx->stats.init_launches = 1;
+
+    // ---- chunks of step attempts; the still-running ids are compacted on the device ----
+    const uint32_t chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : 64u;
+    const int launches_per_sync = 4;
+    uint32_t *counts = (uint32_t *)ctx->counts.p;
+    uint32_t lanes = (uint32_t)B;
+    uint64_t c = 0;  // chunk number
+    for (;;) {
+        for (int r = 0; r < launches_per_sync; ++r, ++c) {
+            IvpKArgs ka = a;
+            ka.chunk = chunk;
+            if (c == 0) {
+                ka.perm_in = nullptr;
+                ka.count_in = nullptr;
+            } else {
+                ka.perm_in = (const uint32_t *)ctx->perm[(c - 1) & 1].p;
+                ka.count_in = counts + ((c - 1) & 3);
+            }
+            ka.perm_out = (uint32_t *)ctx->perm[c & 1].p;
+            ka.count_out = counts + (c & 3);
+            // slot (c+1)&3 is the next launch's count_out: it was zeroed by the initial memset (c = 0) or has to
+            // be reset now; nothing reads it during this launch.
+            if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (profile) { e0 = ev(); HIP_TRY(ctx, hipEventRecord(e0, s)); }
+            HIP_TRY(ctx, do_launch(IVP_LAUNCH_CHUNK, ka, lanes));
+            if (profile) { e1 = ev(); HIP_TRY(ctx, hipEventRecord(e1, s)); step_ev.emplace_back(e0, e1); }
+            ctx->stats.launches += 1;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        lanes = ctx->pinned[0];
+        if (lanes == 0) break;
+    }
+
+    if (profile) {
+        ev_end = ev();
+        HIP_TRY(ctx, hipEventRecord(ev_end, s));
+        HIP_TRY(ctx, hipEventSynchronize(ev_end));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_t0, ev_init1));
+        ctx->stats.init_kernel_ms = ms;
+        for (auto &pr : step_ev) {
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+            ctx->stats.step_kernel_ms += ms;
+        }
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_t0, ev_end));
+        ctx->stats.total_ms = ms;
+        unsigned long long slots = 0;
+        HIP_TRY(ctx, hipMemcpy(&slots, ctx->slot.p, sizeof slots, hipMemcpyDeviceToHost));
+        ctx->stats.lane_attempt_slots = slots;
+        std::vector<uint64_t> tmp(B);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), a.naccpt, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+        uint64_t acc = 0, att = 0;
+        for (uint64_t v : tmp) acc += v;
+        ctx->stats.total_accepted = acc;
+        if (opt->method == IVP_RK23) {  // RK23 counts only accepted steps in nstep (rk23.rs:238)
+            HIP_TRY(ctx, hipMemcpy(tmp.data(), a.nrejct, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+            att = acc;
+            for (uint64_t v : tmp) att += v;
+        } else {
+            HIP_TRY(ctx, hipMemcpy(tmp.data(), a.nstep, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+            for (uint64_t v : tmp) att += v;
+        }
+        ctx->stats.total_attempts = att;
+    }
+    return IVP_OK;
+}
+
+int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0, const double *params,
+                    const double *t0, size_t t0_len, const double *t1, size_t t1_len, const ivp_options_t *opt,
+                    ivp_batch_result_t *out)
+{
+    if (!ctx) return IVP_ERR_BAD_ARGUMENT;
+    ctx->err.clear();
+    int n = 0, np = 0;
+    int rc = validate(ctx, prob, B, opt, &n, &np);
+    if (rc != IVP_OK) return rc;
+    if (!y0 || !t0 || !t1 || !out) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "null y0/t0/t1/out");
+    if (np > 0 && !params) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
+    if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    const size_t ne = opt->t_eval ? (size_t)opt->n_eval : 0;
+    const size_t ml = opt->max_log;
+    const size_t nc = (size_t)ncoef_of(opt->method) * n;
+
+    HIP_TRY(ctx, ctx->st_y0.reserve(sizeof(double) * n * B));
+    HIP_TRY(ctx, ctx->st_params.reserve(sizeof(double) * std::max(np, 1) * B));
+    HIP_TRY(ctx, ctx->st_t0.reserve(sizeof(double) * t0_len));
+    HIP_TRY(ctx, ctx->st_t1.reserve(sizeof(double) * t1_len));
+    HIP_TRY(ctx, hipMemcpy(ctx->st_y0.p, y0, sizeof(double) * n * B, hipMemcpyHostToDevice));
+    if (np > 0) HIP_TRY(ctx, hipMemcpy(ctx->st_params.p, params, sizeof(double) * np * B, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->st_t0.p, t0, sizeof(double) * t0_len, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->st_t1.p, t1, sizeof(double) * t1_len, hipMemcpyHostToDevice));
+
+    // device mirrors of every requested output
+    struct Slot { void *host; size_t bytes; void **dev; };
+    ivp_batch_result_t d;
+    std::memset(&d, 0, sizeof d);
+    Slot slots[18] = {
+        {out->y_end, sizeof(double) * n * B, (void **)&d.y_end},
+        {out->t_end, sizeof(double) * B, (void **)&d.t_end},
+        {out->status, sizeof(int32_t) * B, (void **)&d.status},
+        {out->nfev, sizeof(uint64_t) * B, (void **)&d.nfev},
+        {out->nstep, sizeof(uint64_t) * B, (void **)&d.nstep},
+        {out->naccpt, sizeof(uint64_t) * B, (void **)&d.naccpt},
+        {out->nrejct, sizeof(uint64_t) * B, (void **)&d.nrejct},
+        {out->h_next, sizeof(double) * B, (void **)&d.h_next},
+        {out->y_eval, sizeof(double) * ne * n * B, (void **)&d.y_eval},
+        {out->eval_idx, sizeof(int32_t) * ne * B, (void **)&d.eval_idx},
+        {out->n_filled, sizeof(int32_t) * B, (void **)&d.n_filled},
+        {out->t_log, sizeof(double) * ml * B, (void **)&d.t_log},
+        {out->y_log, sizeof(double) * ml * n * B, (void **)&d.y_log},
+        {out->n_log, sizeof(uint32_t) * B, (void **)&d.n_log},
+        {out->seg_cont, sizeof(double) * ml * nc * B, (void **)&d.seg_cont},
+        {out->seg_xold, sizeof(double) * ml * B, (void **)&d.seg_xold},
+        {out->seg_h, sizeof(double) * ml * B, (void **)&d.seg_h},
+        {out->n_seg, sizeof(uint32_t) * B, (void **)&d.n_seg},
+    };
+    for (int i = 0; i < 18; ++i) {
+        if (slots[i].host && slots[i].bytes) {
+            HIP_TRY(ctx, ctx->st_out[i].reserve(slots[i].bytes));
+            *slots[i].dev = ctx->st_out[i].p;
+        }
+    }
+    rc = ivp_batch_solve_device(ctx, prob, B, (const double *)ctx->st_y0.p, np > 0 ? (const double *)ctx->st_params.p : nullptr,
+                                (const double *)ctx->st_t0.p, t0_len, (const double *)ctx->st_t1.p, t1_len, opt, &d, nullptr);
+    if (rc != IVP_OK) return rc;
+    for (int i = 0; i < 18; ++i)
+        if (slots[i].host && slots[i].bytes)
+            HIP_TRY(ctx, hipMemcpy(slots[i].host, *slots[i].dev, slots[i].bytes, hipMemcpyDeviceToHost));
+    return IVP_OK;
+}
+
+int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, void **handle)
+{
+    if (!ctx || !ode_source || !handle) return IVP_ERR_BAD_ARGUMENT;
+    if (n < 1 || n > IVP_MAX_N || n_params < 0 || n_params > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
+    std::string log;
+    int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, handle, &log);
+    if (rc != IVP_OK) ctx->err = log;
+    return rc;
+}
+
+void ivp_rhs_free(void *handle) { ivp_jit_free(handle); }
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// ivp_jit.cpp -- user-defined right-hand sides compiled at run time with hiprtc.
+//
+// The reference lets a user implement `trait IVP { fn ode(&self, x, y, dydx) }` (src/ivp.rs:27-29)
+// in host Rust.  On the GPU the right-hand side has to be device code, so the analogue is a HIP
+// source snippet defining
+//     __device__ void ode(double x, const double* y, double* dydx, const double* p);
+// which is spliced in front of the very same kernel templates the built-in functors use
+// (ivp_kargs.h + rk_core.h + rk_global.h are embedded in the library as text) and compiled for the
+// context's gfx target.  One module per (method, output mode, fp mode) is built on first use.
+#include "ivp_jit.h"
+
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/ivp_hip.h"
+#include "rk_launch.h"
+#include "ivp_jit_sources.inc"
+
+namespace {
+
+struct JitModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t init = nullptr, chunk = nullptr;
+};
+
+struct JitRhs {
+    int device, n, np;
+    std::string ode_source;
+    std::string arch;
+    std::mutex mu;
+    std::map<std::tuple<int, int, bool>, JitModule> modules;  // (method, fp_mode, full)
+    std::string log;
+};
+
+std::string join(const char *const *parts)
+{
+    std::string s;
+    for (; *parts; ++parts) s += *parts;
+    return s;
+}
+
+std::string build_source(const JitRhs &r, int method, bool full)
+{
+    std::string s;
+    s += "typedef unsigned int uint32_t;\ntypedef int int32_t;\ntypedef unsigned long long uint64_t;\ntypedef long long int64_t;\n";
+    s += "#define IVP_HD __device__ __forceinline__\n";
+    s += "#define IVP_NS ivp_jit\n";
+    s += join(k_src_ivp_kargs_h);
+    s += "\n// ---- user right-hand side ----\n";
+    s += r.ode_source;
+    s += "\n// ---- integrator ----\n";
+    s += join(k_src_rk_core_h);
+    s += join(k_src_rk_global_h);
+    char buf[1024];
+    std::snprintf(buf, sizeof buf,
+                  "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d };\n"
+                  "  static IVP_HD void ode(double x, const double* y, double* d, const double* p) { ::ode(x, y, d, p); } }; }\n"
+                  "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a)\n"
+                  "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
+                  "extern \"C\" __global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void ivp_jit_chunk(const IvpKArgs a)\n"
+                  "{ ivp_jit::chunk_kernel_body<%d, ivp_jit::RhsUser, %s>(a); }\n",
+                  r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false");
+    s += buf;
+    return s;
+}
+
+int compile_module(JitRhs &r, int method, int fp_mode, bool full, JitModule *out)
+{
+    const std::string src = build_source(r, method, full);
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "ivp_user_rhs.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        r.log = "hiprtcCreateProgram failed";
+        return IVP_ERR_JIT;
+    }
+    const std::string arch = "--offload-arch=" + r.arch;
+    std::vector<const char *> opts = {arch.c_str(), "-O3", "-std=c++17"};
+    opts.push_back(fp_mode == IVP_FP_FAST ? "-ffp-contract=fast" : "-ffp-contract=off");
+    opts.push_back(fp_mode == IVP_FP_FAST ? "-DIVP_FAST=1" : "-DIVP_FAST=0");
+    const hiprtcResult cr = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    if (cr != HIPRTC_SUCCESS) {
+        r.log = "hiprtc: " + log;
+        hiprtcDestroyProgram(&prog);
+        return IVP_ERR_JIT;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    if (!out) return IVP_OK;  // compile-only check
+    if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) { r.log = "hipModuleLoadData failed"; return IVP_ERR_HIP; }
+    if (hipModuleGetFunction(&out->init, out->mod, "ivp_jit_init") != hipSuccess ||
+        hipModuleGetFunction(&out->chunk, out->mod, "ivp_jit_chunk") != hipSuccess) {
+        r.log = "kernel lookup failed";
+        return IVP_ERR_HIP;
+    }
+    return IVP_OK;
+}
+
+}  // namespace
+
+int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, void **handle, std::string *log)
+{
+    JitRhs *r = new JitRhs();
+    r->device = device;
+    r->n = n;
+    r->np = n_params;
+    r->ode_source = ode_source;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0]) {
+        r->arch = prop.gcnArchName;
+        const size_t colon = r->arch.find(':');  // "gfx950:sramecc+:xnack-" -> "gfx950"
+        if (colon != std::string::npos) r->arch.resize(colon);
+    } else {
+        r->arch = "gfx950";
+    }
+    // compile the default configuration now so that syntax errors surface at ivp_rhs_compile() time
+    const int rc = compile_module(*r, IVP_DOPRI5, IVP_FP_STRICT, false, nullptr);
+    if (rc != IVP_OK) {
+        if (log) *log = r->log;
+        delete r;
+        return rc;
+    }
+    *handle = r;
+    return IVP_OK;
+}
+
+void ivp_jit_free(void *handle)
+{
+    JitRhs *r = (JitRhs *)handle;
+    if (!r) return;
+    for (auto &kv : r->modules)
+        if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    delete r;
+}
+
+void ivp_jit_dims(void *handle, int *n, int *np)
+{
+    JitRhs *r = (JitRhs *)handle;
+    *n = r->n;
+    *np = r->np;
+}
+
+hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool full, const IvpKArgs &a, uint32_t lanes,
+                          hipStream_t s)
+{
+    JitRhs *r = (JitRhs *)handle;
+    JitModule m;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        auto key = std::make_tuple(method, fp_mode, full);
+        auto it = r->modules.find(key);
+        if (it == r->modules.end()) {
+            JitModule nm;
+            if (compile_module(*r, method, fp_mode, full, &nm) != IVP_OK) {
+                std::fprintf(stderr, "ivp_hip: JIT build failed: %s\n", r->log.c_str());
+                return hipErrorInvalidValue;
+            }
+            it = r->modules.emplace(key, nm).first;
+        }
+        m = it->second;
+    }
+    const unsigned grid = (lanes + IVP_WAVE - 1) / IVP_WAVE;
+    if (grid == 0) return hipSuccess;
+    IvpKArgs ka = a;
+    void *args[] = {&ka};
+    return hipModuleLaunchKernel(what == IVP_LAUNCH_INIT ? m.init : m.chunk, grid, 1, 1, IVP_WAVE, 1, 1, 0, s, args, nullptr);
+}

@@ -1,0 +1,11 @@
+// ivp_jit.h -- run-time compiled right-hand sides (hiprtc): the device-side `impl IVP for T`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include "ivp_kargs.h"
+
+int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, void **handle, std::string *log);
+void ivp_jit_free(void *handle);
+void ivp_jit_dims(void *handle, int *n, int *n_params);
+hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool full, const IvpKArgs &a,
+                          uint32_t lanes, hipStream_t s);

@@ -1,0 +1,73 @@
+// ivp_kargs.h -- kernel argument block shared by the host library and the gfx950 kernels.
+#pragma once
+#ifndef __HIPCC_RTC__
+#include <stdint.h>
+#endif
+
+#define IVP_MAX_N 8        // largest state dimension a thread-per-trajectory kernel keeps in VGPRs
+#define IVP_MAX_P 4
+#define IVP_WAVE 64        // CDNA wavefront
+#define IVP_RUNNING (-1)   // status[] sentinel while a trajectory is still being integrated
+
+// flags[] bit layout (per trajectory, persists between chunk launches)
+#define IVP_F_LAST      0x1u          // `last`   (dopri5.rs:211)
+#define IVP_F_REJECT    0x2u          // `reject` (dopri5.rs:212)
+#define IVP_F_FIRSTOUT  0x4u          // DefaultSolOut.first_output_done (solout.rs:53)
+#define IVP_F_IASTI_SHIFT 4           // iasti   0..15  (dopri5.rs:215)
+#define IVP_F_NONSTIFF_SHIFT 8        // nonstiff 0..6  (dopri5.rs:213)
+#define IVP_F_STIFFCTR_SHIFT 12       // naccpt mod nstiff (0..999), replaces the 64-bit modulo
+
+struct IvpKArgs {
+    // ---- batch geometry ----
+    uint32_t B;               // trajectories in the batch = stride of every SoA array
+    // ---- inputs (init kernel) ----
+    const double *y0;         // [N][B]
+    const double *params;     // [P][B]
+    const double *t0;         // [B] or [1]
+    const double *t1;         // [B] or [1]
+    uint32_t t0_stride;       // 1 = per trajectory, 0 = shared
+    uint32_t t1_stride;
+    // ---- options (uniform -> SGPRs) ----
+    double rtol[IVP_MAX_N];
+    double atol[IVP_MAX_N];
+    double first_step;
+    double max_step;
+    uint64_t nmax;            // Options.max_steps or UINT64_MAX
+    int32_t has_first_step;
+    int32_t has_max_step;
+    // ---- persistent per-trajectory state (doubles as the result arrays) ----
+    double *y;                // [N][B]  current state; y_end on exit
+    double *k1;               // [N][B]  FSAL derivative at (x, y)
+    double *x;                // [B]     t_end on exit
+    double *h;                // [B]     h_next on exit
+    double *facold;           // [B]
+    double *hlamb;            // [B]
+    uint32_t *flags;          // [B]
+    int32_t *status;          // [B]     IVP_RUNNING until the trajectory retires
+    uint64_t *nfev, *nstep, *naccpt, *nrejct;  // [B]
+    // ---- active-set compaction ----
+    const uint32_t *perm_in;  // [count_in] trajectory ids to process; NULL = identity over B
+    const uint32_t *count_in; // device scalar; ignored when perm_in == NULL
+    uint32_t *perm_out;       // ids still running after this launch (appended wave by wave)
+    uint32_t *count_out;      // device scalar, zeroed by the host before the launch
+    uint32_t chunk;           // step attempts per launch
+    // ---- DefaultSolOut outputs (FULL kernels only) ----
+    const double *t_eval;     // [n_eval] shared grid, device
+    int32_t n_eval;           // < 0: Options.t_eval == None
+    double *y_eval;           // [n_eval][N][B]
+    int32_t *eval_idx;        // [n_eval][B]
+    int32_t *n_filled;        // [B] emitted samples so far
+    int32_t *next_idx;        // [B] DefaultSolOut.next_idx
+    uint32_t max_log;
+    double *t_log;            // [max_log][B]
+    double *y_log;            // [max_log][N][B]
+    uint32_t *n_log;          // [B]
+    double *t_last;           // [B] last recorded t (dedupe test, solout.rs:424)
+    int32_t collect_dense;
+    double *seg_cont;         // [max_log][ncoef*N][B]
+    double *seg_xold;         // [max_log][B]
+    double *seg_h;            // [max_log][B]
+    uint32_t *n_seg;          // [B]
+    // ---- profiling ----
+    unsigned long long *slot_counter;  // optional: += lanes x attempts the wave executed
+};

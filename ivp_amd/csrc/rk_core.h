@@ -1,0 +1,1100 @@
+// rk_core.h -- per-lane bodies of the gfx950 batched explicit Runge-Kutta kernels.
+//
+// One GPU lane owns one trajectory (one reference solve_ivp() call): y, the FSAL derivative k1,
+// x, h and the controller memory live in VGPRs for a whole chunk of step attempts; the k-stages are
+// VGPR arrays indexed at compile time; tableau coefficients are literals (wave-uniform -> SGPRs /
+// inline constants).  Nothing here touches LDS or other lanes: trajectories are independent.
+//
+// The code is written against IVP_HD so that tests/host_emul can run the very same bodies lane by
+// lane on a CPU (no GPU in the authoring container); the product only ever compiles it for gfx950
+// through rk_kernels.hip.
+//
+// Floating-point contract: in the STRICT build (-ffp-contract=off) every expression keeps the
+// reference's left-to-right association (SURVEY.md section 7 "FP / semantics notes"), so the result is
+// the same IEEE-754 operation sequence as the Rust crate evaluates; only the step-controller
+// power function differs (ivp_pow below instead of libm pow).  The FAST build lets the compiler
+// contract a*b+c and uses reciprocal sharing inside the right-hand sides.
+//
+// Reference citations are file:line in Ryan-D-Gast/ivp 0.5.1.
+#pragma once
+#ifndef __HIPCC_RTC__
+#include <stdint.h>
+#include <math.h>
+#include "ivp_kargs.h"
+#endif
+
+#ifndef IVP_HD
+#define IVP_HD __host__ __device__ __forceinline__
+#endif
+#ifndef IVP_FAST
+#define IVP_FAST 0
+#endif
+#ifndef IVP_NS
+#define IVP_NS ivp
+#endif
+// KC(c): a wave-uniform f64 literal, materialised into an SGPR pair right where it is used.
+// gfx950 VOP3 f64 instructions cannot encode a 64-bit literal, so every tableau / polynomial
+// coefficient must sit in registers; left alone, LLVM hoists all ~70 of them out of the attempt
+// loop (first into SGPRs, then, once those run out, into *vector* registers: 140+ VGPRs) and
+// halves the occupancy.  XOR-ing the bit pattern with an opaque scalar zero that is re-defined
+// inside the loop (KC_SCOPE) makes each constant loop-variant as far as LICM can tell: it costs
+// two `s_xor_b32 sN, sZ, literal` SALU instructions per use (they co-issue with the other waves'
+// VALU work) and keeps the live register set down to the integrator's real state.
+// On the host (tests/host_emul) KC is the identity.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KC_SCOPE const uint64_t ivp_kz = IVP_NS::ivp_opaque_zero();
+#define KC(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kz)
+#define IVP_OPAQUE_V(v) asm volatile("" : "+v"(v))
+#else
+#define KC_SCOPE
+#define KC(c) (c)
+#define IVP_OPAQUE_V(v) ((void)0)
+#endif
+
+namespace IVP_NS {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t ivp_opaque_zero()
+{
+    uint64_t z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+#endif
+IVP_HD double rs_signum(double v) { return v != v ? v : copysign(1.0, v); }  // Rust f64::signum
+IVP_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
+IVP_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+
+// Step-controller power x^e for x >= 0 (err^expo1, facold^beta, (0.01/der12)^(1/iord)):
+// exp2(e*log2 x) from IEEE +,-,*,/,fma,rint and bit moves only, ~2 ulp.  Replaces f64::powf
+// (dopri5.rs:351-353, dop853.rs:432-434, rk23.rs:289,303, mod.rs:276); deterministic on any IEEE
+// machine, which is what makes the strict path bit-comparable with a CPU restatement.
+IVP_HD double ivp_pow(double x, double e)
+{
+    KC_SCOPE
+    if (e == 0.0) return 1.0;
+    if (x != x || e != e) return x + e;
+    if (x < 0.0) return u2d(0x7FF8000000000000ull);
+    if (x == 0.0) return e > 0.0 ? 0.0 : u2d(0x7FF0000000000000ull);
+    if (x == u2d(0x7FF0000000000000ull)) return e > 0.0 ? x : 0.0;
+    int k = 0;
+    uint64_t u = d2u(x);
+    if ((u >> 52) == 0) { x *= 0x1p54; u = d2u(x); k = -54; }
+    int ex = (int)(u >> 52) - 1023;
+    const uint64_t mant = u & 0x000FFFFFFFFFFFFFull;
+    double m;
+    if (mant > 0x6A09E667F3BCDull) { m = u2d(mant | 0x3FE0000000000000ull); ex += 1; }
+    else { m = u2d(mant | 0x3FF0000000000000ull); }
+    k += ex;
+    const double t = (m - 1.0) / (m + 1.0);
+    const double z = t * t;
+    double p = KC(1.0 / 25.0);
+    p = fma(p, z, KC(1.0 / 23.0));
+    p = fma(p, z, KC(1.0 / 21.0));
+    p = fma(p, z, KC(1.0 / 19.0));
+    p = fma(p, z, KC(1.0 / 17.0));
+    p = fma(p, z, KC(1.0 / 15.0));
+    p = fma(p, z, KC(1.0 / 13.0));
+    p = fma(p, z, KC(1.0 / 11.0));
+    p = fma(p, z, KC(1.0 / 9.0));
+    p = fma(p, z, KC(1.0 / 7.0));
+    p = fma(p, z, KC(1.0 / 5.0));
+    p = fma(p, z, KC(1.0 / 3.0));
+    p = fma(p, z, 1.0);
+    const double lnm = (2.0 * t) * p;
+    const double l2 = fma(lnm, KC(0x1.71547652b82fep+0), (double)k);
+    const double w = e * l2;
+    if (w >= 1024.0) return u2d(0x7FF0000000000000ull);
+    if (w <= -1022.0) return 0.0;
+    const double kd = rint(w);
+    const double r = w - kd;
+    const double v = r * KC(0x1.62e42fefa39efp-1);
+    double q = KC(1.0 / 87178291200.0);
+    q = fma(q, v, KC(1.0 / 6227020800.0));
+    q = fma(q, v, KC(1.0 / 479001600.0));
+    q = fma(q, v, KC(1.0 / 39916800.0));
+    q = fma(q, v, KC(1.0 / 3628800.0));
+    q = fma(q, v, KC(1.0 / 362880.0));
+    q = fma(q, v, KC(1.0 / 40320.0));
+    q = fma(q, v, KC(1.0 / 5040.0));
+    q = fma(q, v, KC(1.0 / 720.0));
+    q = fma(q, v, KC(1.0 / 120.0));
+    q = fma(q, v, KC(1.0 / 24.0));
+    q = fma(q, v, KC(1.0 / 6.0));
+    q = fma(q, v, 0.5);
+    q = fma(q, v, 1.0);
+    q = fma(q, v, 1.0);
+    const int ki = (int)kd;
+    return q * u2d((uint64_t)(ki + 1023) << 52);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Right-hand sides: the device-side `impl IVP for T { fn ode(&self, x, y, dydx) }` (src/ivp.rs:29).
+// ------------------------------------------------------------------------------------------------
+struct RhsDecay {    // examples/exponential_decay.rs:9-13
+    enum { N = 1, P = 1 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *p) { d[0] = -p[0] * y[0]; }
+};
+struct RhsSho {      // tests/common.rs:3-9
+    enum { N = 2, P = 0 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *) { d[0] = y[1]; d[1] = -y[0]; }
+};
+struct RhsVdp {      // benches/benchmark.py:22-27
+    enum { N = 2, P = 1 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *p)
+    {
+        d[0] = y[1];
+        d[1] = p[0] * (1.0 - y[0] * y[0]) * y[1] - y[0];
+    }
+};
+struct RhsCr3bp {    // examples/cr3bp.rs:23-36
+    enum { N = 6, P = 1 };
+    static IVP_HD void ode(double, const double *s, double *d, const double *p)
+    {
+        const double mu = p[0];
+        const double x = s[0], y = s[1], z = s[2], vx = s[3], vy = s[4], vz = s[5];
+        const double a = x + mu;
+        const double b = x - 1.0 + mu;
+#if IVP_FAST
+        // reciprocal sharing: one division per primary instead of three
+        const double d1 = a * a + y * y + z * z;
+        const double d2 = b * b + y * y + z * z;
+        const double r1 = sqrt(d1), r2 = sqrt(d2);
+        const double g1 = (1.0 - mu) / (d1 * r1);
+        const double g2 = mu / (d2 * r2);
+        d[0] = vx; d[1] = vy; d[2] = vz;
+        d[3] = x + 2.0 * vy - g1 * a - g2 * b;
+        d[4] = y - 2.0 * vx - g1 * y - g2 * y;
+        d[5] = -g1 * z - g2 * z;
+#else
+        const double r1 = sqrt(a * a + y * y + z * z);
+        const double r2 = sqrt(b * b + y * y + z * z);
+        const double r13 = r1 * r1 * r1;  // powi(3)
+        const double r23 = r2 * r2 * r2;
+        d[0] = vx; d[1] = vy; d[2] = vz;
+        d[3] = x + 2.0 * vy - (1.0 - mu) * (x + mu) / r13 - mu * (x - 1.0 + mu) / r23;
+        d[4] = y - 2.0 * vx - (1.0 - mu) * y / r13 - mu * y / r23;
+        d[5] = -(1.0 - mu) * z / r13 - mu * z / r23;
+#endif
+    }
+};
+struct RhsLorenz {   // benches/benchmark.py:30-37
+    enum { N = 3, P = 3 };
+    static IVP_HD void ode(double, const double *s, double *d, const double *p)
+    {
+        d[0] = p[0] * (s[1] - s[0]);
+        d[1] = s[0] * (p[1] - s[2]) - s[1];
+        d[2] = s[0] * s[1] - p[2] * s[2];
+    }
+};
+struct RhsZero {     // tests/ivp.rs:11-19
+    enum { N = 3, P = 0 };
+    static IVP_HD void ode(double, const double *, double *d, const double *) { d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; }
+};
+struct RhsRational { // tests/test_helpers.py:23-25
+    enum { N = 2, P = 0 };
+    static IVP_HD void ode(double t, const double *y, double *d, const double *)
+    {
+        d[0] = y[1] / t;
+        d[1] = y[1] * (y[0] + 2.0 * y[1] - 1.0) / (t * (y[0] - 1.0));
+    }
+};
+struct RhsExp2 {     // tests/ivp.rs:291-298
+    enum { N = 2, P = 0 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *) { d[0] = y[0]; d[1] = y[1]; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Per-lane state
+// ------------------------------------------------------------------------------------------------
+template <int N, int P>
+struct Lane {
+    double y[N], k1[N], p[P > 0 ? P : 1];
+    double x, h, facold, hlamb, xend, x0, posneg, hmax;
+    uint32_t flags;
+    int32_t status;
+    uint32_t d_nfev, d_nstep, d_naccpt, d_nrejct;  // this chunk's increments
+    uint32_t budget;      // attempts left before `steps.total > nmax` (saturating)
+    uint32_t acc_small;   // min(naccpt, 2): `steps.accepted > 1` test (dopri5.rs:455)
+    bool over;            // nmax already exceeded on entry
+    // DefaultSolOut registers (FULL kernels)
+    int32_t next_idx, n_filled;
+    uint32_t n_log, n_seg;
+    double t_last;
+};
+
+template <class R>
+IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool rk23, bool full)
+{
+    constexpr int N = R::N, P = R::P;
+    const size_t B = a.B;
+#pragma unroll
+    for (int c = 0; c < N; ++c) { L.y[c] = a.y[c * B + j]; L.k1[c] = a.k1[c * B + j]; }
+#pragma unroll
+    for (int c = 0; c < P; ++c) L.p[c] = a.params[c * B + j];
+    L.x = a.x[j];
+    L.h = a.h[j];
+    L.facold = a.facold[j];
+    L.hlamb = a.hlamb[j];
+    L.x0 = a.t0[(size_t)j * a.t0_stride];
+    L.xend = a.t1[(size_t)j * a.t1_stride];
+    L.posneg = rs_signum(L.xend - L.x0);
+    L.flags = a.flags[j];
+    L.status = IVP_RUNNING;
+    L.d_nfev = L.d_nstep = L.d_naccpt = L.d_nrejct = 0;
+    const uint64_t nstep0 = a.nstep[j];
+    const uint64_t nacc0 = a.naccpt[j];
+    if (rk23) {   // `steps.total >= nmax` (rk23.rs:191)
+        L.over = nstep0 >= a.nmax;
+        const uint64_t left = L.over ? 0 : a.nmax - nstep0;
+        L.budget = left > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)left;
+    } else {      // `steps.total > nmax` (dopri5.rs:268)
+        L.over = nstep0 > a.nmax;
+        const uint64_t left = L.over ? 0 : a.nmax - nstep0;
+        L.budget = left > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)left;
+    }
+    L.acc_small = nacc0 > 2 ? 2u : (uint32_t)nacc0;
+    if (full) {
+        L.next_idx = a.next_idx[j];
+        L.n_filled = a.n_filled[j];
+        L.n_log = a.n_log[j];
+        L.n_seg = a.n_seg[j];
+        L.t_last = a.t_last[j];
+    } else {
+        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    }
+}
+
+template <class R>
+IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L, bool full)
+{
+    constexpr int N = R::N;
+    const size_t B = a.B;
+#pragma unroll
+    for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = L.k1[c]; }
+    a.x[j] = L.x;
+    a.h[j] = L.h;
+    a.facold[j] = L.facold;
+    a.hlamb[j] = L.hlamb;
+    a.flags[j] = L.flags;
+    a.status[j] = L.status;
+    a.nfev[j] += L.d_nfev;
+    a.nstep[j] += L.d_nstep;
+    a.naccpt[j] += L.d_naccpt;
+    a.nrejct[j] += L.d_nrejct;
+    if (full) {
+        a.next_idx[j] = L.next_idx;
+        a.n_filled[j] = L.n_filled;
+        a.n_log[j] = L.n_log;
+        a.n_seg[j] = L.n_seg;
+        a.t_last[j] = L.t_last;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense-output polynomials (dopri5.rs:467-478, dop853.rs:659-670, rk23.rs:313-321)
+// ------------------------------------------------------------------------------------------------
+enum { M_RK23 = 0, M_DOPRI5 = 1, M_DOP853 = 2 };
+template <int M> struct NCoef { enum { v = (M == M_DOPRI5) ? 5 : (M == M_DOP853) ? 8 : 4 }; };
+
+template <int M, int N>
+IVP_HD void interpolate(double xi, double *yi, const double *cont, double xold, double h)
+{
+    if constexpr (M == M_DOPRI5) {
+        const double theta = (xi - xold) / h;
+        const double theta1 = 1.0 - theta;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            yi[i] = cont[i] + theta * (cont[N + i] + theta1 * (cont[2 * N + i] + theta * (cont[3 * N + i] + theta1 * cont[4 * N + i])));
+    } else if constexpr (M == M_DOP853) {
+        const double s = (xi - xold) / h;
+        const double s1 = 1.0 - s;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double conpar = cont[4 * N + i] + s * (cont[5 * N + i] + s1 * (cont[6 * N + i] + s * cont[7 * N + i]));
+            yi[i] = cont[i] + s * (cont[N + i] + s1 * (cont[2 * N + i] + s * (cont[3 * N + i] + s1 * conpar)));
+        }
+    } else {
+        const double xc = (xi - xold) / h;
+        const double x2 = xc * xc;
+        const double x3 = x2 * xc;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            yi[i] = cont[i] + h * (cont[N + i] * xc + cont[2 * N + i] * x2 + cont[3 * N + i] * x3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DefaultSolOut on the device (src/solve/solout.rs:127-431 without events): dense-segment
+// collection, t_eval sampling, accepted-step recording with first_step enforcement.
+// `cont == nullptr` is the initial callback (interpolant None).
+// ------------------------------------------------------------------------------------------------
+template <int M, int N, int P>
+IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t ti, const double *yv)
+{
+    const size_t B = a.B;
+    const size_t k = (size_t)L.n_filled;
+#pragma unroll
+    for (int c = 0; c < N; ++c) a.y_eval[(k * N + c) * B + j] = yv[c];
+    if (a.eval_idx) a.eval_idx[k * B + j] = ti;
+    L.n_filled += 1;
+}
+template <int M, int N, int P>
+IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, const double *yv)
+{
+    const size_t B = a.B;
+    if (L.n_log < a.max_log) {
+        const size_t k = L.n_log;
+        a.t_log[k * B + j] = t;
+#pragma unroll
+        for (int c = 0; c < N; ++c) a.y_log[(k * N + c) * B + j] = yv[c];
+    }
+    L.n_log += 1;
+    L.t_last = t;
+}
+
+template <int M, int N, int P>
+IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
+                        const double *y, const double *cont, double h)
+{
+    constexpr int NC = NCoef<M>::v * N;
+    const double tol = 1e-12;
+    const size_t B = a.B;
+    // dense collection, solout.rs:141-146
+    if (a.collect_dense && x != xold && cont != nullptr && h != 0.0) {
+        if (L.n_seg < a.max_log) {
+            const size_t k = L.n_seg;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) a.seg_cont[(k * NC + c) * B + j] = cont[c];
+            a.seg_xold[k * B + j] = xold;
+            a.seg_h[k * B + j] = h;
+        }
+        L.n_seg += 1;
+    }
+    double yi[N];
+    if (a.n_eval >= 0) {  // Mode 1, solout.rs:344-386
+        int32_t i = L.next_idx;
+        const int32_t ne = a.n_eval;
+        if (fabs(xold - x) <= tol) {
+            while (i < ne && fabs(a.t_eval[i] - x) <= tol) { so_emit_eval<M, N, P>(a, j, L, i, y); ++i; }
+        } else if (x > xold) {
+            while (i < ne && a.t_eval[i] <= x + tol) {
+                const double te = a.t_eval[i];
+                if (te >= xold - tol) { interpolate<M, N>(te, yi, cont, xold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
+                ++i;
+            }
+        } else {
+            while (i < ne && a.t_eval[i] >= x - tol) {
+                const double te = a.t_eval[i];
+                if (te <= xold + tol) { interpolate<M, N>(te, yi, cont, xold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
+                ++i;
+            }
+        }
+        L.next_idx = i;
+    } else if (a.t_log != nullptr) {  // Mode 2, solout.rs:387-428
+        if (a.has_first_step) {
+            if (!(L.flags & IVP_F_FIRSTOUT) && fabs(xold - x) > tol) {
+                const double direction = rs_signum(x - xold);
+                const double target = L.x0 + direction * a.first_step;
+                if (direction * (x - target) >= -tol) {
+                    if (cont != nullptr) {
+                        interpolate<M, N>(target, yi, cont, xold, h);
+                        so_push_log<M, N, P>(a, j, L, target, yi);
+                        L.flags |= IVP_F_FIRSTOUT;
+                    }
+                    if (fabs(x - target) > tol) so_push_log<M, N, P>(a, j, L, x, y);
+                }
+                return;
+            }
+        }
+        if (L.n_log == 0 || fabs(L.t_last - x) > tol) so_push_log<M, N, P>(a, j, L, x, y);
+    }
+}
+
+// does the accepted step [xold, xph] need dense coefficients? (lazy DOP853 dense stages)
+template <int N, int P>
+IVP_HD bool so_needs_dense(const IvpKArgs &a, const Lane<N, P> &L, double xold, double xph)
+{
+    const double tol = 1e-12;
+    if (a.collect_dense) return true;
+    if (a.n_eval >= 0) {
+        if (L.next_idx >= a.n_eval) return false;
+        const double te = a.t_eval[L.next_idx];
+        return xph > xold ? (te <= xph + tol) : (te >= xph - tol);
+    }
+    return a.t_log != nullptr && a.has_first_step && !(L.flags & IVP_F_FIRSTOUT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hinit (src/methods/mod.rs:217-281)
+// ------------------------------------------------------------------------------------------------
+template <class R>
+IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg, const double *f0,
+                    const double *p, int iord, double hmax)
+{
+    constexpr int N = R::N;
+    double dnf = 0.0, dny = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double sk = a.atol[i] + a.rtol[i] * fabs(y[i]);
+        dnf += (f0[i] / sk) * (f0[i] / sk);
+        dny += (y[i] / sk) * (y[i] / sk);
+    }
+    double h;
+    if (dnf <= 1e-10 || dny <= 1e-10) h = 1.0e-6;
+    else h = sqrt(dny / dnf) * 0.01;
+    if (h > fabs(hmax)) h = fabs(hmax);
+    h = fabs(h) * rs_signum(posneg);
+    double y1[N], f1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * f0[i];
+    R::ode(x + h, y1, f1, p);
+    double der2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double sk = a.atol[i] + a.rtol[i] * fabs(y[i]);
+        const double df = (f1[i] - f0[i]) / sk;
+        der2 += df * df;
+    }
+    der2 = sqrt(der2) / fabs(h);
+    const double der12 = fmax(fabs(der2), sqrt(dnf));
+    double h1;
+    if (der12 <= 1.0e-15) h1 = fmax(1.0e-6, fabs(h) * 1.0e-3);
+    else h1 = ivp_pow(0.01 / der12, 1.0 / (double)iord);
+    const double hf = fmin(fmin(fmin(fabs(h), 100.0 * fabs(h)), h1), fabs(hmax));  // mod.rs:279 as written
+    return fabs(hf) * rs_signum(posneg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// init body: the part of solve_ivp()/XXX::solve() before the main loop
+//   (solve_ivp.rs:110-145 zero-interval short-circuit; dopri5.rs:201-263 / dop853.rs:196-269 /
+//    rk23.rs:138-186: f0, hinit or first_step, initial SolOut call)
+// ------------------------------------------------------------------------------------------------
+template <int M, class R, bool FULL>
+IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
+{
+    constexpr int N = R::N, P = R::P;
+    const size_t B = a.B;
+    Lane<N, P> L;
+#pragma unroll
+    for (int c = 0; c < N; ++c) L.y[c] = a.y0[c * B + j];
+#pragma unroll
+    for (int c = 0; c < P; ++c) L.p[c] = a.params[c * B + j];
+    L.x0 = a.t0[(size_t)j * a.t0_stride];
+    L.xend = a.t1[(size_t)j * a.t1_stride];
+    L.x = L.x0;
+    L.flags = 0;
+    L.facold = 1e-4;
+    L.hlamb = 0.0;
+    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    uint64_t nfev = 0;
+
+    if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
+#pragma unroll
+        for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = 0.0; }
+        if (FULL) {
+            if (a.n_eval >= 0) {
+                for (int32_t i = 0; i < a.n_eval; ++i)
+                    if (fabs(a.t_eval[i] - L.x0) < 1e-12) so_emit_eval<M, N, P>(a, j, L, i, L.y);
+            } else if (a.t_log != nullptr) {
+                so_push_log<M, N, P>(a, j, L, L.x0, L.y);
+            }
+            if (a.collect_dense && a.max_log > 0) {  // ContinuousOutput::constant, cont.rs:32-64
+                constexpr int NC = NCoef<M>::v * N;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) a.seg_cont[(size_t)c * B + j] = c < N ? L.y[c] : 0.0;
+                a.seg_xold[j] = L.x0;
+                a.seg_h[j] = 1e-15;
+                L.n_seg = 1;
+            }
+            a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
+            a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+        }
+        a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
+        a.status[j] = 0;
+        a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+        return 0;
+    }
+
+    L.posneg = rs_signum(L.xend - L.x0);
+    // h_max: dopri5.rs:180 keeps the sign of max_step, dop853.rs:172-175 / rk23.rs:135 take |.|
+    if (a.has_max_step) L.hmax = (M == M_DOPRI5) ? a.max_step : fabs(a.max_step);
+    else L.hmax = fabs(L.xend - L.x);
+
+    R::ode(L.x, L.y, L.k1, L.p);
+    nfev += 1;
+    if (a.has_first_step) {
+        L.h = fabs(a.first_step) * L.posneg;
+    } else {
+        nfev += 1;
+        L.h = hinit<R>(a, L.x, L.y, L.posneg, L.k1, L.p, M == M_DOPRI5 ? 5 : (M == M_DOP853 ? 8 : 3), L.hmax);
+    }
+    if (FULL) solout_full<M, N, P>(a, j, L, L.x, L.x, L.y, nullptr, 0.0);
+
+#pragma unroll
+    for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = L.k1[c]; }
+    a.x[j] = L.x; a.h[j] = L.h; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = L.flags;
+    a.status[j] = IVP_RUNNING;
+    a.nfev[j] = nfev; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+    if (FULL) {
+        a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
+        a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+    }
+    return IVP_RUNNING;
+}
+
+// Shared tail of an accepted/rejected attempt for DOPRI5 and DOP853 (dopri5.rs:434-460, dop853.rs:626-652).
+#define IVP_STIFF_BOOKKEEPING(THRESH)                                                              \
+    {                                                                                              \
+        uint32_t iasti = (L.flags >> IVP_F_IASTI_SHIFT) & 0xFu;                                    \
+        uint32_t nonstiff = (L.flags >> IVP_F_NONSTIFF_SHIFT) & 0xFu;                              \
+        if (stden > 0.0) L.hlamb = fabs(h) * sqrt(stnum / stden);                                  \
+        if (L.hlamb > (THRESH)) {                                                                  \
+            nonstiff = 0;                                                                          \
+            iasti += 1;                                                                            \
+            if (iasti == 15) stiff_break = true;                                                   \
+        } else {                                                                                   \
+            nonstiff += 1;                                                                         \
+            if (nonstiff == 6) iasti = 0;                                                          \
+        }                                                                                          \
+        L.flags = (L.flags & ~((0xFu << IVP_F_IASTI_SHIFT) | (0xFu << IVP_F_NONSTIFF_SHIFT))) |    \
+                  ((iasti & 0xFu) << IVP_F_IASTI_SHIFT) | ((nonstiff & 0xFu) << IVP_F_NONSTIFF_SHIFT); \
+    }
+
+// stiffness-test cadence: `steps.accepted % nstiff == 0` with nstiff = 1000 kept as a 10-bit counter
+IVP_HD bool stiff_tick(uint32_t &flags)
+{
+    uint32_t sc = (flags >> IVP_F_STIFFCTR_SHIFT) & 0x3FFu;
+    sc += 1;
+    const bool hit = sc == 1000u;
+    if (hit) sc = 0;
+    flags = (flags & ~(0x3FFu << IVP_F_STIFFCTR_SHIFT)) | (sc << IVP_F_STIFFCTR_SHIFT);
+    return hit || ((flags >> IVP_F_IASTI_SHIFT) & 0xFu) > 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DOPRI5 attempt (dopri5.rs:266-461).  Returns false when the trajectory retired.
+// ------------------------------------------------------------------------------------------------
+template <class R, bool FULL>
+IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
+{
+    KC_SCOPE
+    constexpr int N = R::N, P = R::P;
+    // tableau, dopri5.rs:482-520
+    constexpr double C2 = 0.2, C3 = 0.3, C4 = 0.8, C5 = 8.0 / 9.0;
+    constexpr double A21 = 0.2, A31 = 3.0 / 40.0, A32 = 9.0 / 40.0;
+    constexpr double A41 = 44.0 / 45.0, A42 = -56.0 / 15.0, A43 = 32.0 / 9.0;
+    constexpr double A51 = 19372.0 / 6561.0, A52 = -25360.0 / 2187.0, A53 = 64448.0 / 6561.0, A54 = -212.0 / 729.0;
+    constexpr double A61 = 9017.0 / 3168.0, A62 = -355.0 / 33.0, A63 = 46732.0 / 5247.0, A64 = 49.0 / 176.0, A65 = -5103.0 / 18656.0;
+    constexpr double A71 = 35.0 / 384.0, A73 = 500.0 / 1113.0, A74 = 125.0 / 192.0, A75 = -2187.0 / 6784.0, A76 = 11.0 / 84.0;
+    constexpr double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, E5 = -17253.0 / 339200.0, E6 = 22.0 / 525.0, E7 = -1.0 / 40.0;
+    constexpr double D1 = -12715105075.0 / 11282082432.0, D3 = 87487479700.0 / 32700410799.0, D4 = -10690763975.0 / 1880347072.0,
+                     D5 = 701980252875.0 / 199316789632.0, D6 = -1453857185.0 / 822651844.0, D7 = 69997945.0 / 29380423.0;
+    // struct defaults (dopri5.rs:34-72); solve_ivp overrides only max_step/first_step/max_steps
+    constexpr double uround = 2.3e-16, safety = 0.9, beta = 0.04;
+    constexpr double facc1 = 1.0 / 0.2, facc2 = 1.0 / 10.0;
+    constexpr double expo1 = 0.2 - beta * 0.75;
+
+    if (L.over || L.d_nstep > L.budget) { L.status = 2; return false; }               // NeedLargerNMax
+    double h = L.h;
+    const double x = L.x;
+    if (KC(0.1) * fabs(h) <= fabs(x) * KC(uround)) { L.status = 3; return false; }             // StepSizeTooSmall
+    bool last = (L.flags & IVP_F_LAST) != 0;
+    if ((x + KC(1.01) * h - L.xend) * L.posneg > 0.0) { h = L.xend - x; last = true; }
+    L.d_nstep += 1;
+
+    const double *y = L.y, *k1 = L.k1, *p = L.p;
+    double k2[N], k3[N], k4[N], k5[N], k6[N], y1[N];
+{ const double cA21 = KC(A21);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * cA21 * k1[i];
+}
+    R::ode(x + KC(C2) * h, y1, k2, p);
+{ const double cA31 = KC(A31), cA32 = KC(A32);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA31 * k1[i] + cA32 * k2[i]);
+}
+    R::ode(x + KC(C3) * h, y1, k3, p);
+{ const double cA41 = KC(A41), cA42 = KC(A42), cA43 = KC(A43);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA41 * k1[i] + cA42 * k2[i] + cA43 * k3[i]);
+}
+    R::ode(x + KC(C4) * h, y1, k4, p);
+{ const double cA51 = KC(A51), cA52 = KC(A52), cA53 = KC(A53), cA54 = KC(A54);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA51 * k1[i] + cA52 * k2[i] + cA53 * k3[i] + cA54 * k4[i]);
+}
+    R::ode(x + KC(C5) * h, y1, k5, p);
+{ const double cA61 = KC(A61), cA62 = KC(A62), cA63 = KC(A63), cA64 = KC(A64), cA65 = KC(A65);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA61 * k1[i] + cA62 * k2[i] + cA63 * k3[i] + cA64 * k4[i] + cA65 * k5[i]);
+}
+    const double xph = x + h;
+    R::ode(xph, y1, k6, p);
+{ const double cA71 = KC(A71), cA73 = KC(A73), cA74 = KC(A74), cA75 = KC(A75), cA76 = KC(A76);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA71 * k1[i] + cA73 * k3[i] + cA74 * k4[i] + cA75 * k5[i] + cA76 * k6[i]);
+}
+    R::ode(xph, y1, k2, p);  // k7 -> k2 (FSAL)
+    L.d_nfev += 6;
+
+    double cont[FULL ? 5 * N : 1];
+    if (FULL) {
+{ const double cD1 = KC(D1), cD3 = KC(D3), cD4 = KC(D4), cD5 = KC(D5), cD6 = KC(D6), cD7 = KC(D7);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            cont[4 * N + i] = h * (cD1 * k1[i] + cD3 * k3[i] + cD4 * k4[i] + cD5 * k5[i] + cD6 * k6[i] + cD7 * k2[i]);
+}
+    }
+{ const double cE1 = KC(E1), cE3 = KC(E3), cE4 = KC(E4), cE5 = KC(E5), cE6 = KC(E6), cE7 = KC(E7);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        k4[i] = (cE1 * k1[i] + cE3 * k3[i] + cE4 * k4[i] + cE5 * k5[i] + cE6 * k6[i] + cE7 * k2[i]) * h;
+}
+    double err = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double sk = a.atol[i] + a.rtol[i] * fmax(fabs(y[i]), fabs(y1[i]));
+        err += (k4[i] / sk) * (k4[i] / sk);
+    }
+    err = sqrt(err / (double)N);
+
+    const double fac11 = ivp_pow(err, KC(expo1));
+    double fac = fac11 / ivp_pow(L.facold, beta);
+    fac = fmax(KC(facc2), fmin(KC(facc1), fac / KC(safety)));
+    double hnew = h / fac;
+
+    if (err <= 1.0) {
+        L.facold = fmax(err, KC(1.0e-4));
+        L.d_naccpt += 1;
+        if (L.acc_small < 2) L.acc_small += 1;
+        if (stiff_tick(L.flags)) {  // dopri5.rs:364-391 (rare: every 1000 accepted steps)
+            double stnum = 0.0, stden = 0.0;
+            bool stiff_break = false;
+{ const double cA61 = KC(A61), cA62 = KC(A62), cA63 = KC(A63), cA64 = KC(A64), cA65 = KC(A65);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double d1 = k2[i] - k6[i];
+                const double ysti = y[i] + h * (cA61 * k1[i] + cA62 * k2[i] + cA63 * k3[i] + cA64 * k4[i] + cA65 * k5[i]);
+                const double d2 = y1[i] - ysti;
+                stnum += d1 * d1;
+                stden += d2 * d2;
+            }
+}
+            IVP_STIFF_BOOKKEEPING(3.25)
+            if (stiff_break) { L.h = h; L.status = 4; return false; }                  // ProbablyStiff
+        }
+        if (FULL) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double ydiff = y1[i] - y[i];
+                const double bspl = h * k1[i] - ydiff;
+                cont[i] = y[i];
+                cont[N + i] = ydiff;
+                cont[2 * N + i] = bspl;
+                cont[3 * N + i] = -h * k2[i] + ydiff - bspl;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) { L.k1[i] = k2[i]; L.y[i] = y1[i]; }
+        L.x = xph;
+        if (FULL) solout_full<M_DOPRI5, N, P>(a, j, L, x, xph, L.y, cont, h);
+        if (last) { L.h = hnew; L.status = 0; return false; }                          // Success
+        if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
+        if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
+    } else {
+        hnew = h / fmin(KC(facc1), fac11 / KC(safety));
+        L.flags |= IVP_F_REJECT;
+        if (L.acc_small > 1) L.d_nrejct += 1;
+        last = false;
+    }
+    L.flags = last ? (L.flags | IVP_F_LAST) : (L.flags & ~IVP_F_LAST);
+    L.h = hnew;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DOP853 attempt (dop853.rs:272-653)
+// ------------------------------------------------------------------------------------------------
+template <class R, bool FULL>
+IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
+{
+    KC_SCOPE
+    constexpr int N = R::N, P = R::P;
+    // Hairer's DOP853 coefficients, dop853.rs:674-848
+    constexpr double C2 = 0.526001519587677318785587544488e-01, C3 = 0.789002279381515978178381316732e-01,
+                     C4 = 0.118350341907227396726757197510e+00, C5 = 0.281649658092772603273242802490e+00,
+                     C6 = 0.333333333333333333333333333333e+00, C7 = 0.25e+00, C8 = 0.307692307692307692307692307692e+00,
+                     C9 = 0.651282051282051282051282051282e+00, C10 = 0.6e+00, C11 = 0.857142857142857142857142857142e+00,
+                     C14 = 0.1e+00, C15 = 0.2e+00, C16 = 7.777777777777778e-1;
+    constexpr double A21 = 5.26001519587677318785587544488e-2;
+    constexpr double A31 = 1.97250569845378994544595329183e-2, A32 = 5.91751709536136983633785987549e-2;
+    constexpr double A41 = 2.95875854768068491816892993775e-2, A43 = 8.87627564304205475450678981324e-2;
+    constexpr double A51 = 2.41365134159266685502369798665e-1, A53 = -8.84549479328286085344864962717e-1, A54 = 9.24834003261792003115737966543e-1;
+    constexpr double A61 = 3.7037037037037037037037037037e-2, A64 = 1.70828608729473871279604482173e-1, A65 = 1.25467687566822425016691814123e-1;
+    constexpr double A71 = 3.7109375e-2, A74 = 1.70252211019544039314978060272e-1, A75 = 6.02165389804559606850219397283e-2, A76 = -1.7578125e-2;
+    constexpr double A81 = 3.70920001185047927108779319836e-2, A84 = 1.70383925712239993810214054705e-1, A85 = 1.07262030446373284651809199168e-1,
+                     A86 = -1.53194377486244017527936158236e-2, A87 = 8.27378916381402288758473766002e-3;
+    constexpr double A91 = 6.24110958716075717114429577812e-1, A94 = -3.36089262944694129406857109825e0, A95 = -8.68219346841726006818189891453e-1,
+                     A96 = 2.75920996994467083049415600797e1, A97 = 2.01540675504778934086186788979e1, A98 = -4.34898841810699588477366255144e1;
+    constexpr double A101 = 4.77662536438264365890433908527e-1, A104 = -2.48811461997166764192642586468e0, A105 = -5.90290826836842996371446475743e-1,
+                     A106 = 2.12300514481811942347288949897e1, A107 = 1.52792336328824235832596922938e1, A108 = -3.32882109689848629194453265587e1,
+                     A109 = -2.03312017085086261358222928593e-2;
+    constexpr double A111 = -9.3714243008598732571704021658e-1, A114 = 5.18637242884406370830023853209e0, A115 = 1.09143734899672957818500254654e0,
+                     A116 = -8.14978701074692612513997267357e0, A117 = -1.85200656599969598641566180701e1, A118 = 2.27394870993505042818970056734e1,
+                     A119 = 2.49360555267965238987089396762e0, A1110 = -3.0467644718982195003823669022e0;
+    constexpr double A121 = 2.27331014751653820792359768449e0, A124 = -1.05344954667372501984066689879e1, A125 = -2.00087205822486249909675718444e0,
+                     A126 = -1.79589318631187989172765950534e1, A127 = 2.79488845294199600508499808837e1, A128 = -2.85899827713502369474065508674e0,
+                     A129 = -8.87285693353062954433549289258e0, A1210 = 1.23605671757943030647266201528e1, A1211 = 6.43392746015763530355970484046e-1;
+    constexpr double B1 = 5.42937341165687622380535766363e-2, B6 = 4.45031289275240888144113950566e0, B7 = 1.89151789931450038304281599044e0,
+                     B8 = -5.8012039600105847814672114227e0, B9 = 3.1116436695781989440891606237e-1, B10 = -1.52160949662516078556178806805e-1,
+                     B11 = 2.01365400804030348374776537501e-1, B12 = 4.47106157277725905176885569043e-2;
+    constexpr double BH1 = 0.244094488188976377952755905512e+00, BH2 = 0.733846688281611857341361741547e+00, BH3 = 0.220588235294117647058823529412e-01;
+    constexpr double ER1 = 0.1312004499419488073250102996e-01, ER6 = -0.1225156446376204440720569753e+01, ER7 = -0.4957589496572501915214079952e+00,
+                     ER8 = 0.1664377182454986536961530415e+01, ER9 = -0.3503288487499736816886487290e+00, ER10 = 0.3341791187130174790297318841e+00,
+                     ER11 = 0.8192320648511571246570742613e-01, ER12 = -0.2235530786388629525884427845e-01;
+    constexpr double A141 = 5.61675022830479523392909219681e-2, A147 = 2.53500210216624811088794765333e-1, A148 = -2.46239037470802489917441475441e-1,
+                     A149 = -1.24191423263816360469010140626e-1, A1410 = 1.5329179827876569731206322685e-1, A1411 = 8.20105229563468988491666602057e-3,
+                     A1412 = 7.56789766054569976138603589584e-3, A1413 = -8.298e-3;
+    constexpr double A151 = 3.18346481635021405060768473261e-2, A156 = 2.83009096723667755288322961402e-2, A157 = 5.35419883074385676223797384372e-2,
+                     A158 = -5.49237485713909884646569340306e-2, A1511 = -1.08347328697249322858509316994e-4, A1512 = 3.82571090835658412954920192323e-4,
+                     A1513 = -3.40465008687404560802977114492e-4, A1514 = 1.41312443674632500278074618366e-1;
+    constexpr double A161 = -4.28896301583791923408573538692e-1, A166 = -4.69762141536116384314449447206e0, A167 = 7.68342119606259904184240953878e0,
+                     A168 = 4.06898981839711007970213554331e0, A169 = 3.56727187455281109270669543021e-1, A1613 = -1.39902416515901462129418009734e-3,
+                     A1614 = 2.9475147891527723389556272149e0, A1615 = -9.15095847217987001081870187138e0;
+    constexpr double D41 = -0.84289382761090128651353491142e+01, D46 = 0.56671495351937776962531783590e+00, D47 = -0.30689499459498916912797304727e+01,
+                     D48 = 0.23846676565120698287728149680e+01, D49 = 0.21170345824450282767155149946e+01, D410 = -0.87139158377797299206789907490e+00,
+                     D411 = 0.22404374302607882758541771650e+01, D412 = 0.63157877876946881815570249290e+00, D413 = -0.88990336451333310820698117400e-01,
+                     D414 = 0.18148505520854727256656404962e+02, D415 = -0.91946323924783554000451984436e+01, D416 = -0.44360363875948939664310572000e+01;
+    constexpr double D51 = 0.10427508642579134603413151009e+02, D56 = 0.24228349177525818288430175319e+03, D57 = 0.16520045171727028198505394887e+03,
+                     D58 = -0.37454675472269020279518312152e+03, D59 = -0.22113666853125306036270938578e+02, D510 = 0.77334326684722638389603898808e+01,
+                     D511 = -0.30674084731089398182061213626e+02, D512 = -0.93321305264302278729567221706e+01, D513 = 0.15697238121770843886131091075e+02,
+                     D514 = -0.31139403219565177677282850411e+02, D515 = -0.93529243588444783865713862664e+01, D516 = 0.35816841486394083752465898540e+02;
+    constexpr double D61 = 0.19985053242002433820987653617e+02, D66 = -0.38703730874935176555105901742e+03, D67 = -0.18917813819516756882830838328e+03,
+                     D68 = 0.52780815920542364900561016686e+03, D69 = -0.11573902539959630126141871134e+02, D610 = 0.68812326946963000169666922661e+01,
+                     D611 = -0.10006050966910838403183860980e+01, D612 = 0.77771377980534432092869265740e+00, D613 = -0.27782057523535084065932004339e+01,
+                     D614 = -0.60196695231264120758267380846e+02, D615 = 0.84320405506677161018159903784e+02, D616 = 0.11992291136182789328035130030e+02;
+    constexpr double D71 = -0.25693933462703749003312586129e+02, D76 = -0.15418974869023643374053993627e+03, D77 = -0.23152937917604549567536039109e+03,
+                     D78 = 0.35763911791061412378285349910e+03, D79 = 0.93405324183624310003907691704e+02, D710 = -0.37458323136451633156875139351e+02,
+                     D711 = 0.10409964950896230045147246184e+03, D712 = 0.29840293426660503123344363579e+02, D713 = -0.43533456590011143754432175058e+02,
+                     D714 = 0.96324553959188282948394950600e+02, D715 = -0.39177261675615439165231486172e+02, D716 = -0.14972683625798562581422125276e+03;
+    // struct defaults (dop853.rs:34-63)
+    constexpr double uround = 2.3e-16, safety = 0.9, beta = 0.0;
+    constexpr double facc1 = 1.0 / 0.333, facc2 = 1.0 / 6.0;
+    constexpr double expo1 = 1.0 / 8.0 - beta * 0.2;
+
+    if (L.over || L.d_nstep > L.budget) { L.status = 2; return false; }
+    double h = L.h;
+    const double x = L.x;
+    if (KC(0.1) * fabs(h) <= fabs(x) * KC(uround)) { L.status = 3; return false; }
+    bool last = (L.flags & IVP_F_LAST) != 0;
+    if ((x + KC(1.01) * h - L.xend) * L.posneg > 0.0) { h = L.xend - x; last = true; }
+    L.d_nstep += 1;
+
+    const double *y = L.y, *k1 = L.k1, *p = L.p;
+    double k2[N], k3[N], k4[N], k5[N], k6[N], k7[N], k8[N], k9[N], k10[N], y1[N];
+{ const double cA21 = KC(A21);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * cA21 * k1[i];
+}
+    R::ode(x + KC(C2) * h, y1, k2, p);
+{ const double cA31 = KC(A31), cA32 = KC(A32);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA31 * k1[i] + cA32 * k2[i]);
+}
+    R::ode(x + KC(C3) * h, y1, k3, p);
+{ const double cA41 = KC(A41), cA43 = KC(A43);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA41 * k1[i] + cA43 * k3[i]);
+}
+    R::ode(x + KC(C4) * h, y1, k4, p);
+{ const double cA51 = KC(A51), cA53 = KC(A53), cA54 = KC(A54);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA51 * k1[i] + cA53 * k3[i] + cA54 * k4[i]);
+}
+    R::ode(x + KC(C5) * h, y1, k5, p);
+{ const double cA61 = KC(A61), cA64 = KC(A64), cA65 = KC(A65);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA61 * k1[i] + cA64 * k4[i] + cA65 * k5[i]);
+}
+    R::ode(x + KC(C6) * h, y1, k6, p);
+{ const double cA71 = KC(A71), cA74 = KC(A74), cA75 = KC(A75), cA76 = KC(A76);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA71 * k1[i] + cA74 * k4[i] + cA75 * k5[i] + cA76 * k6[i]);
+}
+    R::ode(x + KC(C7) * h, y1, k7, p);
+{ const double cA81 = KC(A81), cA84 = KC(A84), cA85 = KC(A85), cA86 = KC(A86), cA87 = KC(A87);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA81 * k1[i] + cA84 * k4[i] + cA85 * k5[i] + cA86 * k6[i] + cA87 * k7[i]);
+}
+    R::ode(x + KC(C8) * h, y1, k8, p);
+{ const double cA91 = KC(A91), cA94 = KC(A94), cA95 = KC(A95), cA96 = KC(A96), cA97 = KC(A97), cA98 = KC(A98);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = y[i] + h * (cA91 * k1[i] + cA94 * k4[i] + cA95 * k5[i] + cA96 * k6[i] + cA97 * k7[i] + cA98 * k8[i]);
+}
+    R::ode(x + KC(C9) * h, y1, k9, p);
+{ const double cA101 = KC(A101), cA104 = KC(A104), cA105 = KC(A105), cA106 = KC(A106), cA107 = KC(A107), cA108 = KC(A108), cA109 = KC(A109);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = y[i] + h * (cA101 * k1[i] + cA104 * k4[i] + cA105 * k5[i] + cA106 * k6[i] + cA107 * k7[i] + cA108 * k8[i] + cA109 * k9[i]);
+}
+    R::ode(x + KC(C10) * h, y1, k10, p);
+{ const double cA111 = KC(A111), cA114 = KC(A114), cA115 = KC(A115), cA116 = KC(A116), cA117 = KC(A117), cA118 = KC(A118), cA119 = KC(A119), cA1110 = KC(A1110);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = y[i] + h * (cA111 * k1[i] + cA114 * k4[i] + cA115 * k5[i] + cA116 * k6[i] + cA117 * k7[i] + cA118 * k8[i] + cA119 * k9[i] + cA1110 * k10[i]);
+}
+    R::ode(x + KC(C11) * h, y1, k2, p);
+    const double xph = x + h;
+{ const double cA121 = KC(A121), cA124 = KC(A124), cA125 = KC(A125), cA126 = KC(A126), cA127 = KC(A127), cA128 = KC(A128), cA129 = KC(A129), cA1210 = KC(A1210), cA1211 = KC(A1211);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = y[i] + h * (cA121 * k1[i] + cA124 * k4[i] + cA125 * k5[i] + cA126 * k6[i] + cA127 * k7[i] + cA128 * k8[i] + cA129 * k9[i]
+                            + cA1210 * k10[i] + cA1211 * k2[i]);
+}
+    R::ode(xph, y1, k3, p);
+    L.d_nfev += 11;
+
+{ const double cB1 = KC(B1), cB6 = KC(B6), cB7 = KC(B7), cB8 = KC(B8), cB9 = KC(B9), cB10 = KC(B10), cB11 = KC(B11), cB12 = KC(B12);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        k4[i] = cB1 * k1[i] + cB6 * k6[i] + cB7 * k7[i] + cB8 * k8[i] + cB9 * k9[i] + cB10 * k10[i] + cB11 * k2[i] + cB12 * k3[i];
+        k5[i] = y[i] + h * k4[i];
+    }
+}
+    double err = 0.0, err2 = 0.0;
+{ const double cBH1 = KC(BH1), cBH2 = KC(BH2), cBH3 = KC(BH3), cER1 = KC(ER1), cER6 = KC(ER6), cER7 = KC(ER7), cER8 = KC(ER8), cER9 = KC(ER9), cER10 = KC(ER10), cER11 = KC(ER11), cER12 = KC(ER12);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double sk = a.atol[i] + a.rtol[i] * fmax(fabs(y[i]), fabs(k5[i]));
+        double erri = k4[i] - cBH1 * k1[i] - cBH2 * k9[i] - cBH3 * k3[i];
+        double q = erri / sk;
+        err2 += q * q;
+        erri = cER1 * k1[i] + cER6 * k6[i] + cER7 * k7[i] + cER8 * k8[i] + cER9 * k9[i] + cER10 * k10[i] + cER11 * k2[i] + cER12 * k3[i];
+        q = erri / sk;
+        err += q * q;
+    }
+}
+    double deno = err + 0.01 * err2;
+    if (deno <= 0.0) deno = 1.0;
+    err = fabs(h) * err * sqrt(1.0 / ((double)N * deno));
+
+    const double fac11 = ivp_pow(err, KC(expo1));
+    double fac = fac11 / ivp_pow(L.facold, beta);
+    fac = fmax(KC(facc2), fmin(KC(facc1), fac / KC(safety)));
+    double hnew = h / fac;
+
+    if (err <= 1.0) {
+        L.facold = fmax(err, KC(1.0e-4));
+        L.d_naccpt += 1;
+        if (L.acc_small < 2) L.acc_small += 1;
+        R::ode(xph, k5, k4, p);
+        L.d_nfev += 1;
+        if (stiff_tick(L.flags)) {  // dop853.rs:447-472
+            double stnum = 0.0, stden = 0.0;
+            bool stiff_break = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double d1 = k4[i] - k3[i];
+                const double d2 = k5[i] - y1[i];
+                stnum += d1 * d1;
+                stden += d2 * d2;
+            }
+            IVP_STIFF_BOOKKEEPING(6.1)
+            if (stiff_break) { L.h = h; L.status = 4; return false; }
+        }
+        // Dense output (dop853.rs:476-592).  The reference computes it on every accepted step
+        // (struct default dense_output = true) and counts its 3 evaluations in nfev; the
+        // coefficients feed nothing but the interpolant, so the kernel evaluates them only when
+        // this step's interpolant is actually consumed, and always counts the 3 evaluations.
+        L.d_nfev += 3;
+        double cont[FULL ? 8 * N : 1];
+        const bool need_dense = FULL && so_needs_dense<N, P>(a, L, x, xph);
+        if (FULL && need_dense) {
+{ const double cD41 = KC(D41), cD46 = KC(D46), cD47 = KC(D47), cD48 = KC(D48), cD49 = KC(D49), cD410 = KC(D410), cD411 = KC(D411), cD412 = KC(D412), cD51 = KC(D51), cD56 = KC(D56), cD57 = KC(D57), cD58 = KC(D58), cD59 = KC(D59), cD510 = KC(D510), cD511 = KC(D511), cD512 = KC(D512), cD61 = KC(D61), cD66 = KC(D66), cD67 = KC(D67), cD68 = KC(D68), cD69 = KC(D69), cD610 = KC(D610), cD611 = KC(D611), cD612 = KC(D612), cD71 = KC(D71), cD76 = KC(D76), cD77 = KC(D77), cD78 = KC(D78), cD79 = KC(D79), cD710 = KC(D710), cD711 = KC(D711), cD712 = KC(D712);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                cont[i] = y[i];
+                const double ydiff = k5[i] - y[i];
+                cont[N + i] = ydiff;
+                const double bspl = h * k1[i] - ydiff;
+                cont[2 * N + i] = bspl;
+                cont[3 * N + i] = ydiff - h * k4[i] - bspl;
+                cont[4 * N + i] = cD41 * k1[i] + cD46 * k6[i] + cD47 * k7[i] + cD48 * k8[i] + cD49 * k9[i] + cD410 * k10[i] + cD411 * k2[i] + cD412 * k3[i];
+                cont[5 * N + i] = cD51 * k1[i] + cD56 * k6[i] + cD57 * k7[i] + cD58 * k8[i] + cD59 * k9[i] + cD510 * k10[i] + cD511 * k2[i] + cD512 * k3[i];
+                cont[6 * N + i] = cD61 * k1[i] + cD66 * k6[i] + cD67 * k7[i] + cD68 * k8[i] + cD69 * k9[i] + cD610 * k10[i] + cD611 * k2[i] + cD612 * k3[i];
+                cont[7 * N + i] = cD71 * k1[i] + cD76 * k6[i] + cD77 * k7[i] + cD78 * k8[i] + cD79 * k9[i] + cD710 * k10[i] + cD711 * k2[i] + cD712 * k3[i];
+            }
+}
+{ const double cA141 = KC(A141), cA147 = KC(A147), cA148 = KC(A148), cA149 = KC(A149), cA1410 = KC(A1410), cA1411 = KC(A1411), cA1412 = KC(A1412), cA1413 = KC(A1413);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                y1[i] = y[i] + h * (cA141 * k1[i] + cA147 * k7[i] + cA148 * k8[i] + cA149 * k9[i] + cA1410 * k10[i] + cA1411 * k2[i] + cA1412 * k3[i] + cA1413 * k4[i]);
+}
+            R::ode(x + KC(C14) * h, y1, k10, p);
+{ const double cA151 = KC(A151), cA156 = KC(A156), cA157 = KC(A157), cA158 = KC(A158), cA1511 = KC(A1511), cA1512 = KC(A1512), cA1513 = KC(A1513), cA1514 = KC(A1514);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                y1[i] = y[i] + h * (cA151 * k1[i] + cA156 * k6[i] + cA157 * k7[i] + cA158 * k8[i] + cA1511 * k2[i] + cA1512 * k3[i] + cA1513 * k4[i] + cA1514 * k10[i]);
+}
+            R::ode(x + KC(C15) * h, y1, k2, p);
+{ const double cA161 = KC(A161), cA166 = KC(A166), cA167 = KC(A167), cA168 = KC(A168), cA169 = KC(A169), cA1613 = KC(A1613), cA1614 = KC(A1614), cA1615 = KC(A1615);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                y1[i] = y[i] + h * (cA161 * k1[i] + cA166 * k6[i] + cA167 * k7[i] + cA168 * k8[i] + cA169 * k9[i] + cA1613 * k4[i] + cA1614 * k10[i] + cA1615 * k2[i]);
+}
+            R::ode(x + KC(C16) * h, y1, k3, p);
+{ const double cD413 = KC(D413), cD414 = KC(D414), cD415 = KC(D415), cD416 = KC(D416), cD513 = KC(D513), cD514 = KC(D514), cD515 = KC(D515), cD516 = KC(D516), cD613 = KC(D613), cD614 = KC(D614), cD615 = KC(D615), cD616 = KC(D616), cD713 = KC(D713), cD714 = KC(D714), cD715 = KC(D715), cD716 = KC(D716);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                cont[4 * N + i] = h * (cont[4 * N + i] + cD413 * k4[i] + cD414 * k10[i] + cD415 * k2[i] + cD416 * k3[i]);
+                cont[5 * N + i] = h * (cont[5 * N + i] + cD513 * k4[i] + cD514 * k10[i] + cD515 * k2[i] + cD516 * k3[i]);
+                cont[6 * N + i] = h * (cont[6 * N + i] + cD613 * k4[i] + cD614 * k10[i] + cD615 * k2[i] + cD616 * k3[i]);
+                cont[7 * N + i] = h * (cont[7 * N + i] + cD713 * k4[i] + cD714 * k10[i] + cD715 * k2[i] + cD716 * k3[i]);
+            }
+}
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) { L.k1[i] = k4[i]; L.y[i] = k5[i]; }
+        L.x = xph;
+        if (FULL) solout_full<M_DOP853, N, P>(a, j, L, x, xph, L.y, need_dense ? cont : nullptr, h);
+        if (last) { L.h = hnew; L.status = 0; return false; }
+        if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
+        if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
+    } else {
+        hnew = h / fmin(KC(facc1), fac11 / KC(safety));
+        L.flags |= IVP_F_REJECT;
+        if (L.acc_small > 1) L.d_nrejct += 1;
+        last = false;
+    }
+    L.flags = last ? (L.flags | IVP_F_LAST) : (L.flags & ~IVP_F_LAST);
+    L.h = hnew;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RK23 attempt (rk23.rs:189-307)
+// ------------------------------------------------------------------------------------------------
+template <class R, bool FULL>
+IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
+{
+    KC_SCOPE
+    constexpr int N = R::N, P = R::P;
+    // tableau, rk23.rs:325-347
+    constexpr double C2 = 0.5, C3 = 0.75, A21 = 0.5, A32 = 0.75;
+    constexpr double B1 = 2.0 / 9.0, B2 = 1.0 / 3.0, B3 = 4.0 / 9.0;
+    constexpr double E1 = 5.0 / 72.0, E2 = -1.0 / 12.0, E3 = -1.0 / 9.0, E4 = 1.0 / 8.0;
+    constexpr double D21 = -4.0 / 3.0, D22 = 1.0, D23 = 4.0 / 3.0, D24 = -1.0;
+    constexpr double D31 = 5.0 / 9.0, D32 = -2.0 / 3.0, D33 = -8.0 / 9.0, D34 = 1.0;
+    constexpr double safety = 0.9, scale_min = 0.2, scale_max = 10.0;  // rk23.rs:16-36
+    constexpr double error_exponent = -1.0 / 3.0;
+
+    if (L.over || L.d_nstep >= L.budget) { L.status = 2; return false; }   // `steps.total >= nmax`
+    double h = L.h;
+    const double x = L.x;
+    if ((x + h - L.xend) * L.posneg > 0.0) h = L.xend - x;
+
+    const double *y = L.y, *k1 = L.k1, *p = L.p;
+    double k2[N], k3[N], k4[N], yt[N], ye[N];
+{ const double cA21 = KC(A21);
+#pragma unroll
+    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * cA21 * k1[i];
+}
+    R::ode(x + KC(C2) * h, yt, k2, p);
+{ const double cA32 = KC(A32);
+#pragma unroll
+    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * cA32 * k2[i];
+}
+    R::ode(x + KC(C3) * h, yt, k3, p);
+{ const double cB1 = KC(B1), cB2 = KC(B2), cB3 = KC(B3);
+#pragma unroll
+    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * (cB1 * k1[i] + cB2 * k2[i] + cB3 * k3[i]);
+}
+    R::ode(x + h, yt, k4, p);
+    L.d_nfev += 3;
+{ const double cE1 = KC(E1), cE2 = KC(E2), cE3 = KC(E3), cE4 = KC(E4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) ye[i] = h * (cE1 * k1[i] + cE2 * k2[i] + cE3 * k3[i] + cE4 * k4[i]);
+}
+    double err = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double tl = a.atol[i] + a.rtol[i] * fmax(fabs(yt[i]), fabs(y[i]));
+        const double q = ye[i] / tl;
+        err += q * q;
+    }
+    err = sqrt(err / (double)N);
+
+    if (err <= 1.0) {
+        L.d_nstep += 1;
+        L.d_naccpt += 1;
+        const double xnew = x + h;
+        if (FULL) {
+            double cont[4 * N];
+{ const double cD21 = KC(D21), cD22 = KC(D22), cD23 = KC(D23), cD24 = KC(D24), cD31 = KC(D31), cD32 = KC(D32), cD33 = KC(D33), cD34 = KC(D34);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                cont[i] = y[i];
+                cont[N + i] = k1[i];
+                cont[2 * N + i] = cD21 * k1[i] + cD22 * k2[i] + cD23 * k3[i] + cD24 * k4[i];
+                cont[3 * N + i] = cD31 * k1[i] + cD32 * k2[i] + cD33 * k3[i] + cD34 * k4[i];
+            }
+}
+#pragma unroll
+            for (int i = 0; i < N; ++i) L.y[i] = yt[i];
+            L.x = xnew;
+            solout_full<M_RK23, N, P>(a, j, L, x, xnew, L.y, cont, h);
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) L.y[i] = yt[i];
+            L.x = xnew;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) L.k1[i] = k4[i];
+        h *= fmax(fmin(KC(safety) * ivp_pow(err, KC(error_exponent)), KC(scale_max)), KC(scale_min));
+        if (fabs(h) > L.hmax) h = L.hmax * L.posneg;
+        L.h = h;
+        if (xnew == L.xend) { L.status = 0; return false; }
+    } else {
+        L.d_nrejct += 1;
+        h *= fmax(fmin(KC(safety) * ivp_pow(err, KC(error_exponent)), 1.0), KC(scale_min));
+        L.h = h;
+        // The reference never terminates from here when err is NaN (h *= 1.0 forever) or once h has
+        // collapsed to 0 (rk23.rs:300-306 has no underflow test).  A GPU lane must retire: report
+        // StepSizeTooSmall, the status DOPRI5/DOP853 give for the same situation.
+        if (err != err || h == 0.0) { L.status = 3; return false; }
+    }
+    if (L.h == 0.0 && L.x != L.xend) { L.status = 3; return false; }
+    return true;
+}
+
+// One chunk of step attempts for one lane. Every lane leaves after at most `chunk` attempts.
+template <int M, class R, bool FULL>
+IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
+{
+    Lane<R::N, R::P> L;
+    lane_load<R>(a, j, L, M == M_RK23, FULL);
+    if (a.has_max_step) L.hmax = (M == M_DOPRI5) ? a.max_step : fabs(a.max_step);
+    else L.hmax = fabs(L.xend - L.x0);
+    uint32_t it = 0;
+    bool run = true;
+    while (run && it < a.chunk) {
+        if constexpr (M == M_DOPRI5) run = dopri5_attempt<R, FULL>(a, j, L);
+        else if constexpr (M == M_DOP853) run = dop853_attempt<R, FULL>(a, j, L);
+        else run = rk23_attempt<R, FULL>(a, j, L);
+        ++it;
+    }
+    // Re-derive the store addresses from an opaque copy of j: otherwise the ~2 VGPRs per state array
+    // that the loads' address arithmetic produced stay live across the whole attempt loop.
+    uint32_t js = j;
+    IVP_OPAQUE_V(js);
+    lane_store<R>(a, js, L, FULL);
+    status_out = L.status;
+    return it;
+}
+
+}  // namespace IVP_NS

@@ -1,0 +1,71 @@
+// rk_global.h -- __global__ wrappers around the per-lane bodies of rk_core.h (device only).
+// Shared by the ahead-of-time kernels (rk_kernels.hip) and the hiprtc path (ivp_jit.cpp embeds this
+// text together with ivp_kargs.h and rk_core.h).
+#pragma once
+#ifndef IVP_MIN_WAVES
+#define IVP_MIN_WAVES 2
+#endif
+
+namespace IVP_NS {
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Append the ids of still-running trajectories to perm_out: ballot -> popcount -> one atomicAdd per
+// wave -> each lane writes at base + its rank among the set bits.
+__device__ __forceinline__ void compact_append(const IvpKArgs &a, uint32_t j, bool still)
+{
+    const unsigned long long m = __ballot(still);
+    if (m == 0ull) return;
+    const uint32_t lane = lane_id();
+    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(a.count_out, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (still) a.perm_out[base + rank] = j;
+}
+
+template <int M, class R, bool FULL>
+__global__ __launch_bounds__(IVP_WAVE) void init_kernel_t(const IvpKArgs a)
+{
+    const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x;
+    const bool valid = i < a.B;
+    int32_t st = 0;
+    if (valid) st = init_body<M, R, FULL>(a, i);
+    if (a.perm_out) compact_append(a, i, valid && st == IVP_RUNNING);
+}
+
+template <int M, class R, bool FULL>
+__device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
+{
+    const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x;
+    const uint32_t count = a.perm_in ? *a.count_in : a.B;
+    if (blockIdx.x * IVP_WAVE >= count) return;  // whole wave beyond the active set (stale grid bound)
+    const bool valid = i < count;
+    uint32_t j = 0;
+    bool active = false;
+    if (valid) {
+        j = a.perm_in ? a.perm_in[i] : i;
+        active = a.status[j] == IVP_RUNNING;
+    }
+    uint32_t it = 0;
+    int32_t st = 0;
+    if (active) it = chunk_body<M, R, FULL>(a, j, st);
+    const bool still = active && st == IVP_RUNNING;
+    compact_append(a, j, still);
+    if (a.slot_counter) {
+        // divergence accounting: lanes launched x attempts this wave actually ran (= its slowest lane)
+        uint32_t mx = it;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        if (lane_id() == 0) atomicAdd(a.slot_counter, (unsigned long long)mx * IVP_WAVE);
+    }
+}
+
+template <int M, class R, bool FULL>
+__global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void chunk_kernel_t(const IvpKArgs a)
+{
+    chunk_kernel_body<M, R, FULL>(a);
+}
+
+}  // namespace IVP_NS

@@ -1,0 +1,75 @@
+// rk_kernels.hip -- gfx950 kernels of the batched explicit RK integrator and their launch table.
+//
+// Compiled twice (see Makefile):
+//   -DIVP_FAST=0 -ffp-contract=off   -> ivp_launch_strict   (reference operation order, no FMA fusion)
+//   -DIVP_FAST=1 -ffp-contract=fast  -> ivp_launch_fast     (FMA contraction + reciprocal sharing)
+//
+// Launch geometry: one 64-lane wavefront per workgroup, one lane per trajectory.  There is no LDS
+// and no barrier (trajectories are independent), so a one-wave workgroup frees its SIMD slot the
+// moment its slowest lane retires and the dispatcher back-fills it; grids are >> 256 CUs x 4 SIMDs
+// for every BASELINE config (100k trajectories = 1563 waves, 1M = 15625).  SoA state makes each
+// per-component access one contiguous 512-byte wave transaction.  Lanes whose trajectory has retired
+// are predicated off inside a chunk; between chunks the still-running ids are compacted with a
+// wave ballot + one atomic per wave so the next launch runs dense wavefronts again.
+#include <hip/hip_runtime.h>
+
+#define IVP_HD __host__ __device__ __forceinline__
+#if IVP_FAST
+#define IVP_NS ivp_fast
+#else
+#define IVP_NS ivp_strict
+#endif
+#include "rk_core.h"
+#include "rk_global.h"
+#include "rk_launch.h"
+
+namespace {
+
+using namespace IVP_NS;
+
+template <int M, class R, bool FULL>
+hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+{
+    const dim3 grid((lanes + IVP_WAVE - 1) / IVP_WAVE), block(IVP_WAVE);
+    if (grid.x == 0) return hipSuccess;
+    if (what == IVP_LAUNCH_INIT) hipLaunchKernelGGL((init_kernel_t<M, R, FULL>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((chunk_kernel_t<M, R, FULL>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+template <class R>
+hipError_t launch_rhs(int what, int method, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+{
+    switch (method) {
+    case M_RK23:
+        return full ? launch_one<M_RK23, R, true>(what, a, lanes, s) : launch_one<M_RK23, R, false>(what, a, lanes, s);
+    case M_DOPRI5:
+        return full ? launch_one<M_DOPRI5, R, true>(what, a, lanes, s) : launch_one<M_DOPRI5, R, false>(what, a, lanes, s);
+    case M_DOP853:
+        return full ? launch_one<M_DOP853, R, true>(what, a, lanes, s) : launch_one<M_DOP853, R, false>(what, a, lanes, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+#if IVP_FAST
+#define IVP_LAUNCH_NAME ivp_launch_fast
+#else
+#define IVP_LAUNCH_NAME ivp_launch_strict
+#endif
+
+hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+{
+    switch (rhs_id) {
+    case 0: return launch_rhs<IVP_NS::RhsDecay>(what, method, full, a, lanes, s);
+    case 1: return launch_rhs<IVP_NS::RhsSho>(what, method, full, a, lanes, s);
+    case 2: return launch_rhs<IVP_NS::RhsVdp>(what, method, full, a, lanes, s);
+    case 3: return launch_rhs<IVP_NS::RhsCr3bp>(what, method, full, a, lanes, s);
+    case 4: return launch_rhs<IVP_NS::RhsLorenz>(what, method, full, a, lanes, s);
+    case 5: return launch_rhs<IVP_NS::RhsZero>(what, method, full, a, lanes, s);
+    case 6: return launch_rhs<IVP_NS::RhsRational>(what, method, full, a, lanes, s);
+    case 7: return launch_rhs<IVP_NS::RhsExp2>(what, method, full, a, lanes, s);
+    }
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,69 @@
+// emul.cpp -- TEST-ONLY harness: runs the per-lane kernel bodies of ivp_amd/csrc/rk_core.h on the
+// CPU, lane by lane, with the same init -> chunk -> chunk ... schedule the GPU launch loop uses.
+//
+// It exists because the authoring container has no GPU: it lets the `-m "not gpu"` tests check the
+// kernel logic (chunk boundaries, state save/restore, flag packing, DefaultSolOut on the device)
+// bit for bit against the CPU oracle before any GPU minute is spent.  It is NOT part of the
+// product: nothing in ivp_amd/ or libivp_hip.so links or loads it, and the product has no CPU path.
+// Compiled with g++ -ffp-contract=off (strict) or -ffp-contract=fast -DIVP_FAST=1 (fast).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#define IVP_HD inline
+#define IVP_NS ivp_emul
+#include "../../ivp_amd/csrc/rk_core.h"
+
+using namespace ivp_emul;
+
+template <int M, class R, bool FULL>
+static void run_all(IvpKArgs a, uint64_t *chunks_out)
+{
+    uint64_t chunks = 0;
+    for (uint32_t j = 0; j < a.B; ++j) {
+        int32_t st = init_body<M, R, FULL>(a, j);
+        while (st == IVP_RUNNING) {
+            chunk_body<M, R, FULL>(a, j, st);
+            ++chunks;
+        }
+    }
+    if (chunks_out) *chunks_out = chunks;
+}
+
+template <class R>
+static int run_rhs(int method, bool full, const IvpKArgs &a, uint64_t *chunks)
+{
+    switch (method) {
+    case 0: full ? run_all<0, R, true>(a, chunks) : run_all<0, R, false>(a, chunks); return 0;
+    case 1: full ? run_all<1, R, true>(a, chunks) : run_all<1, R, false>(a, chunks); return 0;
+    case 2: full ? run_all<2, R, true>(a, chunks) : run_all<2, R, false>(a, chunks); return 0;
+    }
+    return -1;
+}
+
+extern "C" int emul_is_fast(void) { return IVP_FAST; }
+
+extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint64_t *chunks)
+{
+    IvpKArgs a = *args;
+    const size_t B = a.B;
+    // scratch the library would own
+    std::vector<double> k1(8 * B), facold(B), hlamb(B), t_last(B);
+    std::vector<uint32_t> flags(B);
+    std::vector<int32_t> next_idx(B);
+    a.k1 = k1.data(); a.facold = facold.data(); a.hlamb = hlamb.data(); a.flags = flags.data();
+    a.t_last = t_last.data(); a.next_idx = next_idx.data();
+    switch (rhs_id) {
+    case 0: return run_rhs<RhsDecay>(method, full, a, chunks);
+    case 1: return run_rhs<RhsSho>(method, full, a, chunks);
+    case 2: return run_rhs<RhsVdp>(method, full, a, chunks);
+    case 3: return run_rhs<RhsCr3bp>(method, full, a, chunks);
+    case 4: return run_rhs<RhsLorenz>(method, full, a, chunks);
+    case 5: return run_rhs<RhsZero>(method, full, a, chunks);
+    case 6: return run_rhs<RhsRational>(method, full, a, chunks);
+    case 7: return run_rhs<RhsExp2>(method, full, a, chunks);
+    }
+    return -1;
+}
+
+extern "C" size_t emul_kargs_size(void) { return sizeof(IvpKArgs); }

@@ -1,0 +1,128 @@
+"""TEST-ONLY driver of tests/host_emul/libemul_{strict,fast}.so (see emul.cpp): runs the per-lane
+kernel bodies of ivp_amd/csrc/rk_core.h on the CPU with the GPU launch loop's chunk schedule."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+VP = C.c_void_p
+
+
+class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
+    _fields_ = [
+        ("B", C.c_uint32),
+        ("y0", VP), ("params", VP), ("t0", VP), ("t1", VP),
+        ("t0_stride", C.c_uint32), ("t1_stride", C.c_uint32),
+        ("rtol", C.c_double * 8), ("atol", C.c_double * 8),
+        ("first_step", C.c_double), ("max_step", C.c_double),
+        ("nmax", C.c_uint64),
+        ("has_first_step", C.c_int32), ("has_max_step", C.c_int32),
+        ("y", VP), ("k1", VP), ("x", VP), ("h", VP), ("facold", VP), ("hlamb", VP),
+        ("flags", VP), ("status", VP), ("nfev", VP), ("nstep", VP), ("naccpt", VP), ("nrejct", VP),
+        ("perm_in", VP), ("count_in", VP), ("perm_out", VP), ("count_out", VP),
+        ("chunk", C.c_uint32),
+        ("t_eval", VP), ("n_eval", C.c_int32),
+        ("y_eval", VP), ("eval_idx", VP), ("n_filled", VP), ("next_idx", VP),
+        ("max_log", C.c_uint32),
+        ("t_log", VP), ("y_log", VP), ("n_log", VP), ("t_last", VP),
+        ("collect_dense", C.c_int32),
+        ("seg_cont", VP), ("seg_xold", VP), ("seg_h", VP), ("n_seg", VP),
+        ("slot_counter", VP),
+    ]
+
+
+_libs = {}
+RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7}
+RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0)}
+METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2}
+NCOEF = {0: 4, 1: 5, 2: 8}
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def lib(fast=False):
+    key = bool(fast)
+    if key not in _libs:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libemul_fast.so" if fast else "libemul_strict.so"))
+        L.emul_solve.restype = C.c_int
+        L.emul_solve.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(KArgs), C.POINTER(C.c_uint64)]
+        L.emul_kargs_size.restype = C.c_size_t
+        assert L.emul_kargs_size() == C.sizeof(KArgs), (L.emul_kargs_size(), C.sizeof(KArgs))
+        assert L.emul_is_fast() == int(fast)
+        _libs[key] = L
+    return _libs[key]
+
+
+def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
+                first_step=None, max_step=None, dense_output=False, max_log=0, chunk=64, fast=False):
+    L = lib(fast)
+    rid = RHS[rhs]
+    n, npar = RHS_DIMS[rid]
+    m = METHODS[method.upper()]
+    y0 = np.ascontiguousarray(y0, dtype=np.float64)
+    B = y0.shape[1]
+    params = np.ascontiguousarray(params, dtype=np.float64) if npar else np.zeros((1, B))
+    t0 = np.atleast_1d(np.asarray(t0, dtype=np.float64)).copy()
+    t1 = np.atleast_1d(np.asarray(t1, dtype=np.float64)).copy()
+    a = KArgs()
+    a.B = B
+    p = lambda arr: arr.ctypes.data_as(VP)
+    a.y0, a.params, a.t0, a.t1 = p(y0), p(params), p(t0), p(t1)
+    a.t0_stride, a.t1_stride = int(t0.size > 1), int(t1.size > 1)
+    rt = np.broadcast_to(np.asarray(rtol, dtype=np.float64), (n,))
+    at = np.broadcast_to(np.asarray(atol, dtype=np.float64), (n,))
+    for i in range(8):
+        a.rtol[i] = rt[i] if i < n else rt[-1]
+        a.atol[i] = at[i] if i < n else at[-1]
+    a.first_step = float(first_step or 0.0)
+    a.has_first_step = int(first_step is not None)
+    a.max_step = float(max_step or 0.0)
+    a.has_max_step = int(max_step is not None)
+    a.nmax = int(max_steps) if max_steps else 2 ** 64 - 1
+    res = {
+        "y_end": np.zeros((n, B)), "t_end": np.zeros(B), "h_next": np.zeros(B), "status": np.zeros(B, dtype=np.int32),
+        "nfev": np.zeros(B, dtype=np.uint64), "nstep": np.zeros(B, dtype=np.uint64),
+        "naccpt": np.zeros(B, dtype=np.uint64), "nrejct": np.zeros(B, dtype=np.uint64),
+    }
+    a.y, a.x, a.h, a.status = p(res["y_end"]), p(res["t_end"]), p(res["h_next"]), p(res["status"])
+    a.nfev, a.nstep, a.naccpt, a.nrejct = p(res["nfev"]), p(res["nstep"]), p(res["naccpt"]), p(res["nrejct"])
+    a.chunk = chunk
+    a.n_eval = -1
+    full = t_eval is not None or max_log > 0
+    keep = []
+    if full:
+        res["n_filled"] = np.zeros(B, dtype=np.int32)
+        res["n_log"] = np.zeros(B, dtype=np.uint32)
+        res["n_seg"] = np.zeros(B, dtype=np.uint32)
+        a.n_filled, a.n_log, a.n_seg = p(res["n_filled"]), p(res["n_log"]), p(res["n_seg"])
+        if t_eval is not None:
+            te = np.ascontiguousarray(t_eval, dtype=np.float64)
+            keep.append(te)
+            ne = te.size
+            a.n_eval = ne
+            a.t_eval = p(te) if ne else None
+            res["y_eval"] = np.full((max(ne, 1), n, B), np.nan)
+            res["eval_idx"] = np.full((max(ne, 1), B), -1, dtype=np.int32)
+            a.y_eval, a.eval_idx = p(res["y_eval"]), p(res["eval_idx"])
+        elif max_log > 0:
+            res["t_log"] = np.full((max_log, B), np.nan)
+            res["y_log"] = np.full((max_log, n, B), np.nan)
+            a.t_log, a.y_log = p(res["t_log"]), p(res["y_log"])
+        a.max_log = max_log
+        if dense_output and max_log > 0:
+            nc = NCOEF[m] * n
+            res["seg_cont"] = np.full((max_log, nc, B), np.nan)
+            res["seg_xold"] = np.full((max_log, B), np.nan)
+            res["seg_h"] = np.full((max_log, B), np.nan)
+            a.seg_cont, a.seg_xold, a.seg_h = p(res["seg_cont"]), p(res["seg_xold"]), p(res["seg_h"])
+            a.collect_dense = 1
+    chunks = C.c_uint64(0)
+    rc = L.emul_solve(m, rid, int(full), C.byref(a), C.byref(chunks))
+    assert rc == 0
+    res["chunks"] = chunks.value
+    return res
