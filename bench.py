@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X batched explicit-RK integrator.
+
+Workload (BASELINE.json configs[1], "C2"): 100 000 independent 6-state CR3BP trajectories (perturbed
+Arenstorf orbits, one period), DOPRI5, rtol=1e-6, atol=1e-9, inputs resident in HBM.
+One "step" = one complete solve of that batch (init kernel + chunked stepping kernels until every
+trajectory has reached t_end).  Metric: accepted RK steps per second, aggregate over the batch and
+over all ranks.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, every rank integrates its own 100k-trajectory shard of a parameter sweep
+(weak scaling; trajectories are independent so there is no data-path collective) and the end states
+are gathered with one RCCL all-gather per step inside the timed region (BASELINE config C4).
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (HBM view, as the contract asks),
+"roofline_fp64" (the resource that actually binds this kernel: FP64 VALU issue) and "cpu_baseline"
+(the CPU oracle, i.e. the C restatement of the reference algorithm, timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (FMA = 2 flop), SURVEY.md section 8d
+# Algorithmic work of ONE DOPRI5 step attempt on the 6-state CR3BP system:
+#   stage AXPYs 46 + error combo 13 + norm 8 + dense 19 = 86 flop/component, 6 RHS evaluations of ~45 flop,
+#   plus 13 sqrt, ~38 div and 2 pow counted as one flop each.
+FLOP_PER_ATTEMPT = 86 * 6 + 6 * 45 + 13 + 38 + 2
+# Algorithmic HBM bytes per trajectory per stepping-kernel launch: state in + state out
+#   in : y[6] k1[6] x h facold hlamb (16 f64) + mu + flags,status (2x4) + nstep,naccpt (2x8) + perm id 4
+#   out: y[6] k1[6] x h facold hlamb (16 f64) + flags,status + 4 counters read-modify-write (4x16) + perm id 4
+BYTES_PER_LANE_LAUNCH = (16 * 8 + 8 + 8 + 16 + 4) + (16 * 8 + 8 + 64 + 4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=100_000, help="trajectories per GPU (BASELINE C2: 100000)")
+    ap.add_argument("--fp", choices=["strict", "fast"], default="strict")
+    ap.add_argument("--chunk", type=int, default=0, help="step attempts per launch (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import ivp_amd
+    from ivp_amd import workloads as W
+
+    B = args.batch
+    # parameter sweep: rank r integrates its own B perturbed orbits (seed offset => distinct shards)
+    y0, p, t0, t1 = W.cr3bp_batch(B, seed=20260102 + rank)
+    y0d = torch.as_tensor(y0, device=dev)
+    pd = torch.as_tensor(p, device=dev)
+    fp = ivp_amd.FpMode.FAST if args.fp == "fast" else ivp_amd.FpMode.STRICT
+    opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp, chunk_attempts=args.chunk, profile=1)
+    prob = ivp_amd.CR3BP()
+    ctx = ivp_amd.Context(local_rank)
+    out = None
+    gathered = torch.empty((world, 6, B), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        nonlocal out
+        out = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, ctx, out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out.y_end)  # C4: RCCL gather of sol.y over xGMI
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    kern_ms = launches = attempts = slots = lane_launches = 0.0
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = out.stats
+        kern_ms += st["step_kernel_ms"]
+        launches += st["launches"]
+        slots += st["lane_attempt_slots"]
+        lane_launches += st["lane_launches"]
+    sync_all()
+    elapsed = time.perf_counter() - t_begin
+
+    acc = int(out.naccpt.sum().item())
+    attempts = float(out.nstep.sum().item()) * args.steps  # DOPRI5: nstep counts every attempt (dopri5.rs:285)
+    ok = bool((out.status == 0).all().item())
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_acc = torch.tensor([float(acc)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_acc, op=dist.ReduceOp.SUM)
+    elapsed = float(t_el.item())
+    total_acc_per_step = float(t_acc.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_acc_per_step * args.steps / elapsed
+        avg_launch_ms = kern_ms / max(launches, 1)
+        attempts_per_launch = attempts / max(launches, 1)
+        lanes_per_launch = lane_launches / max(launches, 1)  # trajectories that load + store their state
+        bytes_per_launch = lanes_per_launch * BYTES_PER_LANE_LAUNCH
+        gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        tflops = attempts_per_launch * FLOP_PER_ATTEMPT / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes_per_launch.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "accepted RK steps/sec (aggregate), batched CR3BP DOPRI5 @ rtol=1e-6",
+            "value": value,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: 100k independent 6-state CR3BP trajectories (perturbed Arenstorf orbits, one period), "
+                            "DOPRI5 rtol=1e-6 atol=1e-9; one step = whole batch integrated to t_end",
+                "trajectories_per_gpu": B,
+                "fp_mode": args.fp,
+                "chunk_attempts": opts.chunk_attempts or 64,
+                "parallelism": f"dp{world} (independent shards" + (", RCCL all-gather of y_end per step)" if world > 1 else ")"),
+            },
+            "wall_ms_to_t_end": ms_per_step,
+            "accepted_steps_per_batch": total_acc_per_step,
+            "all_success": ok,
+            "wave_lane_utilisation": attempts / slots if slots else None,
+            "roofline": {
+                "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "chunk_kernel_t<DOPRI5, RhsCr3bp, lean>", "avg_launch_ms": avg_launch_ms,
+                "launches_per_step": launches / args.steps,
+                "note": "state is device-resident: HBM traffic is per trajectory per launch, not per step; "
+                        "this fraction is informational, the binding resource is FP64 VALU issue (roofline_fp64)",
+            },
+            "roofline_fp64": {
+                "bound": "valu_fp64", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP64_PEAK_TFLOPS, "flop_per_attempt": FLOP_PER_ATTEMPT,
+                "attempts_per_launch": attempts_per_launch,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(y0, p, t0, t1):
+    """The CPU oracle (C restatement of the reference algorithm, libm pow, -ffp-contract=off) on this host's
+    cores: B back-to-back solve_ivp calls, OpenMP over trajectories.  Bounded to ~10-30 s of CPU work."""
+    from oracle import oracle as O
+    O.build()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU
+    n1 = 4096
+    t = time.perf_counter()
+    r1 = O.solve_batch("cr3bp", y0[:, :n1], p[:, :n1], t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=1)
+    dt1 = time.perf_counter() - t
+    single = r1["total_accepted"] / dt1
+    nall = y0.shape[1]
+    t = time.perf_counter()
+    r = O.solve_batch("cr3bp", y0[:, :nall], p[:, :nall], t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=cores)
+    dt = time.perf_counter() - t
+    return {
+        "value": r["total_accepted"] / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+        "sample": f"the same {nall} CR3BP trajectories, one solve_ivp call each, OpenMP over trajectories "
+                  f"({cores} threads, {dt:.2f} s wall); single thread on the first {n1}: {single:.3e} steps/s",
+        "single_core_value": single,
+        "what": "oracle/ivp_oracle.c: C restatement of the reference (Rust) algorithm; the crate cannot be built here",
+    }
+
+
+if __name__ == "__main__":
+    main()

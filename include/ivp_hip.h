@@ -126,7 +126,8 @@ typedef struct {
     int32_t chunk_attempts; /* step attempts per kernel launch between compactions; 0 = auto */
     uint32_t max_log;       /* capacity (per trajectory) of the accepted-step log t_log/y_log and of the
                                dense-segment log; 0 = do not record (end state only) */
-    int32_t profile;        /* 1: time every kernel launch with HIP events (see ivp_run_stats_t) */
+    int32_t profile;        /* 1: time every kernel launch with HIP events (see ivp_run_stats_t);
+                               2: additionally sum naccpt / attempts over the batch on the host */
 } ivp_options_t;
 
 /* Per-trajectory results: `struct Solution` (src/solve/solution.rs:7-20) + IntegrationResult.h
@@ -166,6 +167,7 @@ typedef struct {
     uint64_t total_accepted;    /* sum over the batch of naccpt                          */
     uint64_t total_attempts;    /* sum over the batch of step attempts                   */
     uint64_t lane_attempt_slots;/* sum over launches of (lanes launched x attempts the wave ran): divergence accounting */
+    uint64_t lane_launches;     /* sum over launches of trajectories that loaded + stored their state */
 } ivp_run_stats_t;
 
 typedef struct ivp_ctx ivp_ctx_t;

@@ -48,6 +48,7 @@ class RunStatsT(C.Structure):
         ("launches", C.c_uint32), ("init_launches", C.c_uint32),
         ("step_kernel_ms", C.c_double), ("init_kernel_ms", C.c_double), ("total_ms", C.c_double),
         ("total_accepted", C.c_uint64), ("total_attempts", C.c_uint64), ("lane_attempt_slots", C.c_uint64),
+        ("lane_launches", C.c_uint64),
     ]
 
 
@@ -86,6 +87,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C ivp_amd/csrc` (or __graft_entry__.build()). "
             "ivp_amd has no CPU fallback.")
+    # PyTorch-ROCm ships its own libamdhip64; two HIP runtimes in one process cannot both own the
+    # device.  Loading torch's first lets the dynamic linker resolve our DT_NEEDED libamdhip64.so.N
+    # to the copy that is already mapped, so tensors and this library share one runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     L.ivp_abi_version.restype = C.c_int
     L.ivp_device_count.restype = C.c_int

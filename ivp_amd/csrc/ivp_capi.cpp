@@ -297,8 +297,8 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     const bool profile = opt->profile != 0;
     ctx->stats = ivp_run_stats_t{};
     if (profile) {
-        HIP_TRY(ctx, ctx->slot.reserve(sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->slot.p, 0, sizeof(unsigned long long), s));
+        HIP_TRY(ctx, ctx->slot.reserve(2 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->slot.p, 0, 2 * sizeof(unsigned long long), s));
         a.slot_counter = (unsigned long long *)ctx->slot.p;
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 4, s));
@@ -380,9 +380,11 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
         }
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_t0, ev_end));
         ctx->stats.total_ms = ms;
-        unsigned long long slots = 0;
-        HIP_TRY(ctx, hipMemcpy(&slots, ctx->slot.p, sizeof slots, hipMemcpyDeviceToHost));
-        ctx->stats.lane_attempt_slots = slots;
+        unsigned long long slots[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(slots, ctx->slot.p, sizeof slots, hipMemcpyDeviceToHost));
+        ctx->stats.lane_attempt_slots = slots[0];
+        ctx->stats.lane_launches = slots[1];
+        if (opt->profile >= 2) {
         std::vector<uint64_t> tmp(B);
         HIP_TRY(ctx, hipMemcpy(tmp.data(), a.naccpt, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
         uint64_t acc = 0, att = 0;
@@ -397,6 +399,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
             for (uint64_t v : tmp) att += v;
         }
         ctx->stats.total_attempts = att;
+        }
     }
     return IVP_OK;
 }

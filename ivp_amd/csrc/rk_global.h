@@ -58,7 +58,11 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
         uint32_t mx = it;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-        if (lane_id() == 0) atomicAdd(a.slot_counter, (unsigned long long)mx * IVP_WAVE);
+        const unsigned long long act = __ballot(active);
+        if (lane_id() == 0) {
+            atomicAdd(a.slot_counter, (unsigned long long)mx * IVP_WAVE);
+            atomicAdd(a.slot_counter + 1, (unsigned long long)__popcll(act));  // trajectories that moved state this launch
+        }
     }
 }
 

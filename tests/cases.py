@@ -1,0 +1,146 @@
+"""Parity cases shared by the CPU (emulated kernel bodies) and GPU (C ABI) test files.
+
+Each case is (name, rhs, builder) where builder() -> (y0[n,B], params[p,B] or None, t0, t1, options).
+Options use the reference's field names (src/solve/options.rs:75-123).
+"""
+import numpy as np
+
+from ivp_amd import workloads as W
+
+
+def _rep(v, B):
+    return np.repeat(np.asarray(v, dtype=np.float64)[:, None], B, axis=1)
+
+
+def c2_cr3bp(B=256, method="DOPRI5", rtol=1e-6, atol=1e-9):
+    def b():
+        y0, p, t0, t1 = W.cr3bp_batch(B)
+        return y0, p, t0, t1, dict(method=method, rtol=rtol, atol=atol)
+    return b
+
+
+def c3_vdp(B=256, method="DOP853", rtol=1e-8, atol=1e-10):
+    def b():
+        y0, p, t0, t1 = W.vdp_batch(B)
+        return y0, p, t0, t1, dict(method=method, rtol=rtol, atol=atol)
+    return b
+
+
+def c1_decay():
+    return np.array([[1.0]]), np.array([[0.5]]), 0.0, 10.0, dict(method="DOPRI5", rtol=1e-6, atol=1e-9)
+
+
+def sho(method, t0=0.0, t1=2 * np.pi, B=70, **kw):
+    def b():
+        rng = np.random.default_rng(5)
+        y0 = np.stack([np.cos(rng.uniform(0, 1, B)), np.sin(rng.uniform(0, 1, B))])
+        y0[:, 0] = [1.0, 0.0]
+        o = dict(method=method, rtol=1e-9, atol=1e-9)
+        o.update(kw)
+        return y0, None, t0, t1, o
+    return b
+
+
+def lorenz(method):
+    def b():
+        B = 65
+        rng = np.random.default_rng(11)
+        y0 = 1.0 + 0.1 * rng.standard_normal((3, B))
+        p = _rep([10.0, 28.0, 8.0 / 3.0], B) * (1.0 + 0.01 * rng.standard_normal((3, B)))
+        return y0, p, 0.0, 3.0, dict(method=method, rtol=1e-8, atol=1e-10)
+    return b
+
+
+def rational(method, t1):
+    def b():
+        B = 33
+        y0 = _rep([1 / 3, 2 / 9], B)
+        y0 *= 1.0 + 1e-3 * np.arange(B) / B
+        return y0, None, 5.0, t1, dict(method=method, rtol=1e-3, atol=1e-6)
+    return b
+
+
+def zero_rhs(method):
+    def b():
+        te = np.array([10.0 * i / 20.0 for i in range(21)])
+        return np.ones((3, 5)), None, 0.0, 10.0, dict(method=method, rtol=1e-9, atol=1e-12, t_eval=te)
+    return b
+
+
+def exp2_vector_rtol():
+    return np.ones((2, 9)), None, 0.0, 1.0, dict(method="DOPRI5", rtol=[1e-2, 1e-10], atol=1e-10)
+
+
+def mixed_intervals(method):
+    """Per-trajectory t0/t1 including zero-length and backward intervals in one batch."""
+    def b():
+        B = 96
+        rng = np.random.default_rng(3)
+        y0 = rng.standard_normal((2, B))
+        t0 = rng.uniform(-1, 1, B)
+        t1 = t0 + rng.uniform(-3, 3, B)
+        t1[::7] = t0[::7]                # zero interval: solve_ivp.rs:110-145
+        t1[3::11] = t0[3::11] + 1e-16    # |xend-x0| < 1e-15
+        return y0, None, t0, t1, dict(method=method, rtol=1e-6, atol=1e-8)
+    return b
+
+
+def blowup_vdp_backward(method):
+    """Van der Pol integrated backwards blows up in finite time: DOPRI5/DOP853 must end with StepSizeTooSmall
+    (dopri5.rs:274-277).  (RK23 has no such test in the reference and never terminates there.)"""
+    def b():
+        B = 24
+        rng = np.random.default_rng(3)
+        y0 = rng.standard_normal((2, B))
+        t0 = rng.uniform(-1, 1, B)
+        return y0, np.full((1, B), 1.0), t0, t0 - 3.0, dict(method=method, rtol=1e-6, atol=1e-8)
+    return b
+
+
+def stiff_vdp(method):
+    """Large-mu Van der Pol with an explicit method: exercises the stiffness detector (ProbablyStiff)."""
+    def b():
+        B = 8
+        y0 = _rep([2.0, 0.0], B)
+        p = np.array([[1.0, 5.0, 50.0, 200.0, 500.0, 1000.0, 2000.0, 5000.0]])
+        return y0, p, 0.0, 40.0, dict(method=method, rtol=1e-4, atol=1e-6)
+    return b
+
+
+def long_sho(method):
+    """> 1000 accepted steps per trajectory: crosses the `accepted % 1000 == 0` stiffness-test cadence."""
+    def b():
+        B = 6
+        y0 = _rep([1.0, 0.0], B)
+        y0[0] += 0.01 * np.arange(B)
+        rt = 1e-10 if method != "RK23" else 1e-6
+        return y0, None, 0.0, 60.0, dict(method=method, rtol=rt, atol=rt)
+    return b
+
+
+CASES = []
+for m, rt, at in (("DOPRI5", 1e-6, 1e-9), ("DOP853", 1e-8, 1e-10), ("RK23", 1e-4, 1e-7)):
+    CASES.append((f"C2-cr3bp-{m}", "cr3bp", c2_cr3bp(256, m, rt, at)))
+    CASES.append((f"C3-vdp-{m}", "vdp", c3_vdp(256, m, rt, at)))
+CASES.append(("C1-decay", "decay", c1_decay))
+for m in ("RK23", "DOPRI5", "DOP853"):
+    CASES.append((f"sho-fwd-{m}", "sho", sho(m)))
+    CASES.append((f"sho-bwd-{m}", "sho", sho(m, 2 * np.pi, 0.0)))
+    CASES.append((f"sho-maxstep-{m}", "sho", sho(m, 0.0, 3.0, rtol=1e-6, atol=1e-9, max_step=0.05)))
+    CASES.append((f"sho-negmaxstep-{m}", "sho", sho(m, 0.0, 3.0, rtol=1e-6, atol=1e-9, max_step=-0.05)))
+    CASES.append((f"sho-firststep-{m}", "sho", sho(m, 0.0, 3.0, rtol=1e-3, atol=1e-6, first_step=0.1)))
+    CASES.append((f"sho-negfirststep-bwd-{m}", "sho", sho(m, 3.0, 0.0, rtol=1e-3, atol=1e-6, first_step=0.1)))
+    CASES.append((f"sho-maxsteps1-{m}", "sho", sho(m, 0.0, 3.0, max_steps=1)))
+    CASES.append((f"sho-maxsteps40-{m}", "sho", sho(m, 0.0, 30.0, max_steps=40)))
+    CASES.append((f"lorenz-{m}", "lorenz", lorenz(m)))
+    CASES.append((f"rational-fwd-{m}", "rational", rational(m, 9.0)))
+    CASES.append((f"rational-bwd-{m}", "rational", rational(m, 1.0)))
+    CASES.append((f"zero-{m}", "zero", zero_rhs(m)))
+    CASES.append((f"mixed-intervals-{m}", "sho", mixed_intervals(m)))
+    CASES.append((f"long-sho-{m}", "sho", long_sho(m)))
+for m in ("DOPRI5", "DOP853"):
+    CASES.append((f"stiff-vdp-{m}", "vdp", stiff_vdp(m)))
+    CASES.append((f"blowup-vdp-bwd-{m}", "vdp", blowup_vdp_backward(m)))
+CASES.append(("exp2-vector-rtol", "exp2", exp2_vector_rtol))
+
+CASE_IDS = [c[0] for c in CASES]

@@ -9,7 +9,7 @@ for B in (100_000,):
     y0d, pd = torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev)
     for fp in (ivp_amd.FpMode.STRICT, ivp_amd.FpMode.FAST):
         for chunk in (32, 64, 128, 512):
-            opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp, chunk_attempts=chunk, profile=True)
+            opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp, chunk_attempts=chunk, profile=2)
             for it in range(3):
                 torch.cuda.synchronize(); t = time.perf_counter()
                 r = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0d, pd, opts)

@@ -1,20 +1,253 @@
-"""GPU parity tests proper: libivp_hip.so (through the C ABI) against the CPU oracle.  Run with -m gpu."""
+"""GPU parity tests proper: libivp_hip.so, called through the C ABI, against the CPU oracle.  Run with -m gpu.
+
+Bars (BASELINE.json north_star: "results match the reference CPU solve_ivp ... within a stated floating-point
+tolerance"):
+  * strict FP mode: BIT-EXACT equality with the oracle's portable-pow build for y_end, t_end, h_next and every
+    counter (the GPU evaluates the same IEEE-754 operation sequence);
+  * against the oracle's libm-pow build (what the Rust crate calls): differences come only from a few-ulp step
+    factor -- tolerance 1e-9 absolute on O(1) states over non-chaotic horizons, stated in each test;
+  * fast FP mode: same tolerance, and end-state error vs an independent truth within 10x of the oracle's.
+"""
+import json
+import os
+
 import numpy as np
 import pytest
 
 from ivp_amd import workloads as W
+from oracle import oracle as O
+from tests.cases import CASES, CASE_IDS, c2_cr3bp, c3_vdp
 from tests.common import assert_bitexact, gpu_batch, oracle_batch
 
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
+
+@pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
+def test_strict_gpu_bitexact_vs_oracle(case):
+    name, rhs, build = case
+    y0, p, t0, t1, o = build()
+    g = gpu_batch(rhs, y0, p, t0, t1, chunk=23, **o)
+    r = oracle_batch(rhs, y0, p, t0, t1, threads=8, **o)
+    assert_bitexact(g, r, name + ": ")
+    if "t_eval" in o:
+        assert np.array_equal(g["n_filled"], r["n_filled"])
+        m = g["n_filled"]
+        for b in range(y0.shape[1]):
+            assert np.array_equal(g["y_eval"][: m[b], :, b], r["y_eval"][: m[b], :, b])
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64, 4096])
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+def test_chunk_size_and_compaction_do_not_change_results(method, chunk):
+    y0, p, t0, t1, o = c3_vdp(300, method)()
+    a = gpu_batch("vdp", y0, p, t0, t1, chunk=chunk, **o)
+    b = oracle_batch("vdp", y0, p, t0, t1, threads=8, **o)
+    assert_bitexact(a, b)
+
+
+def test_device_pointer_entry_point_matches_host_entry_point():
+    y0, p, t0, t1, o = c2_cr3bp(1000)()
+    a = gpu_batch("cr3bp", y0, p, t0, t1, **o)
+    b = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, **o)
+    assert_bitexact(a, b)
+
+
+def test_nan_and_inf_lanes_retire_without_poisoning_neighbours():
+    B = 200
+    y0 = np.tile(np.array([[1.0], [0.0]]), (1, B))
+    y0[0, 3] = np.nan
+    y0[1, 77] = np.inf
+    t0 = np.full(B, 0.5)
+    for method in ("DOPRI5", "DOP853"):
+        g = gpu_batch("sho", y0, None, t0, 3.0, method=method, rtol=1e-6, atol=1e-9)
+        r = oracle_batch("sho", y0, None, t0, 3.0, method=method, rtol=1e-6, atol=1e-9)
+        assert g["status"][3] == 3 and g["status"][77] == 3
+        assert_bitexact(g, r, method + ": ")
+    g = gpu_batch("sho", y0, None, t0, 3.0, method="RK23", rtol=1e-6, atol=1e-9)
+    assert g["status"][3] == 3 and g["status"][77] == 3      # the reference would spin forever here
+    good = np.ones(B, bool); good[[3, 77]] = False
+    assert (g["status"][good] == 0).all()
+
+
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+@pytest.mark.parametrize("direction", ["fwd", "bwd"])
+def test_t_eval_sampling_matches_oracle(method, direction):
+    B = 130
+    rng = np.random.default_rng(2)
+    y0 = np.stack([np.full(B, 1 / 3), np.full(B, 2 / 9)]) * (1 + 1e-3 * rng.standard_normal((2, B)))
+    if direction == "fwd":
+        t0, t1 = 5.0, 9.0
+        te = np.array([4.0, 5.0, 5.01, 5.5, 7.0, 8.0, 8.01, 9.0, 9.5])
+    else:
+        t0, t1 = 5.0, 1.0
+        te = np.array([5.0, 4.99, 3.0, 1.5, 1.1, 1.0, 0.5])
+    o = dict(method=method, rtol=1e-3, atol=1e-6, t_eval=te)
+    g = gpu_batch("rational", y0, None, t0, t1, chunk=5, **o)
+    for b in range(0, B, 13):
+        s = O.solve_ivp("rational", t0, t1, y0[:, b], detpow=True, **o)
+        m = g["n_filled"][b]
+        assert m == len(s.t)
+        assert np.array_equal(te[g["eval_idx"][:m, b]], s.t)
+        assert np.array_equal(g["y_eval"][:m, :, b], s.y)
+
+
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+@pytest.mark.parametrize("first_step", [None, 0.1])
+def test_step_log_and_dense_segments_match_oracle(method, first_step):
+    B = 70
+    rng = np.random.default_rng(4)
+    y0 = np.stack([np.cos(rng.uniform(0, 1, B)), np.sin(rng.uniform(0, 1, B))])
+    for (t0, t1) in ((0.0, 3.0), (3.0, 0.0)):
+        o = dict(method=method, rtol=1e-5, atol=1e-8, dense_output=True)
+        if first_step is not None:
+            o["first_step"] = first_step
+        g = gpu_batch("sho", y0, None, t0, t1, max_log=512, chunk=9, **o)
+        for b in range(0, B, 9):
+            s = O.solve_ivp("sho", t0, t1, y0[:, b], detpow=True, **o)
+            m = g["n_log"][b]
+            assert m == len(s.t)
+            assert np.array_equal(g["t_log"][:m, b], s.t)
+            assert np.array_equal(g["y_log"][:m, :, b], s.y)
+            ns = g["n_seg"][b]
+            assert ns == len(s.seg_h)
+            assert np.array_equal(g["seg_xold"][:ns, b], s.seg_xold)
+            assert np.array_equal(g["seg_h"][:ns, b], s.seg_h)
+            assert np.array_equal(g["seg_cont"][:ns, :, b], s.seg_cont)
+
+
+# ---- against the libm-pow oracle (the faithful restatement) and against independent truth --------------
 
 @pytest.mark.parametrize("method,rtol,atol", [("DOPRI5", 1e-6, 1e-9), ("DOP853", 1e-8, 1e-10), ("RK23", 1e-4, 1e-7)])
-def test_cr3bp_strict_bitexact_vs_oracle(method, rtol, atol):
-    """Strict-FP kernels reproduce the CPU restatement bit for bit (y, t, h, every counter) when both use
-    the same portable step-controller pow: proves IEEE-correct f64 div/sqrt on gfx950 and that the
-    kernel is the same operation sequence as the reference algorithm."""
-    y0, p, t0, t1 = W.cr3bp_batch(2048)
-    g = gpu_batch("cr3bp", y0, p, t0, t1, method=method, rtol=rtol, atol=atol)
-    o = oracle_batch("cr3bp", y0, p, t0, t1, method=method, rtol=rtol, atol=atol, threads=8)
+@pytest.mark.parametrize("fast", [False, True])
+def test_short_horizon_agreement_with_libm_pow_oracle(method, rtol, atol, fast):
+    """short-horizon (t1 = 2.0, before the close lunar approach) GPU-vs-CPU agreement.
+    Tolerance: 1e-9 absolute on O(1) states; step counts identical for >= 95 % of the trajectories."""
+    y0, p, t0, _ = W.cr3bp_batch(1024)
+    g = gpu_batch("cr3bp", y0, p, t0, 2.0, method=method, rtol=rtol, atol=atol, fast=fast)
+    r = oracle_batch("cr3bp", y0, p, t0, 2.0, detpow=False, threads=8, method=method, rtol=rtol, atol=atol)
     assert (g["status"] == 0).all()
-    assert_bitexact(g, o, f"{method}: ")
+    assert np.abs(g["y_end"] - r["y_end"]).max() < 1e-9
+    assert np.mean(g["naccpt"] == r["naccpt"]) > 0.95
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_c2_end_state_error_within_10x_of_cpu_reference(fast):
+    """BASELINE target: end-state error (vs SciPy DOP853@1e-13 truth) within 10x of the CPU reference's."""
+    truth = np.asarray(json.load(open(os.path.join(GOLD, "scipy_truth.json")))["truth"]["cr3bp"]["y_end"])
+    n = len(truth)
+    y0, p, t0, t1 = W.cr3bp_batch(256)
+    g = gpu_batch("cr3bp", y0[:, :n], p[:, :n], t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, fast=fast)
+    r = oracle_batch("cr3bp", y0[:, :n], p[:, :n], t0, t1, detpow=False, method="DOPRI5", rtol=1e-6, atol=1e-9)
+    eg = np.abs(g["y_end"].T - truth).max(axis=1)
+    er = np.abs(r["y_end"].T - truth).max(axis=1)
+    assert np.median(eg) <= 10.0 * np.median(er)
+    assert eg.max() <= 10.0 * er.max()
+
+
+# ---- BASELINE full sizes: size-independent properties -----------------------------------------------------
+
+def _jacobi(s, mu):
+    x, y, z, vx, vy, vz = s
+    r1 = np.sqrt((x + mu) ** 2 + y * y + z * z)
+    r2 = np.sqrt((x - 1.0 + mu) ** 2 + y * y + z * z)
+    return 2.0 * (0.5 * (x * x + y * y) + (1.0 - mu) / r1 + mu / r2) - (vx * vx + vy * vy + vz * vz)
+
+
+def test_c2_full_size_100k_cr3bp_dopri5():
+    B = 100_000
+    y0, p, t0, t1 = W.cr3bp_batch(B)
+    o = dict(method="DOPRI5", rtol=1e-6, atol=1e-9)
+    g = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, **o)
+    assert (g["status"] == 0).all() and (g["t_end"] == t1).all()
+    assert (g["nfev"] == 2 + 6 * g["nstep"]).all()                       # dopri5.rs:231,235,325
+    assert (g["nstep"] >= g["naccpt"] + g["nrejct"]).all()
+    # integral of motion (examples/cr3bp.rs:14-20): drift bounded by the tolerance scale
+    drift = np.abs(_jacobi(g["y_end"], p[0]) - _jacobi(y0, p[0]))
+    assert np.median(drift) < 1e-3 and drift.max() < 1.0
+    # determinism + independence from batch composition: any sub-batch reproduces the same bits
+    idx = np.random.default_rng(0).choice(B, 300, replace=False)
+    sub = gpu_batch("cr3bp", y0[:, idx], p[:, idx], t0, t1, **o)
+    for k in ("y_end", "t_end", "h_next", "nfev", "nstep", "naccpt", "nrejct"):
+        assert np.array_equal(np.asarray(g[k])[..., idx], sub[k]), k
+    # and that sub-batch equals the CPU oracle bit for bit
+    r = oracle_batch("cr3bp", y0[:, idx], p[:, idx], t0, t1, threads=8, **o)
+    assert_bitexact(sub, r)
+
+
+def test_c3_full_size_1m_vdp_dop853():
+    B = 1_000_000
+    y0, p, t0, t1 = W.vdp_batch(B)
+    # odd symmetry of Van der Pol: f(-y) = -f(y) and the error norm is even, so the second half of the batch
+    # (negated initial states, same end times) must come out as the exact negative of the first half
+    h = B // 2
+    y0[:, h:] = -y0[:, :h]
+    t1[h:] = t1[:h]
+    o = dict(method="DOP853", rtol=1e-8, atol=1e-10)
+    g = gpu_batch("vdp", y0, p, t0, t1, device_arrays=True, **o)
+    assert (g["status"] == 0).all() and (g["t_end"] == t1).all()
+    assert np.array_equal(g["y_end"][:, h:], -g["y_end"][:, :h])
+    assert np.array_equal(g["naccpt"][h:], g["naccpt"][:h]) and np.array_equal(g["nrejct"][h:], g["nrejct"][:h])
+    assert (g["nfev"] == 2 + 11 * g["nstep"] + 4 * g["naccpt"]).all()     # dop853.rs:390,444,560
+    idx = np.random.default_rng(1).choice(B, 256, replace=False)
+    r = oracle_batch("vdp", y0[:, idx], p[:, idx], t0, t1[idx], threads=8, **o)
+    for k in ("y_end", "t_end", "h_next", "nfev", "nstep", "naccpt", "nrejct", "status"):
+        assert np.array_equal(np.asarray(g[k])[..., idx].astype(r[k].dtype), r[k]), k
+
+
+# ---- user-defined right-hand side (hiprtc): the device-side `impl IVP` -----------------------------------
+
+CR3BP_SRC = r"""
+__device__ void ode(double t, const double* s, double* d, const double* p)
+{
+    const double mu = p[0];
+    const double x = s[0], y = s[1], z = s[2], vx = s[3], vy = s[4], vz = s[5];
+    const double a = x + mu, b = x - 1.0 + mu;
+    const double r1 = sqrt(a * a + y * y + z * z), r2 = sqrt(b * b + y * y + z * z);
+    const double r13 = r1 * r1 * r1, r23 = r2 * r2 * r2;
+    d[0] = vx; d[1] = vy; d[2] = vz;
+    d[3] = x + 2.0 * vy - (1.0 - mu) * (x + mu) / r13 - mu * (x - 1.0 + mu) / r23;
+    d[4] = y - 2.0 * vx - (1.0 - mu) * y / r13 - mu * y / r23;
+    d[5] = -(1.0 - mu) * z / r13 - mu * z / r23;
+}
+"""
+
+
+def test_user_rhs_compiled_with_hiprtc_matches_builtin_and_oracle():
+    import ivp_amd
+    y0, p, t0, t1 = W.cr3bp_batch(500)
+    f = ivp_amd.DeviceIVP(CR3BP_SRC, n=6, params=(W.ARENSTORF_MU,))
+    for method, rt, at in (("DOPRI5", 1e-6, 1e-9), ("DOP853", 1e-8, 1e-10), ("RK23", 1e-4, 1e-7)):
+        o = ivp_amd.Options(method=method, rtol=rt, atol=at)
+        r = ivp_amd.solve_ivp_batch(f, t0, t1, y0, p, o)
+        ref = oracle_batch("cr3bp", y0, p, t0, t1, threads=8, method=method, rtol=rt, atol=at)
+        got = {k: getattr(r, k) for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct")}
+        assert_bitexact(got, ref, f"jit {method}: ")
+
+
+def test_user_rhs_python_callable_cross_check():
+    """A system that is NOT among the built-ins: damped driven pendulum, checked against the oracle driven by the
+    same formula as a Python callable."""
+    import ivp_amd
+    src = r"""
+    __device__ void ode(double t, const double* y, double* d, const double* p)
+    {
+        d[0] = y[1];
+        d[1] = -p[0] * y[1] - sin(y[0]) + p[1] * cos(p[2] * t);
+    }
+    """
+    par = (0.2, 0.7, 1.3)
+    f = ivp_amd.DeviceIVP(src, n=2, params=par)
+    s = ivp_amd.solve_ivp(f, 0.0, 10.0, [0.3, 0.0], ivp_amd.Options(method="DOPRI5", rtol=1e-8, atol=1e-10))
+    o = O.solve_ivp(lambda t, y, p: [y[1], -par[0] * y[1] - np.sin(y[0]) + par[1] * np.cos(par[2] * t)],
+                    0.0, 10.0, [0.3, 0.0], method="DOPRI5", rtol=1e-8, atol=1e-10)
+    assert s.status == 0 and len(s.t) == len(o.t)
+    # sin/cos come from different libms (ocml vs glibc): tolerance 1e-10 on an O(1) state
+    np.testing.assert_allclose(s.y[-1], o.y[-1], rtol=0, atol=1e-10)
+
+
+def test_jit_syntax_error_is_reported_not_fatal():
+    import ivp_amd
+    with pytest.raises(ivp_amd.ConfigError) as e:
+        ivp_amd.DeviceIVP("__device__ void ode(double t, const double* y, double* d, const double* p) { d[0] = ; }", n=1)
+    assert e.value.code == -104

@@ -1,0 +1,196 @@
+"""The reference's own explicit-RK tests, restated against the PRODUCT API (ivp_amd.solve_ivp -> libivp_hip.so ->
+gfx950 kernels) so that they read like the crate's tests (tests/accuracy.rs, tests/ivp.rs,
+tests/backward_and_bounds.rs and the explicit-RK cases of tests/test_ivp.py / test_step_control.py /
+test_t_eval.py).  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import ivp_amd
+from ivp_amd import SHO, ExponentialDecay, Exp2, Method, Options, Rational, Status, ZeroRhs, solve_ivp
+
+pytestmark = pytest.mark.gpu
+EXPLICIT = [Method.RK23, Method.DOPRI5, Method.DOP853]
+
+
+def default_opts(method, **kw):  # tests/common.rs:21-28
+    return Options(method=method, rtol=1e-9, atol=1e-9, **kw)
+
+
+def sol_rational(t):
+    t = np.asarray(t)
+    return np.asarray((t / (t + 10), 10 * t / (t + 10) ** 2))
+
+
+def compute_error(y, y_true, rtol, atol):
+    e = (y - y_true) / (atol + rtol * np.abs(y_true))
+    return np.linalg.norm(e, axis=0) / np.sqrt(e.shape[0])
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_harmonic_accuracy_end_state(method):  # tests/accuracy.rs:18-48
+    sol = solve_ivp(SHO(), 0.0, 2 * np.pi, [1.0, 0.0], default_opts(method))
+    y_end = sol.y[-1]
+    assert abs(y_end[0] - 1.0) < 1e-5 and abs(y_end[1]) < 1e-5
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_t_eval_sampling_exact_times(method):  # tests/accuracy.rs:51-77
+    t_eval = [i / 10.0 for i in range(11)]
+    sol = solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method=method, rtol=1e-9, atol=1e-9, t_eval=t_eval))
+    for te in t_eval:
+        assert np.any(np.abs(sol.t - te) <= 1e-9)
+    assert len(sol.y) == len(sol.t)
+
+
+def test_iterate_samples():  # tests/accuracy.rs:80-89
+    sol = solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], default_opts(Method.DOPRI5))
+    for t, y in sol.iter():
+        assert 0.0 <= t <= 1.0 and len(y) == 2
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_integration_zero_rhs(method):  # tests/ivp.rs:21-46
+    t_eval = [10.0 * i / 20.0 for i in range(21)]
+    sol = solve_ivp(ZeroRhs(), 0.0, 10.0, [1.0, 1.0, 1.0], Options(method=method, rtol=1e-9, atol=1e-12, t_eval=t_eval))
+    assert np.array_equal(sol.t, t_eval)
+    assert np.abs(sol.y - 1.0).max() <= 1e-12
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_max_step_and_first_step_controls(method):  # tests/ivp.rs:49-104
+    sol = solve_ivp(SHO(), 0.0, 3.0, [1.0, 0.0], Options(method=method, rtol=1e-6, atol=1e-9, max_step=0.05))
+    assert np.abs(np.diff(sol.t)).max() <= 0.05 + 1e-12
+    sol = solve_ivp(SHO(), 0.0, 3.0, [1.0, 0.0], Options(method=method, rtol=1e-3, atol=1e-6, first_step=0.1))
+    assert len(sol.t) >= 2 and abs(abs(sol.t[1] - sol.t[0]) - 0.1) <= 1e-6
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_dense_output_matches_discrete_samples(method):  # tests/ivp.rs:107-136
+    sol = solve_ivp(SHO(), 0.0, 2.0, [1.0, 0.0], Options(method=method, rtol=1e-8, atol=1e-10, dense_output=True))
+    assert sol.sol_span() is not None
+    ys = sol.sol_many(sol.t)
+    assert ys.shape == sol.y.shape and np.abs(ys - sol.y).max() <= 1e-8
+
+
+def test_dense_output_out_of_range_errors():  # tests/ivp.rs:139-149
+    sol = solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], default_opts(Method.DOPRI5, dense_output=True))
+    t0, t1 = sol.sol_span()
+    with pytest.raises(ivp_amd.InterpolationError):
+        sol.sol(t0 - 0.1)
+    with pytest.raises(ivp_amd.InterpolationError):
+        sol.sol(t1 + 0.1)
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_zero_interval_returns_initial_state(method):  # tests/ivp.rs:278-289
+    sol = solve_ivp(SHO(), 1.23, 1.23, [2.0, 3.0], default_opts(method))
+    assert len(sol.t) >= 1 and np.abs(sol.y[-1] - [2.0, 3.0]).max() <= 1e-12
+
+
+def test_vector_rtol_componentwise_control():  # tests/ivp.rs:291-334
+    loose = solve_ivp(Exp2(), 0.0, 1.0, [1.0, 1.0], Options(method=Method.DOPRI5, rtol=[1e-2, 1e-2], atol=1e-10))
+    tight = solve_ivp(Exp2(), 0.0, 1.0, [1.0, 1.0], Options(method=Method.DOPRI5, rtol=[1e-2, 1e-10], atol=1e-10))
+    e = np.e
+    assert abs(tight.y[-1][1] - e) < abs(loose.y[-1][1] - e) * 0.5
+    assert abs(tight.y[-1][0] - e) <= 10.0 * abs(loose.y[-1][0] - e)
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_backward_integration_works(method):  # tests/backward_and_bounds.rs:7-32
+    sol = solve_ivp(SHO(), 2 * np.pi, 0.0, [1.0, 0.0], default_opts(method, dense_output=True))
+    t0, t1 = sol.sol_span()
+    assert t0 > t1
+    mid = 0.5 * (t0 + t1)
+    y_mid = sol.sol(mid)
+    assert abs(y_mid[0] - np.cos(mid)) < 1e-6 and abs(y_mid[1] + np.sin(mid)) < 1e-6
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+@pytest.mark.parametrize("t_span", [(5.0, 9.0), (5.0, 1.0)])
+def test_integration_rational(method, t_span):  # tests/test_ivp.py:173-241
+    rtol, atol = 1e-3, 1e-6
+    res = solve_ivp(Rational(), t_span[0], t_span[1], [1 / 3, 2 / 9],
+                    Options(method=method, rtol=rtol, atol=atol, dense_output=True))
+    assert res.t[0] == t_span[0] and res.status == Status.Success
+    if method == Method.DOP853:
+        assert res.nfev < 50
+    assert res.njev == 0 and res.nlu == 0
+    assert np.all(compute_error(res.y.T, sol_rational(res.t), rtol, atol) < 5)
+    tc = np.linspace(*t_span)
+    yc = np.array([res.continuous_sol.evaluate_extrapolate(t) for t in tc]).T
+    assert np.all(compute_error(yc, sol_rational(tc), rtol, atol) < 5)
+    ys = np.array([res.continuous_sol.evaluate_extrapolate(t) for t in res.t])
+    np.testing.assert_allclose(ys, res.y, rtol=1e-15, atol=1e-15)
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+@pytest.mark.parametrize("t_span", [(5.0, 9.0), (5.0, 1.0)])
+def test_max_step_and_first_step_python(method, t_span):  # tests/test_ivp.py:521-583
+    res = solve_ivp(Rational(), t_span[0], t_span[1], [1 / 3, 2 / 9],
+                    Options(method=method, rtol=1e-3, atol=1e-6, max_step=0.5, first_step=0.1, dense_output=True))
+    assert res.t[0] == t_span[0] and res.t[-1] == t_span[-1]
+    assert np.all(np.abs(np.diff(res.t)) <= 0.5 + 1e-15)
+    np.testing.assert_allclose(0.1, abs(res.t[1] - 5.0))
+    assert res.status == Status.Success
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_max_steps_parameter(method):  # tests/test_step_control.py:93-109
+    res = solve_ivp(ExponentialDecay(1.0), 0.0, 10.0, [1.0], Options(method=method, max_steps=1))
+    assert res.status == Status.NeedLargerNMax and not res.status.is_success()
+    with pytest.raises(ivp_amd.ConfigError) as e:       # nmax == 0 => Err(Config(MustBePositive)), dopri5.rs:183-189
+        solve_ivp(ExponentialDecay(1.0), 0.0, 10.0, [1.0], Options(method=method, max_steps=0))
+    assert e.value.code == -1
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_default_max_steps_is_unlimited(method):  # tests/test_step_control.py:130-159
+    res = solve_ivp(ExponentialDecay(0.001), 0.0, 1e5, [1.0], Options(method=method, rtol=1e-8, atol=1e-10))
+    assert res.status == Status.Success and res.t[-1] == 1e5
+    np.testing.assert_allclose(res.y[-1][0], np.exp(-100.0), rtol=1e-4)
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_t_eval_python(method):  # tests/test_ivp.py:586-672, tests/test_t_eval.py:9-134
+    y0 = [1 / 3, 2 / 9]
+    for t_span in ((5.0, 9.0), (5.0, 1.0)):
+        te = np.linspace(*t_span, 10)
+        res = solve_ivp(Rational(), t_span[0], t_span[1], y0, Options(method=method, rtol=1e-3, atol=1e-6, t_eval=te))
+        assert np.array_equal(res.t, te) and res.status == Status.Success
+        assert np.all(compute_error(res.y.T, sol_rational(res.t), 1e-3, 1e-6) < 5)
+        resd = solve_ivp(Rational(), t_span[0], t_span[1], y0,
+                         Options(method=method, rtol=1e-3, atol=1e-6, t_eval=te, dense_output=True))
+        assert np.array_equal(resd.y, res.y)
+    res = solve_ivp(Rational(), 5.0, 9.0, y0, Options(method=method, t_eval=[5.01, 7.0, 8.0, 8.01]))
+    assert np.array_equal(res.t, [5.01, 7.0, 8.0, 8.01])
+    res = solve_ivp(Rational(), 5.0, 1.0, y0, Options(method=method, t_eval=[4.99, 3.0, 1.5, 1.1]))
+    assert np.array_equal(res.t, [4.99, 3.0, 1.5, 1.1])
+
+
+@pytest.mark.parametrize("method", EXPLICIT)
+def test_no_integration_and_empty(method):  # tests/test_ivp.py:704-728
+    sol = solve_ivp(Rational(), 4.0, 4.0, [2.0, 4.0], Options(method=method, dense_output=True))
+    np.testing.assert_array_equal(sol.continuous_sol.evaluate_extrapolate(4.0), [2.0, 4.0])
+    np.testing.assert_array_equal(sol.continuous_sol.evaluate_extrapolate(6.0), [2.0, 4.0])
+    sol = solve_ivp(SHO(), 0.0, 10.0, [], Options(method=method, dense_output=True))
+    assert np.array_equal(sol.t, [0.0, 10.0]) and sol.y.shape == (2, 0)
+
+
+def test_c1_exponential_decay():  # BASELINE config C1: README.md:74,93-101 and examples/exponential_decay.rs:16-26
+    sol = solve_ivp(ExponentialDecay(0.5), 0.0, 10.0, [1.0], Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
+    assert sol.status == Status.Success and sol.t[0] == 0.0 and sol.t[-1] == 10.0
+    assert abs(sol.y[-1][0] - np.exp(-5.0)) < 1e-6
+    te = np.arange(11.0)
+    sol = solve_ivp(ExponentialDecay(0.5), 0.0, 10.0, [10.0], Options(method="DOPRI5", rtol=1e-8, atol=1e-10, t_eval=te))
+    assert np.array_equal(sol.t, te)
+    assert np.abs(sol.y[:, 0] - 10.0 * np.exp(-0.5 * te)).max() < 1e-6
+
+
+def test_unsupported_methods_and_bad_tolerances_are_config_errors():
+    with pytest.raises(ivp_amd.ConfigError) as e:
+        solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method="BDF"))
+    assert e.value.code == -101
+    with pytest.raises(ivp_amd.ConfigError) as e:      # Tolerance::Vector length mismatch (mod.rs:156-161)
+        solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(rtol=[1e-3, 1e-3, 1e-3]))
+    assert e.value.code == -4
+    assert Method.from_str("rk45") == Method.DOPRI5 and Method.from_str("nonsense") == Method.DOPRI5  # options.rs:61-73
