@@ -32,7 +32,7 @@ class OptionsT(C.Structure):
         ("has_first_step", C.c_int32), ("first_step", C.c_double),
         ("has_max_step", C.c_int32), ("max_step", C.c_double),
         ("dense_output", C.c_int32),
-        ("fp_mode", C.c_int32), ("chunk_attempts", C.c_int32), ("max_log", C.c_uint32), ("profile", C.c_int32),
+        ("fp_mode", C.c_int32), ("chunk_attempts", C.c_int32), ("max_log", C.c_uint32), ("variant", C.c_int32), ("profile", C.c_int32),
     ]
 
 

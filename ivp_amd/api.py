@@ -222,6 +222,7 @@ class Options:
     fp_mode: FpMode = FpMode.STRICT
     chunk_attempts: int = 0
     max_log: int = 0
+    variant: int = 0                   # stepping-kernel variant: 0 auto, 1 lean registers, 2 coefficients resident
     profile: int = 0                   # 1: HIP-event kernel timing, 2: + batch totals (see ivp_run_stats_t)
 
     def _c(self, n: int, keep: list) -> _lib.OptionsT:
@@ -256,6 +257,7 @@ class Options:
         o.fp_mode = int(self.fp_mode)
         o.chunk_attempts = int(self.chunk_attempts)
         o.max_log = int(self.max_log)
+        o.variant = int(self.variant)
         o.profile = int(self.profile)
         return o
 

@@ -303,11 +303,13 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 4, s));
 
-    auto launch = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast : ivp_launch_strict;
+    auto launch_lean = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast : ivp_launch_strict;
+    auto launch_hoist = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast_hoist : ivp_launch_strict_hoist;
+    bool use_hoist = false;
     const bool jit = prob->rhs_id == IVP_RHS_JIT;
     auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
         if (jit) return ivp_jit_launch(prob->jit, what, opt->method, opt->fp_mode, full, ka, lanes, s);
-        return launch(what, opt->method, prob->rhs_id, full, ka, lanes, s);
+        return (use_hoist ? launch_hoist : launch_lean)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
     };
 
     size_t ev_used = 0;
@@ -347,6 +349,13 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     uint64_t c = 0;  // chunk number
     for (;;) {
         const bool tail = adaptive && lanes <= kOneWavePerSimd;
+        // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
+        // registers; auto = resident once at most two waves per SIMD are left to run
+        // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;
+        //  fast-mode FMA fusion differs between them, so there it is fixed by the batch size to keep every
+        //  trajectory's result independent of what else is in the batch at launch time)
+        use_hoist = opt->variant == 2 ||
+                    (opt->variant == 0 && (opt->fp_mode == IVP_FP_FAST ? B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd);
         const int launches_per_sync = tail ? 1 : 4;
         const uint32_t this_chunk = tail ? 1024u : chunk;
         for (int r = 0; r < launches_per_sync; ++r, ++c) {

@@ -40,14 +40,23 @@
 // inside the loop (KC_SCOPE) makes each constant loop-variant as far as LICM can tell: it costs
 // two `s_xor_b32 sN, sZ, literal` SALU instructions per use (they co-issue with the other waves'
 // VALU work) and keeps the live register set down to the integrator's real state.
-// On the host (tests/host_emul) KC is the identity.
-#if defined(__HIP_DEVICE_COMPILE__)
+// On the host (tests/host_emul) KC is the identity.  Build variant IVP_HOIST=1 also makes it the identity:
+// that variant lets LLVM keep every coefficient resident in registers (~250 VGPRs, one or two waves per
+// SIMD) and is the right trade once the active set no longer over-subscribes the chip, where the SALU
+// moves of the lean variant sit on the critical path of a lone wave.
+#ifndef IVP_HOIST
+#define IVP_HOIST 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !IVP_HOIST
 #define KC_SCOPE const uint64_t ivp_kz = IVP_NS::ivp_opaque_zero();
 #define KC(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kz)
-#define IVP_OPAQUE_V(v) asm volatile("" : "+v"(v))
 #else
 #define KC_SCOPE
 #define KC(c) (c)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IVP_OPAQUE_V(v) asm volatile("" : "+v"(v))
+#else
 #define IVP_OPAQUE_V(v) ((void)0)
 #endif
 

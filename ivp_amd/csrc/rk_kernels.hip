@@ -3,6 +3,8 @@
 // Compiled twice (see Makefile):
 //   -DIVP_FAST=0 -ffp-contract=off   -> ivp_launch_strict   (reference operation order, no FMA fusion)
 //   -DIVP_FAST=1 -ffp-contract=fast  -> ivp_launch_fast     (FMA contraction + reciprocal sharing)
+// and each of those once more with -DIVP_HOIST=1 (coefficients resident in registers, see KC() in rk_core.h)
+//                                    -> ivp_launch_strict_hoist / ivp_launch_fast_hoist
 //
 // Launch geometry: one 64-lane wavefront per workgroup, one lane per trajectory.  There is no LDS
 // and no barrier (trajectories are independent), so a one-wave workgroup frees its SIMD slot the
@@ -14,10 +16,21 @@
 #include <hip/hip_runtime.h>
 
 #define IVP_HD __host__ __device__ __forceinline__
-#if IVP_FAST
+#ifndef IVP_HOIST
+#define IVP_HOIST 0
+#endif
+#if IVP_FAST && IVP_HOIST
+#define IVP_NS ivp_fast_h
+#define IVP_LAUNCH_NAME ivp_launch_fast_hoist
+#elif IVP_FAST
 #define IVP_NS ivp_fast
+#define IVP_LAUNCH_NAME ivp_launch_fast
+#elif IVP_HOIST
+#define IVP_NS ivp_strict_h
+#define IVP_LAUNCH_NAME ivp_launch_strict_hoist
 #else
 #define IVP_NS ivp_strict
+#define IVP_LAUNCH_NAME ivp_launch_strict
 #endif
 #include "rk_core.h"
 #include "rk_global.h"
@@ -52,12 +65,6 @@ hipError_t launch_rhs(int what, int method, bool full, const IvpKArgs &a, uint32
 }
 
 }  // namespace
-
-#if IVP_FAST
-#define IVP_LAUNCH_NAME ivp_launch_fast
-#else
-#define IVP_LAUNCH_NAME ivp_launch_strict
-#endif
 
 hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {

@@ -7,4 +7,6 @@ enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1 };
 
 // `lanes` = upper bound of trajectories the launch has to cover (grid = ceil(lanes / 64) one-wave blocks).
 hipError_t ivp_launch_strict(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_strict_hoist(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_fast_hoist(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 hipError_t ivp_launch_fast(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);

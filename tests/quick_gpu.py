@@ -25,14 +25,14 @@ if __name__ == "__main__":
     if "c2" in which:
         y0, p, t0, t1 = W.cr3bp_batch(100_000)
         for fp in (ivp_amd.FpMode.STRICT, ivp_amd.FpMode.FAST):
-            for chunk in (0, 64, 256):
-                r = run(f"C2 {fp.name} chunk={chunk}", ivp_amd.CR3BP(), y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp, chunk_attempts=chunk)
+            for variant in (1, 2, 0):
+                r = run(f"C2 {fp.name} variant={variant}", ivp_amd.CR3BP(), y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp, variant=variant)
         ns = r.nstep.cpu().numpy()
         print("attempt percentiles", np.percentile(ns, [0, 50, 90, 99, 99.9, 99.99, 100]), "count>256", (ns > 256).sum(), ">384", (ns > 384).sum())
     if "c3" in which:
         y0, p, t0, t1 = W.vdp_batch(1_000_000)
         for fp in (ivp_amd.FpMode.STRICT, ivp_amd.FpMode.FAST):
-            for chunk in (0, 32, 128):
-                r = run(f"C3 {fp.name} chunk={chunk}", ivp_amd.VanDerPol(), y0, p, t0, t1, reps=3, method="DOP853", rtol=1e-8, atol=1e-10, fp_mode=fp, chunk_attempts=chunk)
+            for variant in (1, 2, 0):
+                r = run(f"C3 {fp.name} variant={variant}", ivp_amd.VanDerPol(), y0, p, t0, t1, reps=3, method="DOP853", rtol=1e-8, atol=1e-10, fp_mode=fp, variant=variant)
         ns = r.nstep.cpu().numpy()
         print("attempt percentiles", np.percentile(ns, [0, 50, 90, 99, 100]))
