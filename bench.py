@@ -62,7 +62,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
@@ -80,16 +81,16 @@ def main():
     prob = ivp_amd.CR3BP()
     ctx = ivp_amd.Context(local_rank)
     out = None
-    gathered = torch.empty((world, 6, B), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((world, 6, B), dtype=torch.float64, device=dev) if dist is not None else None
 
     def step():
         nonlocal out
         out = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, ctx, out)
-        if world > 1:
+        if dist is not None:
             dist.all_gather_into_tensor(gathered, out.y_end)  # C4: RCCL gather of sol.y over xGMI
 
     def sync_all():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -113,7 +114,7 @@ def main():
     ok = bool((out.status == 0).all().item())
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     t_acc = torch.tensor([float(acc)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(t_acc, op=dist.ReduceOp.SUM)
     elapsed = float(t_el.item())
@@ -177,7 +178,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -32,8 +32,8 @@ extern "C" {
 
 #define IVP_HIP_ABI_VERSION 1
 
-/* Method: same order as `enum Method`, src/solve/options.rs:14-27. Only the explicit adaptive RK
- * methods are on the accelerated path; the others return IVP_ERR_UNSUPPORTED_METHOD. */
+/* Method: same order as `enum Method`, src/solve/options.rs:14-27. The explicit RK methods (RK23, DOPRI5,
+ * DOP853 and the fixed-step RK4) are on the accelerated path; RADAU and BDF return IVP_ERR_UNSUPPORTED_METHOD. */
 typedef enum {
     IVP_RK23 = 0,
     IVP_DOPRI5 = 1, /* "RK45" */
@@ -61,10 +61,10 @@ typedef enum {
     IVP_ERR_OUT_OF_RANGE = -2,            /* ConfigError::OutOfRange           */
     IVP_ERR_NEGATIVE_TOLERANCE = -3,      /* ConfigError::NegativeTolerance    */
     IVP_ERR_TOLERANCE_SIZE_MISMATCH = -4, /* ConfigError::ToleranceSizeMismatch (a panic in the reference, src/methods/mod.rs:156-161) */
-    IVP_ERR_INVALID_STEP_SIZE = -5,       /* ConfigError::InvalidStepSize      */
+    IVP_ERR_INVALID_STEP_SIZE = -5,       /* ConfigError::InvalidStepSize (RK4: first_step zero / wrong sign, rk4.rs:81-87) */
     IVP_ERR_INVALID_SCALE_FACTORS = -6,   /* ConfigError::InvalidScaleFactors  */
     IVP_ERR_BAD_ARGUMENT = -100,          /* NULL pointer, unknown rhs id, n mismatch ...            */
-    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RK4 / RADAU / BDF: not on the accelerated path          */
+    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU / BDF: not on the accelerated path                */
     IVP_ERR_NO_DEVICE = -102,             /* no HIP device: there is deliberately no CPU fallback    */
     IVP_ERR_HIP = -103,                   /* a HIP runtime call failed; see ivp_last_error_string()  */
     IVP_ERR_JIT = -104                    /* hiprtc compilation of a user RHS failed                 */

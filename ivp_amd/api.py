@@ -326,6 +326,15 @@ def _interpolate(method: Method, xi: float, cont: np.ndarray, n: int, xold: floa
         s1 = 1.0 - s
         conpar = c[4] + s * (c[5] + s1 * (c[6] + s * c[7]))
         return c[0] + s * (c[1] + s1 * (c[2] + s * (c[3] + s1 * conpar)))
+    if method == Method.RK4:  # rk4.rs:229-244
+        t = (xi - xold) / h
+        t2 = t * t
+        t3 = t2 * t
+        h00 = 2.0 * t3 - 3.0 * t2 + 1.0
+        h10 = t3 - 2.0 * t2 + t
+        h01 = -2.0 * t3 + 3.0 * t2
+        h11 = t3 - t2
+        return h00 * c[0] + h10 * h * c[1] + h01 * c[3] + h11 * h * c[2]
     xc = (xi - xold) / h
     x2 = xc * xc
     x3 = x2 * xc
@@ -523,7 +532,7 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
     method = options.method_enum
     ne = 0 if options.t_eval is None else len(options.t_eval)
     ml = int(options.max_log)
-    nc = method.coeffs_per_state() * n if method in (Method.RK23, Method.DOPRI5, Method.DOP853) else 0
+    nc = method.coeffs_per_state() * n if method in (Method.RK23, Method.DOPRI5, Method.DOP853, Method.RK4) else 0
 
     res = out or BatchSolution(
         y_end=xp_zeros((n, B), f64), t_end=xp_zeros((B,), f64), status=xp_zeros((B,), i32),

@@ -107,9 +107,9 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "problem dims (n=%d,p=%d) do not match rhs (n=%d,p=%d)", prob->n, prob->n_params, n, p);
     if (n < 1 || n > IVP_MAX_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
     if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
-    if (opt->method == IVP_RK4 || opt->method == IVP_RADAU || opt->method == IVP_BDF)
+    if (opt->method == IVP_RADAU || opt->method == IVP_BDF)
         return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "method %d is not on the accelerated explicit-RK path", opt->method);
-    if (opt->method < IVP_RK23 || opt->method > IVP_DOP853) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown method %d", opt->method);
+    if (opt->method < IVP_RK23 || opt->method > IVP_RK4) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown method %d", opt->method);
     if (opt->rtol_vec && opt->rtol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "rtol: expected %d, got %d", n, opt->rtol_vec_len);
     if (opt->atol_vec && opt->atol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "atol: expected %d, got %d", n, opt->atol_vec_len);
     if (opt->t_eval && opt->n_eval < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative n_eval");
@@ -258,7 +258,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     HIP_TRY(ctx, ctx->flags.reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[0].reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[1].reserve(sizeof(uint32_t) * B));
-    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 4));
+    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 8));  // [0..3] active-count ring, [4] error flags
     a.k1 = (double *)ctx->k1.p;
     a.facold = (double *)ctx->facold.p;
     a.hlamb = (double *)ctx->hlamb.p;
@@ -301,7 +301,8 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
         HIP_TRY(ctx, hipMemsetAsync(ctx->slot.p, 0, 2 * sizeof(unsigned long long), s));
         a.slot_counter = (unsigned long long *)ctx->slot.p;
     }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 8, s));
+    a.err_flag = (uint32_t *)ctx->counts.p + 4;
 
     auto launch_lean = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast : ivp_launch_strict;
     auto launch_hoist = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast_hoist : ivp_launch_strict_hoist;
@@ -347,6 +348,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     uint32_t *counts = (uint32_t *)ctx->counts.p;
     uint32_t lanes = (uint32_t)B;
     uint64_t c = 0;  // chunk number
+    bool err_checked = false;
     for (;;) {
         const bool tail = adaptive && lanes <= kOneWavePerSimd;
         // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
@@ -380,7 +382,13 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
             ctx->stats.launches += 1;
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (!err_checked) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (!err_checked) {
+            err_checked = true;
+            if (ctx->pinned[1] & 0x1u)  // IVP_ERRFLAG_INVALID_STEP: RK4::solve's Err(InvalidStepSize), rk4.rs:81-87
+                return fail(ctx, IVP_ERR_INVALID_STEP_SIZE, "RK4: step size is zero or its sign does not match xend - x0 for at least one trajectory");
+        }
         lanes = ctx->pinned[0];
         if (lanes == 0) break;
     }

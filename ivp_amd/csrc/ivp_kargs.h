@@ -68,6 +68,7 @@ struct IvpKArgs {
     double *seg_xold;         // [max_log][B]
     double *seg_h;            // [max_log][B]
     uint32_t *n_seg;          // [B]
+    uint32_t *err_flag;       // device word: IVP_ERRFLAG_* bits raised by the init kernel
     // ---- profiling ----
     unsigned long long *slot_counter;  // optional: += lanes x attempts the wave executed
 };

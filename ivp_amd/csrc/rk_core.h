@@ -73,6 +73,16 @@ __device__ __forceinline__ uint64_t ivp_opaque_zero()
     return z;
 }
 #endif
+// whole-call validation failures that can only be detected per trajectory (the reference's Err(Error::Config))
+#define IVP_ERRFLAG_INVALID_STEP 0x1u
+IVP_HD void ivp_flag_error(const IvpKArgs &a, uint32_t bit)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(a.err_flag, bit);
+#else
+    *a.err_flag |= bit;
+#endif
+}
 IVP_HD double rs_signum(double v) { return v != v ? v : copysign(1.0, v); }  // Rust f64::signum
 IVP_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
 IVP_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
@@ -306,7 +316,7 @@ IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L,
 // ------------------------------------------------------------------------------------------------
 // Dense-output polynomials (dopri5.rs:467-478, dop853.rs:659-670, rk23.rs:313-321)
 // ------------------------------------------------------------------------------------------------
-enum { M_RK23 = 0, M_DOPRI5 = 1, M_DOP853 = 2 };
+enum { M_RK23 = 0, M_DOPRI5 = 1, M_DOP853 = 2, M_RK4 = 3 };   // Method order, options.rs:14-27
 template <int M> struct NCoef { enum { v = (M == M_DOPRI5) ? 5 : (M == M_DOP853) ? 8 : 4 }; };
 
 template <int M, int N>
@@ -326,6 +336,17 @@ IVP_HD void interpolate(double xi, double *yi, const double *cont, double xold, 
             const double conpar = cont[4 * N + i] + s * (cont[5 * N + i] + s1 * (cont[6 * N + i] + s * cont[7 * N + i]));
             yi[i] = cont[i] + s * (cont[N + i] + s1 * (cont[2 * N + i] + s * (cont[3 * N + i] + s1 * conpar)));
         }
+    } else if constexpr (M == M_RK4) {   // rk4.rs:229-244
+        const double t = (xi - xold) / h;
+        const double t2 = t * t;
+        const double t3 = t2 * t;
+        const double h00 = 2.0 * t3 - 3.0 * t2 + 1.0;
+        const double h10 = t3 - 2.0 * t2 + t;
+        const double h01 = -2.0 * t3 + 3.0 * t2;
+        const double h11 = t3 - t2;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            yi[i] = h00 * cont[i] + h10 * h * cont[N + i] + h01 * cont[3 * N + i] + h11 * h * cont[2 * N + i];
     } else {
         const double xc = (xi - xold) / h;
         const double x2 = xc * xc;
@@ -534,11 +555,26 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     else L.hmax = fabs(L.xend - L.x);
 
     R::ode(L.x, L.y, L.k1, L.p);
-    nfev += 1;
-    if (a.has_first_step) {
+    if constexpr (M == M_RK4) {
+        // solve_ivp.rs:184-196: h = first_step or (xend - x0)/100; RK4::solve rejects h == 0 or a sign that
+        // does not match xend - x0 (rk4.rs:81-87, Err(InvalidStepSize)): flagged for the host, lane parked.
+        // The initial evaluation is not counted in nfev (rk4.rs:119).
+        L.h = a.has_first_step ? a.first_step : (L.xend - L.x0) / 100.0;
+        if (L.h == 0.0 || rs_signum(L.h) != L.posneg) {
+            ivp_flag_error(a, IVP_ERRFLAG_INVALID_STEP);
+#pragma unroll
+            for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = 0.0; }
+            a.x[j] = L.x0; a.h[j] = L.h; a.facold[j] = 0.0; a.hlamb[j] = 0.0; a.flags[j] = 0;
+            a.status[j] = 0;
+            a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+            if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
+            return 0;
+        }
+    } else if (a.has_first_step) {
+        nfev += 1;
         L.h = fabs(a.first_step) * L.posneg;
     } else {
-        nfev += 1;
+        nfev += 2;  // f(x0, y0) and hinit's Euler probe
         L.h = hinit<R>(a, L.x, L.y, L.posneg, L.k1, L.p, M == M_DOPRI5 ? 5 : (M == M_DOP853 ? 8 : 3), L.hmax);
     }
     if (FULL) solout_full<M, N, P>(a, j, L, L.x, L.x, L.y, nullptr, 0.0);
@@ -1081,12 +1117,68 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RK4 step (rk4.rs:137-226): fixed step, no error control.  Quirks kept: steps.accepted stays 0, the last
+// step is not shortened (the final x is x0 + k*h), nfev counts 4 per step and not the initial evaluation.
+// ------------------------------------------------------------------------------------------------
+template <class R, bool FULL>
+IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
+{
+    KC_SCOPE
+    constexpr int N = R::N, P = R::P;
+    constexpr double C2 = 0.5, C3 = 0.5, A21 = 0.5, A32 = 0.5;   // rk4.rs:247-257 (C4 = A43 = 1)
+    constexpr double B1 = 1.0 / 6.0, B2 = 1.0 / 3.0, B3 = 1.0 / 3.0, B4 = 1.0 / 6.0;
+
+    if (L.over || L.d_nstep >= L.budget) { L.status = 2; return false; }   // `steps.total >= nmax`
+    const double h = L.h;
+    const double x = L.x;
+    const bool last = (x + KC(1.01) * h - L.xend) * rs_signum(h) > 0.0;
+
+    const double *y = L.y, *k1 = L.k1, *p = L.p;
+    double k2[N], k3[N], k4[N], yt[N], yold[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * A21 * k1[i];
+    R::ode(x + C2 * h, yt, k2, p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * A32 * k2[i];
+    R::ode(x + C3 * h, yt, k3, p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * 1.0 * k3[i];
+    R::ode(x + 1.0 * h, yt, k4, p);
+    const double xnew = x + h;
+    {
+        const double cB1 = KC(B1), cB2 = KC(B2), cB3 = KC(B3), cB4 = KC(B4);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            yold[i] = y[i];
+            L.y[i] = y[i] + h * (cB1 * k1[i] + cB2 * k2[i] + cB3 * k3[i] + cB4 * k4[i]);
+        }
+    }
+    R::ode(xnew, L.y, L.k1, p);
+    L.x = xnew;
+    L.d_nfev += 4;
+    L.d_nstep += 1;
+    if (FULL) {
+        double cont[4 * N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            cont[i] = yold[i];
+            cont[N + i] = k4[i];
+            cont[2 * N + i] = L.k1[i];
+            cont[3 * N + i] = L.y[i];
+        }
+        solout_full<M_RK4, N, P>(a, j, L, x, xnew, L.y, cont, h);
+    }
+    if (last) { L.status = 0; return false; }
+    return true;
+}
+
 // One chunk of step attempts for one lane. Every lane leaves after at most `chunk` attempts.
 template <int M, class R, bool FULL>
 IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     Lane<R::N, R::P> L;
-    lane_load<R>(a, j, L, M == M_RK23, FULL);
+    lane_load<R>(a, j, L, M == M_RK23 || M == M_RK4, FULL);
     if (a.has_max_step) L.hmax = (M == M_DOPRI5) ? a.max_step : fabs(a.max_step);
     else L.hmax = fabs(L.xend - L.x0);
     uint32_t it = 0;
@@ -1094,6 +1186,7 @@ IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
     while (run && it < a.chunk) {
         if constexpr (M == M_DOPRI5) run = dopri5_attempt<R, FULL>(a, j, L);
         else if constexpr (M == M_DOP853) run = dop853_attempt<R, FULL>(a, j, L);
+        else if constexpr (M == M_RK4) run = rk4_attempt<R, FULL>(a, j, L);
         else run = rk23_attempt<R, FULL>(a, j, L);
         ++it;
     }

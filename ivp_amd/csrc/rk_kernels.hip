@@ -60,6 +60,8 @@ hipError_t launch_rhs(int what, int method, bool full, const IvpKArgs &a, uint32
         return full ? launch_one<M_DOPRI5, R, true>(what, a, lanes, s) : launch_one<M_DOPRI5, R, false>(what, a, lanes, s);
     case M_DOP853:
         return full ? launch_one<M_DOP853, R, true>(what, a, lanes, s) : launch_one<M_DOP853, R, false>(what, a, lanes, s);
+    case M_RK4:
+        return full ? launch_one<M_RK4, R, true>(what, a, lanes, s) : launch_one<M_RK4, R, false>(what, a, lanes, s);
     }
     return hipErrorInvalidValue;
 }

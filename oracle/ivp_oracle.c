@@ -226,6 +226,18 @@ static void interp_rk23(double xi, double *yi, const double *cont, int n, double
         yi[i] = cont[i] + h * (cont[n + i] * xc + cont[2 * n + i] * x2 + cont[3 * n + i] * x3);
     }
 }
+static void interp_rk4(double xi, double *yi, const double *cont, int n, double xold, double h)
+{   /* rk4.rs:229-244: cubic Hermite on (y_old, k4, k1_new, y_new) as stored at rk4.rs:186-190 */
+    double t = (xi - xold) / h;
+    double t2 = t * t;
+    double t3 = t2 * t;
+    double h00 = 2.0 * t3 - 3.0 * t2 + 1.0;
+    double h10 = t3 - 2.0 * t2 + t;
+    double h01 = -2.0 * t3 + 3.0 * t2;
+    double h11 = t3 - t2;
+    for (int i = 0; i < n; i++)
+        yi[i] = h00 * cont[i] + h10 * h * cont[n + i] + h01 * cont[3 * n + i] + h11 * h * cont[2 * n + i];
+}
 static int ncoef_of(int method)
 {   /* options.rs:34-43 */
     return method == ORC_DOPRI5 ? 5 : method == ORC_DOP853 ? 8 : 4;
@@ -234,6 +246,7 @@ static void interp_any(int method, double xi, double *yi, const double *cont, in
 {
     if (method == ORC_DOPRI5) interp_dopri5(xi, yi, cont, n, xold, h);
     else if (method == ORC_DOP853) interp_dop853(xi, yi, cont, n, xold, h);
+    else if (method == ORC_RK4) interp_rk4(xi, yi, cont, n, xold, h);
     else interp_rk23(xi, yi, cont, n, xold, h);
 }
 
@@ -923,6 +936,66 @@ static int rk23_solve(orc_ode_fn f, const double *p, int n, double x0, const dou
 }
 
 /* ------------------------------------------------------------------------------------------
+ * RK4 (src/methods/rk4.rs:64-226): fixed step.  Quirks kept: the initial f(x0,y0) is not counted
+ * in nfev (rk4.rs:119), steps.accepted is never incremented, and the last step is NOT shortened
+ * (rk4.rs:148-152 only sets `last`), so the final x is x0 + k*h, wherever that lands.
+ * ---------------------------------------------------------------------------------------- */
+static int rk4_solve(orc_ode_fn f, const double *p, int n, double x0, const double *y0, double xend, double h,
+                     const orc_options *opt, solout_t *so, int_result *res, double *y_final, double *x_final)
+{
+    const double C2 = 0.5, C3 = 0.5, C4 = 1.0, A21 = 0.5, A32 = 0.5, A43 = 1.0;
+    const double B1 = 1.0 / 6.0, B2 = 1.0 / 3.0, B3 = 1.0 / 3.0, B4 = 1.0 / 6.0;
+    double x = x0;
+    const double posneg = rs_signum(xend - x);
+    if (h == 0.0 || rs_signum(h) != posneg) return ORC_ERR_INVALID_STEP_SIZE; /* rk4.rs:81-87 */
+    const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE;
+
+    double *w = (double *)malloc((size_t)n * (6 + 4) * sizeof(double));
+    double *y = w, *k1 = w + n, *k2 = w + 2 * n, *k3 = w + 3 * n, *k4 = w + 4 * n, *yt = w + 5 * n, *cont = w + 6 * n;
+    memcpy(y, y0, (size_t)n * sizeof(double));
+    uint64_t nfev = 0, nstep = 0;
+    int status = ORC_SUCCESS;
+    double xold = x;
+
+    f(x, y, k1, p); /* not counted */
+    so_call(so, xold, x, y, NULL, 0.0);
+
+    for (;;) {
+        if (nstep >= nmax) { status = ORC_NEED_LARGER_NMAX; break; }
+        int last = 0;
+        if ((x + 1.01 * h - xend) * rs_signum(h) > 0.0) last = 1;
+
+        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A21 * k1[i];
+        f(x + C2 * h, yt, k2, p);
+        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A32 * k2[i];
+        f(x + C3 * h, yt, k3, p);
+        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A43 * k3[i];
+        f(x + C4 * h, yt, k4, p);
+
+        xold = x;
+        memcpy(yt, y, (size_t)n * sizeof(double));
+        x += h;
+        for (int i = 0; i < n; i++) y[i] += h * (B1 * k1[i] + B2 * k2[i] + B3 * k3[i] + B4 * k4[i]);
+        f(x, y, k1, p);
+        nfev += 4;
+        nstep += 1;
+
+        memcpy(cont, yt, (size_t)n * sizeof(double));
+        for (int i = 0; i < n; i++) { cont[n + i] = k4[i]; cont[2 * n + i] = k1[i]; }
+        memcpy(cont + 3 * n, y, (size_t)n * sizeof(double));
+        so_call(so, xold, x, y, cont, h);
+        if (last) break;
+    }
+    res->h = h; res->status = status;
+    res->nfev = nfev; res->nstep = nstep; res->naccpt = 0; res->nrejct = 0;
+    memcpy(y_final, y, (size_t)n * sizeof(double));
+    *x_final = x;
+    free(w);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
  * solve_ivp (src/solve/solve_ivp.rs:99-313)
  * ---------------------------------------------------------------------------------------- */
 static void constant_solution(orc_solution *sol, int method, int n, double x0, const double *y0)
@@ -946,7 +1019,7 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     sol->n = n;
     sol->ncoef = ncoef_of(opt->method);
     if (n > 64) return ORC_ERR_BAD_ARGUMENT;
-    if (opt->method < ORC_RK23 || opt->method > ORC_DOP853) return ORC_ERR_BAD_ARGUMENT;
+    if (opt->method < ORC_RK23 || opt->method > ORC_RK4) return ORC_ERR_BAD_ARGUMENT;
 
     if (fabs(xend - x0) < 1e-15) { /* solve_ivp.rs:110-145 */
         if (opt->n_eval >= 0) {
@@ -989,7 +1062,7 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
 
     tol_t rtol = {opt->rtol, opt->rtol_len}, atol = {opt->atol, opt->atol_len};
     /* Tolerance::Vector with the wrong length panics in the reference (mod.rs:156-161 / index OOB) */
-    if ((rtol.len != 1 && rtol.len != n) || (atol.len != 1 && atol.len != n))
+    if (opt->method != ORC_RK4 && ((rtol.len != 1 && rtol.len != n) || (atol.len != 1 && atol.len != n)))
         return ORC_ERR_TOLERANCE_SIZE_MISMATCH;
 
     solout_t so;
@@ -1006,6 +1079,10 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     int rc;
     if (opt->method == ORC_DOPRI5) rc = dopri5_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
     else if (opt->method == ORC_DOP853) rc = dop853_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
+    else if (opt->method == ORC_RK4) { /* solve_ivp.rs:184-196: h = first_step or (xend - x0) / 100 */
+        double h4 = opt->has_first_step ? opt->first_step : (xend - x0) / 100.0;
+        rc = rk4_solve(f, params, n, x0, y0, xend, h4, opt, &so, &r, yf, &xf);
+    }
     else rc = rk23_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
     if (rc != ORC_OK) {
         free(so.t); free(so.y); free(so.seg_cont); free(so.seg_xold); free(so.seg_h);

@@ -19,6 +19,7 @@
  *   src/methods/dopri5.rs:122-520   DOPRI5::solve, interpolate, tableau
  *   src/methods/dop853.rs:114-848   DOP853::solve, interpolate, tableau
  *   src/methods/rk23.rs:81-347      RK23::solve, interpolate, tableau
+ *   src/methods/rk4.rs:64-257       RK4::solve, interpolate, tableau
  *   src/solve/solve_ivp.rs:99-313   solve_ivp front end
  *   src/solve/solout.rs:127-431     DefaultSolOut (dense collection, t_eval, step record)
  *   src/solve/cont.rs:16-153        ContinuousOutput
@@ -36,7 +37,7 @@ extern "C" {
 #endif
 
 /* Method enum order follows src/solve/options.rs:14-27. */
-enum { ORC_RK23 = 0, ORC_DOPRI5 = 1, ORC_DOP853 = 2 };
+enum { ORC_RK23 = 0, ORC_DOPRI5 = 1, ORC_DOP853 = 2, ORC_RK4 = 3 };
 
 /* Status order follows src/status.rs:4-19. */
 enum {

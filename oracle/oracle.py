@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2}
+METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7}
 RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0)}
 STATUS = ["Success", "UserInterrupt", "NeedLargerNMax", "StepSizeTooSmall", "ProbablyStiff",

@@ -142,5 +142,12 @@ for m in ("DOPRI5", "DOP853"):
     CASES.append((f"stiff-vdp-{m}", "vdp", stiff_vdp(m)))
     CASES.append((f"blowup-vdp-bwd-{m}", "vdp", blowup_vdp_backward(m)))
 CASES.append(("exp2-vector-rtol", "exp2", exp2_vector_rtol))
+# fixed-step RK4 (rk4.rs): default h = (xend - x0)/100, explicit first_step, step cap, backward
+CASES.append(("rk4-cr3bp-default-h", "cr3bp", lambda: (*W.cr3bp_batch(64)[:3], 2.0, dict(method="RK4"))))
+CASES.append(("rk4-sho-h", "sho", sho("RK4", 0.0, 2 * np.pi, first_step=2 * np.pi / 2000)))
+CASES.append(("rk4-sho-bwd", "sho", sho("RK4", 3.0, 0.0, first_step=-0.01)))
+CASES.append(("rk4-sho-maxsteps", "sho", sho("RK4", 0.0, 3.0, max_steps=30)))
+CASES.append(("rk4-mixed-intervals", "sho", mixed_intervals("RK4")))
+CASES.append(("rk4-zero-teval", "zero", zero_rhs("RK4")))
 
 CASE_IDS = [c[0] for c in CASES]

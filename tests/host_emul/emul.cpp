@@ -37,6 +37,7 @@ static int run_rhs(int method, bool full, const IvpKArgs &a, uint64_t *chunks)
     case 0: full ? run_all<0, R, true>(a, chunks) : run_all<0, R, false>(a, chunks); return 0;
     case 1: full ? run_all<1, R, true>(a, chunks) : run_all<1, R, false>(a, chunks); return 0;
     case 2: full ? run_all<2, R, true>(a, chunks) : run_all<2, R, false>(a, chunks); return 0;
+    case 3: full ? run_all<3, R, true>(a, chunks) : run_all<3, R, false>(a, chunks); return 0;
     }
     return -1;
 }
@@ -51,19 +52,23 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
     std::vector<double> k1(8 * B), facold(B), hlamb(B), t_last(B);
     std::vector<uint32_t> flags(B);
     std::vector<int32_t> next_idx(B);
+    uint32_t err_flag = 0;
+    a.err_flag = &err_flag;
     a.k1 = k1.data(); a.facold = facold.data(); a.hlamb = hlamb.data(); a.flags = flags.data();
     a.t_last = t_last.data(); a.next_idx = next_idx.data();
+    int rc = -1;
     switch (rhs_id) {
-    case 0: return run_rhs<RhsDecay>(method, full, a, chunks);
-    case 1: return run_rhs<RhsSho>(method, full, a, chunks);
-    case 2: return run_rhs<RhsVdp>(method, full, a, chunks);
-    case 3: return run_rhs<RhsCr3bp>(method, full, a, chunks);
-    case 4: return run_rhs<RhsLorenz>(method, full, a, chunks);
-    case 5: return run_rhs<RhsZero>(method, full, a, chunks);
-    case 6: return run_rhs<RhsRational>(method, full, a, chunks);
-    case 7: return run_rhs<RhsExp2>(method, full, a, chunks);
+    case 0: rc = run_rhs<RhsDecay>(method, full, a, chunks); break;
+    case 1: rc = run_rhs<RhsSho>(method, full, a, chunks); break;
+    case 2: rc = run_rhs<RhsVdp>(method, full, a, chunks); break;
+    case 3: rc = run_rhs<RhsCr3bp>(method, full, a, chunks); break;
+    case 4: rc = run_rhs<RhsLorenz>(method, full, a, chunks); break;
+    case 5: rc = run_rhs<RhsZero>(method, full, a, chunks); break;
+    case 6: rc = run_rhs<RhsRational>(method, full, a, chunks); break;
+    case 7: rc = run_rhs<RhsExp2>(method, full, a, chunks); break;
     }
-    return -1;
+    if (rc == 0 && (err_flag & 0x1u)) return -5;  // IVP_ERR_INVALID_STEP_SIZE
+    return rc;
 }
 
 extern "C" size_t emul_kargs_size(void) { return sizeof(IvpKArgs); }

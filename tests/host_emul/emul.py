@@ -29,6 +29,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("t_log", VP), ("y_log", VP), ("n_log", VP), ("t_last", VP),
         ("collect_dense", C.c_int32),
         ("seg_cont", VP), ("seg_xold", VP), ("seg_h", VP), ("n_seg", VP),
+        ("err_flag", VP),
         ("slot_counter", VP),
     ]
 
@@ -36,8 +37,8 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
 _libs = {}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7}
 RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0)}
-METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2}
-NCOEF = {0: 4, 1: 5, 2: 8}
+METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3}
+NCOEF = {0: 4, 1: 5, 2: 8, 3: 4}
 
 
 def build():
@@ -123,6 +124,8 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
             a.collect_dense = 1
     chunks = C.c_uint64(0)
     rc = L.emul_solve(m, rid, int(full), C.byref(a), C.byref(chunks))
+    if rc == -5:
+        raise ValueError("IVP_ERR_INVALID_STEP_SIZE")
     assert rc == 0
     res["chunks"] = chunks.value
     return res

@@ -26,14 +26,18 @@ def compute_error(y, y_true, rtol, atol):
     return np.linalg.norm(e, axis=0) / np.sqrt(e.shape[0])
 
 
-@pytest.mark.parametrize("method", EXPLICIT)
+@pytest.mark.parametrize("method", EXPLICIT + [Method.RK4])
 def test_harmonic_accuracy_end_state(method):  # tests/accuracy.rs:18-48
-    sol = solve_ivp(SHO(), 0.0, 2 * np.pi, [1.0, 0.0], default_opts(method))
+    if method == Method.RK4:   # fixed step chosen to land on the period (accuracy.rs:24-31)
+        opts = Options(method=method, first_step=2 * np.pi / 2000.0)
+    else:
+        opts = default_opts(method)
+    sol = solve_ivp(SHO(), 0.0, 2 * np.pi, [1.0, 0.0], opts)
     y_end = sol.y[-1]
     assert abs(y_end[0] - 1.0) < 1e-5 and abs(y_end[1]) < 1e-5
 
 
-@pytest.mark.parametrize("method", EXPLICIT)
+@pytest.mark.parametrize("method", EXPLICIT + [Method.RK4])
 def test_t_eval_sampling_exact_times(method):  # tests/accuracy.rs:51-77
     t_eval = [i / 10.0 for i in range(11)]
     sol = solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method=method, rtol=1e-9, atol=1e-9, t_eval=t_eval))
@@ -184,6 +188,14 @@ def test_c1_exponential_decay():  # BASELINE config C1: README.md:74,93-101 and 
     sol = solve_ivp(ExponentialDecay(0.5), 0.0, 10.0, [10.0], Options(method="DOPRI5", rtol=1e-8, atol=1e-10, t_eval=te))
     assert np.array_equal(sol.t, te)
     assert np.abs(sol.y[:, 0] - 10.0 * np.exp(-0.5 * te)).max() < 1e-6
+
+
+def test_rk4_invalid_step_size_is_a_config_error():  # rk4.rs:81-87
+    with pytest.raises(ivp_amd.ConfigError) as e:
+        solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method=Method.RK4, first_step=-0.1))
+    assert e.value.code == -5
+    sol = solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method=Method.RK4))      # default h = (xend - x0)/100
+    assert sol.nstep == 100 and sol.nfev == 400 and sol.naccpt == 0 and len(sol.t) == 101
 
 
 def test_unsupported_methods_and_bad_tolerances_are_config_errors():

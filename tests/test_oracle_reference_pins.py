@@ -22,13 +22,14 @@ def compute_error(y, y_true, rtol, atol):
 
 # ---- tests/accuracy.rs ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("method", EXPLICIT)
+@pytest.mark.parametrize("method", EXPLICIT + ["RK4"])
 def test_harmonic_accuracy_end_state(method):  # tests/accuracy.rs:18-48
-    s = O.solve_ivp("sho", 0.0, 2 * np.pi, [1.0, 0.0], method=method, rtol=1e-9, atol=1e-9)
+    kw = dict(first_step=2 * np.pi / 2000.0) if method == "RK4" else dict(rtol=1e-9, atol=1e-9)
+    s = O.solve_ivp("sho", 0.0, 2 * np.pi, [1.0, 0.0], method=method, **kw)
     assert abs(s.y[-1, 0] - 1.0) < 1e-5 and abs(s.y[-1, 1]) < 1e-5
 
 
-@pytest.mark.parametrize("method", EXPLICIT)
+@pytest.mark.parametrize("method", EXPLICIT + ["RK4"])
 def test_t_eval_sampling_exact_times(method):  # tests/accuracy.rs:51-77
     te = np.arange(11) / 10.0
     s = O.solve_ivp("sho", 0.0, 1.0, [1.0, 0.0], method=method, rtol=1e-9, atol=1e-9, t_eval=te)
