@@ -177,11 +177,33 @@ static void rhs_exp2(double t, const double *y, double *d, const double *p)
     d[1] = y[1];
 }
 
+static void rhs_linear(double t, const double *y, double *d, const double *p)
+{   /* tests/test_helpers.py:11-12 */
+    (void)t; (void)p;
+    d[0] = -y[0] - 5.0 * y[1];
+    d[1] = y[0] + y[1];
+}
+static void rhs_robertson(double t, const double *s, double *d, const double *p)
+{   /* tests/test_ivp.py:327-333 */
+    (void)t; (void)p;
+    double x = s[0], y = s[1], z = s[2];
+    d[0] = -0.04 * x + 1e4 * y * z;
+    d[1] = 0.04 * x - 1e4 * y * z - 3e7 * y * y;
+    d[2] = 3e7 * y * y;
+}
+static void rhs_vdp_eps(double t, const double *y, double *d, const double *p)
+{   /* examples/van_der_pol.rs:9-14 */
+    (void)t;
+    d[0] = y[1];
+    d[1] = ((1.0 - y[0] * y[0]) * y[1] - y[0]) / p[0];
+}
+
 orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *np_out)
 {
     static const struct { orc_ode_fn f; int n, np; } tab[ORC_RHS_COUNT] = {
         {rhs_decay, 1, 1}, {rhs_sho, 2, 0}, {rhs_vdp, 2, 1}, {rhs_cr3bp, 6, 1},
         {rhs_lorenz, 3, 3}, {rhs_zero, 3, 0}, {rhs_rational, 2, 0}, {rhs_exp2, 2, 0},
+        {rhs_linear, 2, 0}, {rhs_robertson, 3, 0}, {rhs_vdp_eps, 2, 1},
     };
     if (rhs_id < 0 || rhs_id >= ORC_RHS_COUNT) return NULL;
     if (n_out) *n_out = tab[rhs_id].n;
@@ -238,15 +260,38 @@ static void interp_rk4(double xi, double *yi, const double *cont, int n, double 
     for (int i = 0; i < n; i++)
         yi[i] = h00 * cont[i] + h10 * h * cont[n + i] + h01 * cont[3 * n + i] + h11 * h * cont[2 * n + i];
 }
+static void interp_bdf(double xi, double *yi, const double *cont, int n, double xold, double h)
+{   /* bdf.rs:618-656; cont is per-state blocks [D0, D1..D5, order] */
+    if (h == 0.0 || n == 0) return;
+    double ordf = round(cont[6]);
+    if (ordf < 1.0) ordf = 1.0;
+    if (ordf > 5.0) ordf = 5.0;
+    int order = (int)ordf;
+    double x_new = xold + h;
+    double p[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < order; k++) {
+        double denom = h * ((double)k + 1.0);
+        double t_shift = x_new - h * (double)k;
+        double xf = (xi - t_shift) / denom;
+        p[k] = k == 0 ? xf : p[k - 1] * xf;
+    }
+    for (int i = 0; i < n; i++) {
+        const double *b = cont + (size_t)i * 7;
+        double sum = b[0];
+        for (int k = 0; k < order; k++) sum += b[1 + k] * p[k];
+        yi[i] = sum;
+    }
+}
 static int ncoef_of(int method)
 {   /* options.rs:34-43 */
-    return method == ORC_DOPRI5 ? 5 : method == ORC_DOP853 ? 8 : 4;
+    return method == ORC_DOPRI5 ? 5 : method == ORC_DOP853 ? 8 : method == ORC_BDF ? 7 : 4;
 }
 static void interp_any(int method, double xi, double *yi, const double *cont, int n, double xold, double h)
 {
     if (method == ORC_DOPRI5) interp_dopri5(xi, yi, cont, n, xold, h);
     else if (method == ORC_DOP853) interp_dop853(xi, yi, cont, n, xold, h);
     else if (method == ORC_RK4) interp_rk4(xi, yi, cont, n, xold, h);
+    else if (method == ORC_BDF) interp_bdf(xi, yi, cont, n, xold, h);
     else interp_rk23(xi, yi, cont, n, xold, h);
 }
 
@@ -280,8 +325,16 @@ static void so_push(solout_t *s, double t, const double *y)
 }
 
 /* Returns 0 = Continue (the only flag DefaultSolOut produces without events). */
-static int so_call(solout_t *s, double xold, double x, const double *y,
-                   const double *cont /* NULL = no interpolant */, double h)
+static int so_call2(solout_t *s, double xold, double x, const double *y,
+                    const double *cont /* NULL = no interpolant */, double ixold, double h);
+static int so_call(solout_t *s, double xold, double x, const double *y, const double *cont, double h)
+{
+    return so_call2(s, xold, x, y, cont, xold, h);
+}
+/* `xold` is what the integrator passes as the callback's first argument; `ixold`/`h` are the interpolant's own
+ * anchor (StepInterpolant.xold, .h): identical for the RK methods, different for BDF (bdf.rs:518-519). */
+static int so_call2(solout_t *s, double xold, double x, const double *y,
+                    const double *cont /* NULL = no interpolant */, double ixold, double h)
 {
     int n = s->n;
     /* solout.rs:141-146 */
@@ -295,7 +348,7 @@ static int so_call(solout_t *s, double xold, double x, const double *y,
                 s->seg_h = (double *)realloc(s->seg_h, s->segcap * sizeof(double));
             }
             memcpy(s->seg_cont + s->nseg * (size_t)nc, cont, (size_t)nc * sizeof(double));
-            s->seg_xold[s->nseg] = xold;
+            s->seg_xold[s->nseg] = ixold;
             s->seg_h[s->nseg] = h;
             s->nseg++;
         }
@@ -316,7 +369,7 @@ static int so_call(solout_t *s, double xold, double x, const double *y,
             if (forward) {
                 while (i < ne && s->t_eval[i] <= x + s->tol) {
                     if (s->t_eval[i] >= xold - s->tol) {
-                        interp_any(s->method, s->t_eval[i], yi, cont, n, xold, h);
+                        interp_any(s->method, s->t_eval[i], yi, cont, n, ixold, h);
                         so_push(s, s->t_eval[i], yi);
                     }
                     i++;
@@ -324,7 +377,7 @@ static int so_call(solout_t *s, double xold, double x, const double *y,
             } else {
                 while (i < ne && s->t_eval[i] >= x - s->tol) {
                     if (s->t_eval[i] <= xold + s->tol) {
-                        interp_any(s->method, s->t_eval[i], yi, cont, n, xold, h);
+                        interp_any(s->method, s->t_eval[i], yi, cont, n, ixold, h);
                         so_push(s, s->t_eval[i], yi);
                     }
                     i++;
@@ -340,7 +393,7 @@ static int so_call(solout_t *s, double xold, double x, const double *y,
                 double target = s->x0 + direction * s->first_step;
                 if (direction * (x - target) >= -s->tol) {
                     if (cont) {
-                        interp_any(s->method, target, yi, cont, n, xold, h);
+                        interp_any(s->method, target, yi, cont, n, ixold, h);
                         so_push(s, target, yi);
                         s->first_output_done = 1;
                     }
@@ -996,6 +1049,363 @@ static int rk4_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Dense LU with partial pivoting and the matching solve (Hairer's DEC/SOL):
+ * src/matrix/lu.rs:37-125, src/matrix/linear.rs:55-96.  Row-major a[r*n + c].
+ * ---------------------------------------------------------------------------------------- */
+static int lu_decomp(double *a, int *ip, int n)
+{
+    if (n == 1) {
+        if (a[0] == 0.0) return -1;
+        ip[0] = 0;
+        return 0;
+    }
+    for (int k = 0; k < n - 1; k++) {
+        int m = k;
+        double max_val = fabs(a[k * n + k]);
+        for (int i = k + 1; i < n; i++) {
+            double v = fabs(a[i * n + k]);
+            if (v > max_val) { max_val = v; m = i; }
+        }
+        ip[k] = m;
+        double pivot = a[m * n + k];
+        if (pivot == 0.0) return -1;
+        if (m != k) { double t = a[m * n + k]; a[m * n + k] = a[k * n + k]; a[k * n + k] = t; }
+        double t = 1.0 / pivot;
+        for (int i = k + 1; i < n; i++) a[i * n + k] = -a[i * n + k] * t;
+        for (int j = k + 1; j < n; j++) {
+            double tj = a[m * n + j];
+            if (m != k) { double tmp = a[m * n + j]; a[m * n + j] = a[k * n + j]; a[k * n + j] = tmp; }
+            if (tj != 0.0)
+                for (int i = k + 1; i < n; i++) a[i * n + j] += a[i * n + k] * tj;
+        }
+    }
+    if (a[(n - 1) * n + (n - 1)] == 0.0) return -1;
+    return 0;
+}
+static void lin_solve(const double *a, double *b, const int *ip, int n)
+{
+    if (n == 1) { b[0] /= a[0]; return; }
+    for (int k = 0; k < n - 1; k++) {
+        int m = ip[k];
+        double t = b[m]; b[m] = b[k]; b[k] = t;
+        for (int i = k + 1; i < n; i++) b[i] += a[i * n + k] * b[k];
+    }
+    for (int kb = 1; kb < n; kb++) {
+        int k = n - kb;
+        b[k] /= a[k * n + k];
+        for (int i = 0; i < k; i++) b[i] += a[i * n + k] * -b[k];
+    }
+    b[0] /= a[0];
+}
+
+/* Default finite-difference Jacobian, trait IVP::jac (src/ivp.rs:67-107). */
+static void fd_jac(orc_ode_fn f, const double *p, int n, double x, const double *y, double *jac)
+{
+    double yp[64], fp[64], fo[64];
+    memcpy(yp, y, (size_t)n * sizeof(double));
+    f(x, y, fo, p);
+    const double eps = sqrt(2.220446049250313e-16);
+    for (int col = 0; col < n; col++) {
+        double yo = y[col];
+        double pert = eps * fmax(fabs(yo), 1.0);
+        yp[col] = yo + pert;
+        f(x, yp, fp, p);
+        yp[col] = yo;
+        for (int row = 0; row < n; row++) jac[row * n + col] = (fp[row] - fo[row]) / pert;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BDF 1..5 (src/methods/bdf.rs:86-732)
+ * ---------------------------------------------------------------------------------------- */
+#define BDF_MAXO 5
+static double wrms_scaled(const double *v, const double *scale, int n)
+{   /* bdf.rs:659-667 */
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) {
+        double denom = scale[i] == 0.0 ? 2.220446049250313e-16 : scale[i];
+        double ratio = v[i] / denom;
+        sum += ratio * ratio;
+    }
+    return sqrt(sum / (double)n);
+}
+static void compute_r(int order, double factor, double r[6][6])
+{   /* bdf.rs:694-713 */
+    int size = order + 1;
+    double m[6][6];
+    memset(m, 0, sizeof m);
+    memset(r, 0, sizeof(double) * 36);
+    for (int j = 0; j < size; j++) m[0][j] = 1.0;
+    for (int i = 1; i < size; i++)
+        for (int j = 1; j < size; j++) m[i][j] = ((double)i - 1.0 - factor * (double)j) / (double)i;
+    for (int j = 0; j < size; j++) r[0][j] = m[0][j];
+    for (int i = 1; i < size; i++)
+        for (int j = 0; j < size; j++) r[i][j] = r[i - 1][j] * m[i][j];
+}
+static void change_d(double *d /* [8][n] */, int n, int order, double factor)
+{   /* bdf.rs:669-692 */
+    if (factor == 1.0) return;
+    if (order > BDF_MAXO) order = BDF_MAXO;
+    int size = order + 1;
+    double r[6][6], u[6][6], ru[6][6];
+    compute_r(order, factor, r);
+    compute_r(order, 1.0, u);
+    memset(ru, 0, sizeof ru);
+    for (int i = 0; i < size; i++)          /* matmul, bdf.rs:715-732 */
+        for (int k = 0; k < size; k++) {
+            double coeff = r[i][k];
+            if (coeff == 0.0) continue;
+            for (int j = 0; j < size; j++) ru[i][j] += coeff * u[k][j];
+        }
+    double scratch[6][64];
+    for (int row = 0; row <= order; row++) {
+        for (int i = 0; i < n; i++) scratch[row][i] = 0.0;
+        for (int k = 0; k <= order; k++) {
+            double coeff = ru[k][row];
+            if (coeff == 0.0) continue;
+            for (int i = 0; i < n; i++) scratch[row][i] += coeff * d[k * n + i];
+        }
+    }
+    for (int i = 0; i <= order; i++) memcpy(d + (size_t)i * n, scratch[i], (size_t)n * sizeof(double));
+}
+
+static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const double *y0, double xend,
+                     const tol_t *rtol, const tol_t *atol, const orc_options *opt, solout_t *so,
+                     int_result *res, double *y_final, double *x_final, uint64_t *njev_out, uint64_t *nlu_out)
+{
+    static const double KAPPA[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
+    const double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0, SAFETY_DEFAULT = 0.9;
+    const double EPS = 2.220446049250313e-16, MIN_POSITIVE = 2.2250738585072014e-308;
+    double x = x0;
+    for (int i = 0; i < n; i++) {   /* bdf.rs:112-128 */
+        if (tol_at(rtol, i) < 0.0 || tol_at(atol, i) < 0.0) return ORC_ERR_NEGATIVE_TOLERANCE;
+    }
+    const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE;
+    const double direction = rs_signum(xend - x);
+    const double hmax = fabs(opt->has_max_step ? opt->max_step : fabs(xend - x));
+    const double hmin = fabs(opt->has_min_step ? opt->min_step : 0.0);
+    uint64_t nfev = 0, njev = 0, nlu = 0, nstep = 0, naccpt = 0, nrejct = 0;
+
+    double *w = (double *)calloc((size_t)n * (8 + 8 + 7) + (size_t)n * n * 2 + 8, sizeof(double));
+    double *y = w, *f0 = w + n, *psi = w + 2 * n, *scale = w + 3 * n, *y_predict = w + 4 * n, *y_new = w + 5 * n,
+           *delta = w + 6 * n, *rhs = w + 7 * n, *d = w + 8 * n, *cont = w + 16 * n, *jac = w + 23 * n,
+           *lu = w + 23 * n + (size_t)n * n;
+    int pivot[64];
+    memcpy(y, y0, (size_t)n * sizeof(double));
+    f(x, y, f0, p);
+    nfev += 1;
+    fd_jac(f, p, n, x, y, jac);
+    njev += 1;
+    int lu_is_current = 0;
+    double current_c = 0.0;
+
+    double gamma[6], alpha[6], error_const[6];
+    gamma[0] = 0.0;
+    for (int k = 1; k <= BDF_MAXO; k++) gamma[k] = gamma[k - 1] + 1.0 / (double)k;
+    for (int k = 0; k <= BDF_MAXO; k++) alpha[k] = (1.0 - KAPPA[k]) * gamma[k];
+    for (int k = 0; k <= BDF_MAXO; k++) error_const[k] = KAPPA[k] * gamma[k] + 1.0 / ((double)k + 1.0);
+
+    double rtol_min = INFINITY;
+    for (int i = 0; i < n; i++) rtol_min = fmin(rtol_min, tol_at(rtol, i));
+    rtol_min = fmax(rtol_min, EPS);
+    double newton_tol = fmax(10.0 * EPS / rtol_min, fmin(sqrt(rtol_min), 0.03));
+    if (newton_tol <= 0.0) newton_tol = 1e-9;
+    const int newton_maxiter = 4;
+
+    double h_abs;
+    if (opt->has_first_step) {
+        if (opt->first_step == 0.0) { free(w); return ORC_ERR_INVALID_STEP_SIZE; }
+        h_abs = fabs(opt->first_step);
+    } else {
+        double f1[64], y1[64];
+        double guess = hinit(f, p, n, x, y, direction, f0, f1, y1, 1, hmax, atol, rtol);
+        double max_h = fabs(xend - x);
+        if (fabs(guess) > max_h) guess = max_h * direction;
+        h_abs = fabs(guess);
+    }
+    h_abs = fmin(h_abs, fmax(hmax, MIN_POSITIVE));
+    double current_h = h_abs;
+
+    memcpy(d, y, (size_t)n * sizeof(double));
+    for (int i = 0; i < n; i++) d[n + i] = f0[i] * current_h * direction;
+    int order = 1, n_equal_steps = 0, status;
+
+    so_call(so, x, x, y, NULL, 0.0);
+
+    for (;;) {
+        if (nstep >= nmax) { status = ORC_NEED_LARGER_NMAX; break; }
+        if (current_h < MIN_POSITIVE) { status = ORC_STEP_SIZE_TOO_SMALL; break; }
+        double h_try = current_h;
+        if (h_try > hmax) {
+            change_d(d, n, order, hmax / h_try);
+            h_try = hmax; current_h = h_try; n_equal_steps = 0; lu_is_current = 0;
+        }
+        if (h_try < hmin && hmin > 0.0) {
+            change_d(d, n, order, fmax(hmin / h_try, 1.0));
+            h_try = hmin; current_h = h_try; n_equal_steps = 0; lu_is_current = 0;
+        }
+        double h_signed = direction * h_try;
+        const double x_start = x;
+        double x_new = x + h_signed;
+        if (direction * (x_new - xend) > 0.0) {
+            double step_to_end = fabs(xend - x);
+            if (step_to_end == 0.0) { status = ORC_SUCCESS; break; }
+            double factor = step_to_end / h_try;
+            change_d(d, n, order, factor);
+            current_h *= factor;
+            h_try = current_h;
+            h_signed = direction * h_try;
+            x_new = x + h_signed;
+            n_equal_steps = 0; lu_is_current = 0;
+        }
+        if ((x + 0.1 * fabs(h_signed)) == x) { status = ORC_STEP_SIZE_TOO_SMALL; break; }
+        nstep += 1;
+
+        for (int i = 0; i < n; i++) {
+            double sum = 0.0;
+            for (int k = 0; k <= order; k++) sum += d[k * n + i];
+            y_predict[i] = sum;
+        }
+        for (int i = 0; i < n; i++) {
+            scale[i] = tol_at(atol, i) + tol_at(rtol, i) * fabs(y_predict[i]);
+            if (scale[i] == 0.0) scale[i] = EPS;
+        }
+        for (int i = 0; i < n; i++) {
+            double sacc = 0.0;
+            for (int j = 1; j <= order; j++) sacc += gamma[j] * d[j * n + i];
+            psi[i] = sacc / alpha[order];
+        }
+        const double c = h_signed / alpha[order];
+        if (!lu_is_current || fabs(c - current_c) / fmax(fabs(c), 1.0) > 0.1) {
+            for (int r = 0; r < n; r++) {
+                for (int ci = 0; ci < n; ci++) lu[r * n + ci] = -c * jac[r * n + ci];
+                lu[r * n + r] += 1.0;
+            }
+            nlu += 1;
+            if (lu_decomp(lu, pivot, n) == 0) { lu_is_current = 1; current_c = c; }
+            else {
+                change_d(d, n, order, 0.5);
+                current_h *= 0.5; n_equal_steps = 0; lu_is_current = 0; nrejct += 1;
+                continue;
+            }
+        }
+
+        memcpy(y_new, y_predict, (size_t)n * sizeof(double));
+        for (int i = 0; i < n; i++) delta[i] = 0.0;
+        int converged = 0, has_prev = 0, iters = 0;
+        double dy_norm_prev = 0.0;
+        while (iters < newton_maxiter) {
+            f(x_new, y_new, rhs, p);
+            nfev += 1;
+            for (int i = 0; i < n; i++) rhs[i] = c * rhs[i] - psi[i] - delta[i];
+            lin_solve(lu, rhs, pivot, n);
+            double dy_norm = wrms_scaled(rhs, scale, n);
+            int rate_condition = 0;
+            if (has_prev && dy_norm_prev > 0.0) {
+                double rate = dy_norm / dy_norm_prev;
+                if (rate >= 1.0) rate_condition = 1;
+                else {
+                    double remaining = (double)(newton_maxiter - iters);
+                    double estimate = ORC_POW(rate, remaining) / (1.0 - rate) * dy_norm;
+                    if (estimate > newton_tol) rate_condition = 1;
+                }
+            }
+            for (int i = 0; i < n; i++) { y_new[i] += rhs[i]; delta[i] += rhs[i]; }
+            if (dy_norm == 0.0) { converged = 1; break; }
+            if (has_prev && dy_norm_prev > 0.0) {
+                double rate = dy_norm / dy_norm_prev;
+                if (rate < 1.0) {
+                    double estimate = rate / (1.0 - rate) * dy_norm;
+                    if (estimate < newton_tol) { converged = 1; break; }
+                }
+            }
+            if (rate_condition) break;
+            dy_norm_prev = dy_norm; has_prev = 1;
+            iters += 1;
+        }
+        if (!converged) {
+            fd_jac(f, p, n, x_new, y_predict, jac);
+            njev += 1;
+            lu_is_current = 0;
+            change_d(d, n, order, 0.5);
+            current_h *= 0.5; n_equal_steps = 0; nrejct += 1;
+            continue;
+        }
+        const double safety = SAFETY_DEFAULT * (2.0 * (double)newton_maxiter + 1.0)
+                            / (2.0 * (double)newton_maxiter + (double)(iters + 1));
+        for (int i = 0; i < n; i++) {
+            scale[i] = tol_at(atol, i) + tol_at(rtol, i) * fabs(y_new[i]);
+            if (scale[i] == 0.0) scale[i] = EPS;
+        }
+        for (int i = 0; i < n; i++) rhs[i] = error_const[order] * delta[i];
+        const double error_norm = wrms_scaled(rhs, scale, n);
+        if (error_norm > 1.0) {
+            double factor = safety * ORC_POW(error_norm, -1.0 / ((double)order + 1.0));
+            factor = fmax(factor, MIN_FACTOR);
+            change_d(d, n, order, factor);
+            current_h *= factor; n_equal_steps = 0; nrejct += 1;
+            continue;
+        }
+        naccpt += 1;
+        n_equal_steps += 1;
+        x = x_new;
+        memcpy(y, y_new, (size_t)n * sizeof(double));
+        for (int i = 0; i < n; i++) {
+            d[(order + 2) * n + i] = delta[i] - d[(order + 1) * n + i];
+            d[(order + 1) * n + i] = delta[i];
+        }
+        for (int k = order; k >= 0; k--)
+            for (int i = 0; i < n; i++) d[k * n + i] += d[(k + 1) * n + i];
+        for (int i = 0; i < n; i++) {
+            double *b = cont + (size_t)i * 7;
+            b[0] = d[i];
+            for (int k = 0; k < BDF_MAXO; k++) b[1 + k] = (k + 1 <= order) ? d[(k + 1) * n + i] : 0.0;
+            b[6] = (double)order;
+        }
+        /* bdf.rs:518-519: interpolant anchored at x_start, callback xold = x - h_signed */
+        so_call2(so, x - h_signed, x, y, cont, x_start, h_signed);
+        if (direction * (x - xend) >= 0.0) { status = ORC_SUCCESS; break; }
+
+        if (n_equal_steps >= order + 1) {
+            double err_m = INFINITY, err_p = INFINITY;
+            if (order > 1) {
+                for (int i = 0; i < n; i++) rhs[i] = error_const[order - 1] * d[order * n + i];
+                err_m = wrms_scaled(rhs, scale, n);
+            }
+            if (order < BDF_MAXO) {
+                for (int i = 0; i < n; i++) rhs[i] = error_const[order + 1] * d[(order + 2) * n + i];
+                err_p = wrms_scaled(rhs, scale, n);
+            }
+            double errors[3] = {err_m, error_norm, err_p}, factors[3];
+            for (int idx = 0; idx < 3; idx++) factors[idx] = ORC_POW(errors[idx], -1.0 / ((double)order + (double)idx));
+            int best = 0;   /* Iterator::max_by: a later element replaces unless the current max is strictly greater */
+            for (int idx = 1; idx < 3; idx++) if (!(factors[best] > factors[idx])) best = idx;
+            int new_order = order;
+            if (best == 0 && order > 1) new_order -= 1;
+            else if (best == 2 && order < BDF_MAXO) new_order += 1;
+            double max_factor = 0.0;
+            for (int idx = 0; idx < 3; idx++) max_factor = fmax(max_factor, factors[idx]);
+            double step_factor = fmin(safety * max_factor, MAX_FACTOR);
+            int old_order = order;
+            change_d(d, n, new_order, step_factor);
+            current_h *= step_factor;
+            order = new_order;
+            n_equal_steps = 0;
+            lu_is_current = 0;
+            if (new_order != old_order) { fd_jac(f, p, n, x, y, jac); njev += 1; }
+        }
+    }
+    res->h = direction * current_h; res->status = status;
+    res->nfev = nfev; res->nstep = nstep; res->naccpt = naccpt; res->nrejct = nrejct;
+    *njev_out = njev; *nlu_out = nlu;
+    memcpy(y_final, y, (size_t)n * sizeof(double));
+    *x_final = x;
+    free(w);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
  * solve_ivp (src/solve/solve_ivp.rs:99-313)
  * ---------------------------------------------------------------------------------------- */
 static void constant_solution(orc_solution *sol, int method, int n, double x0, const double *y0)
@@ -1005,7 +1415,11 @@ static void constant_solution(orc_solution *sol, int method, int n, double x0, c
     sol->ncoef = nc;
     sol->nseg = 1;
     sol->seg_cont = (double *)calloc((size_t)(nc * n > 0 ? nc * n : 1), sizeof(double));
-    for (int i = 0; i < n; i++) sol->seg_cont[i] = y0[i];
+    if (method == ORC_BDF) {   /* cont.rs:44-51: per-state blocks, order marker 1 */
+        for (int i = 0; i < n; i++) { sol->seg_cont[i * nc] = y0[i]; sol->seg_cont[i * nc + nc - 1] = 1.0; }
+    } else {
+        for (int i = 0; i < n; i++) sol->seg_cont[i] = y0[i];
+    }
     sol->seg_xold = (double *)malloc(sizeof(double));
     sol->seg_h = (double *)malloc(sizeof(double));
     sol->seg_xold[0] = x0;
@@ -1019,7 +1433,7 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     sol->n = n;
     sol->ncoef = ncoef_of(opt->method);
     if (n > 64) return ORC_ERR_BAD_ARGUMENT;
-    if (opt->method < ORC_RK23 || opt->method > ORC_RK4) return ORC_ERR_BAD_ARGUMENT;
+    if (opt->method < ORC_RK23 || opt->method > ORC_BDF || opt->method == ORC_RADAU) return ORC_ERR_BAD_ARGUMENT;
 
     if (fabs(xend - x0) < 1e-15) { /* solve_ivp.rs:110-145 */
         if (opt->n_eval >= 0) {
@@ -1079,6 +1493,11 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     int rc;
     if (opt->method == ORC_DOPRI5) rc = dopri5_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
     else if (opt->method == ORC_DOP853) rc = dop853_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
+    else if (opt->method == ORC_BDF) { /* solve_ivp.rs:268-285 */
+        uint64_t njev = 0, nlu = 0;
+        rc = bdf_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf, &njev, &nlu);
+        sol->njev = njev; sol->nlu = nlu;
+    }
     else if (opt->method == ORC_RK4) { /* solve_ivp.rs:184-196: h = first_step or (xend - x0) / 100 */
         double h4 = opt->has_first_step ? opt->first_step : (xend - x0) / 100.0;
         rc = rk4_solve(f, params, n, x0, y0, xend, h4, opt, &so, &r, yf, &xf);
@@ -1089,7 +1508,7 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
         return rc;
     }
     sol->len = so.len; sol->t = so.t; sol->y = so.y;
-    sol->nfev = r.nfev; sol->njev = 0; sol->nlu = 0;
+    sol->nfev = r.nfev;
     sol->nstep = r.nstep; sol->naccpt = r.naccpt; sol->nrejct = r.nrejct;
     sol->status = r.status;
     sol->h_next = r.h;

@@ -20,6 +20,9 @@
  *   src/methods/dop853.rs:114-848   DOP853::solve, interpolate, tableau
  *   src/methods/rk23.rs:81-347      RK23::solve, interpolate, tableau
  *   src/methods/rk4.rs:64-257       RK4::solve, interpolate, tableau
+ *   src/methods/bdf.rs:86-732       BDF::solve, interpolate, change_d ("next" row)
+ *   src/matrix/lu.rs:37-125, src/matrix/linear.rs:55-96   lu_decomp / lin_solve
+ *   src/ivp.rs:67-107               default finite-difference Jacobian
  *   src/solve/solve_ivp.rs:99-313   solve_ivp front end
  *   src/solve/solout.rs:127-431     DefaultSolOut (dense collection, t_eval, step record)
  *   src/solve/cont.rs:16-153        ContinuousOutput
@@ -37,7 +40,7 @@ extern "C" {
 #endif
 
 /* Method enum order follows src/solve/options.rs:14-27. */
-enum { ORC_RK23 = 0, ORC_DOPRI5 = 1, ORC_DOP853 = 2, ORC_RK4 = 3 };
+enum { ORC_RK23 = 0, ORC_DOPRI5 = 1, ORC_DOP853 = 2, ORC_RK4 = 3, ORC_RADAU = 4 /* not restated */, ORC_BDF = 5 };
 
 /* Status order follows src/status.rs:4-19. */
 enum {
@@ -60,7 +63,10 @@ enum {
     ORC_RHS_ZERO = 5,     /* tests/ivp.rs:11-19                                  n=3 */
     ORC_RHS_RATIONAL = 6, /* tests/test_helpers.py:23-25                         n=2 */
     ORC_RHS_EXP2 = 7,     /* tests/ivp.rs:291-298                                n=2 */
-    ORC_RHS_COUNT = 8
+    ORC_RHS_LINEAR = 8,   /* tests/test_helpers.py:11-12                         n=2 */
+    ORC_RHS_ROBERTSON = 9,/* tests/test_ivp.py:327-333                           n=3 */
+    ORC_RHS_VDP_EPS = 10, /* examples/van_der_pol.rs:9-14         p={eps}        n=2 */
+    ORC_RHS_COUNT = 11
 };
 
 typedef void (*orc_ode_fn)(double x, const double *y, double *dydx, const double *p);
@@ -80,6 +86,8 @@ typedef struct {
     int has_max_step;
     double max_step;
     int dense_output;     /* Options.dense_output: collect per-step interpolants */
+    int has_min_step;     /* Options.min_step (BDF only) */
+    double min_step;
     /* Oracle-only guard (not in the reference): stop after this many step attempts
      * with ORC_NEED_LARGER_NMAX.  0 => no guard.  Needed because RK23 in the reference
      * never terminates when the error estimate is NaN (rk23.rs:300-306 leaves h unchanged). */

@@ -15,9 +15,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3}
-RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7}
-RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0)}
+METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3, "BDF": 5}
+RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
+       "linear": 8, "robertson": 9, "vdp_eps": 10}
+RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0),
+            8: (2, 0), 9: (3, 0), 10: (2, 1)}
 STATUS = ["Success", "UserInterrupt", "NeedLargerNMax", "StepSizeTooSmall", "ProbablyStiff",
           "SingularMatrix", "PoorConvergence"]
 
@@ -32,6 +34,7 @@ class _Options(C.Structure):
         ("has_first_step", C.c_int), ("first_step", C.c_double),
         ("has_max_step", C.c_int), ("max_step", C.c_double),
         ("dense_output", C.c_int),
+        ("has_min_step", C.c_int), ("min_step", C.c_double),
         ("attempt_guard", C.c_uint64),
     ]
 
@@ -103,7 +106,7 @@ class _OptHolder:
     """Builds the C options struct and keeps the numpy buffers it points at alive."""
 
     def __init__(self, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
-                 first_step=None, max_step=None, dense_output=False, attempt_guard=0):
+                 first_step=None, max_step=None, min_step=None, dense_output=False, attempt_guard=0):
         m = METHODS[method.upper()] if isinstance(method, str) else int(method)
         self.rtol = np.atleast_1d(np.asarray(rtol, dtype=np.float64)).copy()
         self.atol = np.atleast_1d(np.asarray(atol, dtype=np.float64)).copy()
@@ -123,6 +126,8 @@ class _OptHolder:
         o.has_max_step = int(max_step is not None)
         o.max_step = float(max_step or 0.0)
         o.dense_output = int(bool(dense_output))
+        o.has_min_step = int(min_step is not None)
+        o.min_step = float(min_step or 0.0)
         o.attempt_guard = int(attempt_guard)
         self.c = o
         self.method = m

@@ -121,3 +121,26 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "scipy_truth.json"), "w") as fh:
         json.dump({"meta": meta, "truth": truth_cases()}, fh, indent=1)
     print("wrote fixtures")
+
+
+def stiff_truth():
+    """Independent high-accuracy end states for the stiff ("next" row, BDF) problems: SciPy Radau, rtol=1e-10."""
+    out = {}
+    r = solve_ivp(lambda t, y: vdp(t, y, 1000.0), (0.0, 3000.0), [2.0, 0.0], method="Radau", rtol=1e-10, atol=1e-12)
+    out["vdp_mu1000_t3000"] = list(map(float, r.y[:, -1]))
+
+    def rob(t, s):
+        x, y, z = s
+        return [-0.04 * x + 1e4 * y * z, 0.04 * x - 1e4 * y * z - 3e7 * y * y, 3e7 * y * y]
+    r = solve_ivp(rob, (0.0, 1e8), [1e4, 0.0, 0.0], method="Radau", rtol=1e-10, atol=1e-10)
+    out["robertson_t1e8"] = list(map(float, r.y[:, -1]))
+    r = solve_ivp(lambda t, y: [y[1], ((1.0 - y[0] * y[0]) * y[1] - y[0]) / 1e-3], (0.0, 2.0), [2.0, 0.0],
+                  method="Radau", rtol=1e-10, atol=1e-12)
+    out["vdp_eps1e-3_t2"] = list(map(float, r.y[:, -1]))
+    return out
+
+
+if __name__ == "__main__":
+    with open(os.path.join(HERE, "scipy_stiff_truth.json"), "w") as fh:
+        json.dump({"meta": {"scipy": __import__("scipy").__version__}, "truth": stiff_truth()}, fh, indent=1)
+    print("wrote stiff truth")

@@ -211,3 +211,74 @@ def test_tbound_respected(method):  # tests/test_ivp.py:885-949, tests/test_edge
         lo, hi = min(a, b), max(a, b)
         assert s.status == 0 and s.t[-1] == b
         assert min(seen) >= lo and max(seen) <= hi
+
+
+# ---- BDF ("next" row): the reference's pins for src/methods/bdf.rs -------------------
+
+def sol_linear(t):
+    return np.vstack((-5 * np.sin(2 * t), 2 * np.cos(2 * t) + np.sin(2 * t)))
+
+
+def test_bdf_harmonic_accuracy_and_backward():  # tests/accuracy.rs:18-48, tests/backward_and_bounds.rs:7-32
+    s = O.solve_ivp("sho", 0.0, 2 * np.pi, [1.0, 0.0], method="BDF", rtol=1e-9, atol=1e-9)
+    assert abs(s.y[-1, 0] - 1.0) < 1e-5 and abs(s.y[-1, 1]) < 1e-5
+    s = O.solve_ivp("sho", 2 * np.pi, 0.0, [1.0, 0.0], method="BDF", rtol=1e-9, atol=1e-9, dense_output=True)
+    t0, t1 = s.sol_span()
+    mid = 0.5 * (t0 + t1)
+    ym = s.sol(mid)
+    assert t0 > t1 and abs(ym[0] - np.cos(mid)) < 1e-6 and abs(ym[1] + np.sin(mid)) < 1e-6
+
+
+def test_bdf_t_eval_max_step_zero_interval():  # tests/accuracy.rs:51-77, tests/ivp.rs:49-76,278-289
+    te = np.arange(11) / 10.0
+    s = O.solve_ivp("sho", 0.0, 1.0, [1.0, 0.0], method="BDF", rtol=1e-9, atol=1e-9, t_eval=te)
+    assert all(np.any(np.abs(s.t - t) <= 1e-9) for t in te)
+    s = O.solve_ivp("sho", 0.0, 3.0, [1.0, 0.0], method="BDF", rtol=1e-6, atol=1e-9, max_step=0.05)
+    assert np.abs(np.diff(s.t)).max() <= 0.05 + 1e-12
+    s = O.solve_ivp("sho", 1.23, 1.23, [2.0, 3.0], method="BDF", rtol=1e-9, atol=1e-9)
+    assert np.abs(s.y[-1] - [2.0, 3.0]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("t_span", [(5.0, 9.0), (5.0, 1.0)])
+def test_bdf_integration_rational(t_span):  # tests/test_ivp.py:173-241, tests/test_basic_integration.py:89-104
+    rtol, atol = 1e-3, 1e-6
+    s = O.solve_ivp("rational", t_span[0], t_span[1], [1 / 3, 2 / 9], method="BDF", rtol=rtol, atol=atol, dense_output=True)
+    assert s.t[0] == t_span[0] and s.status == 0
+    assert 0 < s.njev and 0 < s.nlu
+    assert np.all(compute_error(s.y.T, sol_rational(s.t), rtol, atol) < 5)
+    tc = np.linspace(*t_span)
+    yc = np.array([s.sol_extrapolate(t) for t in tc]).T
+    assert np.all(compute_error(yc, sol_rational(tc), rtol, atol) < 5)
+    ys = np.array([s.sol_extrapolate(t) for t in s.t])
+    np.testing.assert_allclose(ys, s.y, rtol=1e-15, atol=1e-15)
+
+
+def test_bdf_integration_const_jac():  # tests/test_ivp.py:273-317, tests/test_stiff.py:35-53 (FD Jacobian here)
+    rtol, atol = 1e-3, 1e-6
+    s = O.solve_ivp("linear", 0.0, 2.0, [0.0, 2.0], method="BDF", rtol=rtol, atol=atol, dense_output=True)
+    assert s.t[0] == 0.0 and s.status == 0 and s.nfev < 100
+    assert np.all(compute_error(s.y.T, sol_linear(s.t), rtol, atol) < 10)
+    tc = np.linspace(0.0, 2.0)
+    yc = np.array([s.sol_extrapolate(t) for t in tc]).T
+    assert np.all(compute_error(yc, sol_linear(tc), rtol, atol) < 60)
+    ys = np.array([s.sol_extrapolate(t) for t in s.t])
+    np.testing.assert_allclose(ys, s.y, rtol=1e-14, atol=1e-14)
+
+
+def test_bdf_integration_stiff_robertson():  # tests/test_ivp.py:320-342
+    s = O.solve_ivp("robertson", 0.0, 1e8, [1e4, 0.0, 0.0], method="BDF", rtol=1e-6, atol=1e-6)
+    assert s.status == 0 and s.nfev < 5000 and s.njev < 200
+
+
+def test_bdf_against_independent_stiff_truth():
+    """SciPy Radau @1e-10 (tests/golden/scipy_stiff_truth.json) for the BDF workloads: BASELINE C5's Van der Pol
+    mu=1000 on [0,3000] (benches/benchmark.py:118-126), Robertson, and examples/van_der_pol.rs."""
+    import json, os
+    tr = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scipy_stiff_truth.json")))["truth"]
+    s = O.solve_ivp("vdp", 0.0, 3000.0, [2.0, 0.0], params=[1000.0], method="BDF", rtol=1e-4, atol=1e-6)
+    assert s.status == 0 and np.abs(s.y[-1] - tr["vdp_mu1000_t3000"]).max() < 1e-2
+    s = O.solve_ivp("robertson", 0.0, 1e8, [1e4, 0.0, 0.0], method="BDF", rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(s.y[-1], tr["robertson_t1e8"], rtol=1e-4, atol=1e-6)
+    te = np.arange(21) * 0.1
+    s = O.solve_ivp("vdp_eps", 0.0, 2.0, [2.0, 0.0], params=[1e-3], method="BDF", rtol=1e-6, atol=1e-8, t_eval=te)
+    assert np.array_equal(s.t, te) and np.abs(s.y[-1] - tr["vdp_eps1e-3_t2"]).max() < 1e-4
