@@ -33,7 +33,8 @@ extern "C" {
 #define IVP_HIP_ABI_VERSION 1
 
 /* Method: same order as `enum Method`, src/solve/options.rs:14-27. The explicit RK methods (RK23, DOPRI5,
- * DOP853 and the fixed-step RK4) are on the accelerated path; RADAU and BDF return IVP_ERR_UNSUPPORTED_METHOD. */
+ * DOP853, the fixed-step RK4) and the variable-order implicit BDF are on the accelerated path; RADAU returns
+ * IVP_ERR_UNSUPPORTED_METHOD. */
 typedef enum {
     IVP_RK23 = 0,
     IVP_DOPRI5 = 1, /* "RK45" */
@@ -64,7 +65,7 @@ typedef enum {
     IVP_ERR_INVALID_STEP_SIZE = -5,       /* ConfigError::InvalidStepSize (RK4: first_step zero / wrong sign, rk4.rs:81-87) */
     IVP_ERR_INVALID_SCALE_FACTORS = -6,   /* ConfigError::InvalidScaleFactors  */
     IVP_ERR_BAD_ARGUMENT = -100,          /* NULL pointer, unknown rhs id, n mismatch ...            */
-    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU / BDF: not on the accelerated path                */
+    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU: not on the accelerated path                      */
     IVP_ERR_NO_DEVICE = -102,             /* no HIP device: there is deliberately no CPU fallback    */
     IVP_ERR_HIP = -103,                   /* a HIP runtime call failed; see ivp_last_error_string()  */
     IVP_ERR_JIT = -104                    /* hiprtc compilation of a user RHS failed                 */
@@ -82,7 +83,10 @@ typedef enum {
     IVP_RHS_ZERO = 5,     /* y' = 0                                    n=3  tests/ivp.rs:11-19                 */
     IVP_RHS_RATIONAL = 6, /* SciPy "rational" problem                  n=2  tests/test_helpers.py:23-25        */
     IVP_RHS_EXP2 = 7,     /* y' = y                                    n=2  tests/ivp.rs:291-298               */
-    IVP_RHS_BUILTIN_COUNT = 8,
+    IVP_RHS_LINEAR = 8,   /* y' = A y, A = [[-1,-5],[1,1]]            n=2  tests/test_helpers.py:11-12        */
+    IVP_RHS_ROBERTSON = 9,/* Robertson kinetics                        n=3  tests/test_ivp.py:327-333          */
+    IVP_RHS_VDP_EPS = 10, /* stiff Van der Pol        p={eps}          n=2  examples/van_der_pol.rs:9-14       */
+    IVP_RHS_BUILTIN_COUNT = 11,
     IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */
 } ivp_rhs_id_t;
 
@@ -121,6 +125,8 @@ typedef struct {
     int32_t has_max_step;   /* Options.max_step is Some(..) */
     double max_step;
     int32_t dense_output;   /* Options.dense_output: record per-step interpolants (needs max_log > 0) */
+    int32_t has_min_step;   /* Options.min_step is Some(..) (read by BDF only, src/solve/solve_ivp.rs:271) */
+    double min_step;
     /* ---- knobs that exist only on the GPU path ---- */
     int32_t fp_mode;        /* ivp_fp_mode_t, default IVP_FP_STRICT */
     int32_t chunk_attempts; /* step attempts per kernel launch between compactions; 0 = auto */
@@ -156,6 +162,9 @@ typedef struct {
     double *seg_xold;   /* [max_log][B]                                                         */
     double *seg_h;      /* [max_log][B]                                                         */
     uint32_t *n_seg;    /* [B]                                                                  */
+    /* implicit methods (BDF): Solution.njev / Solution.nlu; zero for the explicit RK methods  */
+    uint64_t *njev;     /* [B]                                                                  */
+    uint64_t *nlu;      /* [B]                                                                  */
 } ivp_batch_result_t;
 
 /* What the last solve on a context did (filled when options.profile == 1). */

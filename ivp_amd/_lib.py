@@ -32,6 +32,7 @@ class OptionsT(C.Structure):
         ("has_first_step", C.c_int32), ("first_step", C.c_double),
         ("has_max_step", C.c_int32), ("max_step", C.c_double),
         ("dense_output", C.c_int32),
+        ("has_min_step", C.c_int32), ("min_step", C.c_double),
         ("fp_mode", C.c_int32), ("chunk_attempts", C.c_int32), ("max_log", C.c_uint32), ("variant", C.c_int32), ("profile", C.c_int32),
     ]
 
@@ -40,7 +41,7 @@ class BatchResultT(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in (
         "y_end", "t_end", "status", "nfev", "nstep", "naccpt", "nrejct", "h_next",
         "y_eval", "eval_idx", "n_filled", "t_log", "y_log", "n_log",
-        "seg_cont", "seg_xold", "seg_h", "n_seg")]
+        "seg_cont", "seg_xold", "seg_h", "n_seg", "njev", "nlu")]
 
 
 class RunStatsT(C.Structure):

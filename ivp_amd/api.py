@@ -165,7 +165,24 @@ class Exp2(IVP):  # tests/ivp.rs:291-298
     rhs_id = 7; n = 2; n_params = 0
 
 
-BUILTIN = {"decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
+@dataclass
+class LinearSystem(IVP):  # tests/test_helpers.py:11-12  (y' = [[-1,-5],[1,1]] y)
+    rhs_id = 8; n = 2; n_params = 0
+
+
+@dataclass
+class Robertson(IVP):  # tests/test_ivp.py:327-333
+    rhs_id = 9; n = 3; n_params = 0
+
+
+@dataclass
+class StiffVanDerPol(IVP):  # examples/van_der_pol.rs:5-15
+    eps: float = 1e-3
+    rhs_id = 10; n = 2; n_params = 1
+    def params(self): return (self.eps,)
+
+
+BUILTIN = {"linear": LinearSystem, "robertson": Robertson, "vdp_eps": StiffVanDerPol, "decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
            "zero": ZeroRhs, "rational": Rational, "exp2": Exp2}
 
 
@@ -216,7 +233,7 @@ class Options:
     t_eval: Optional[Sequence[float]] = None
     first_step: Optional[float] = None
     max_step: Optional[float] = None
-    min_step: Optional[float] = None      # RADAU/BDF only in the reference; ignored by explicit RK
+    min_step: Optional[float] = None      # read by BDF only (src/solve/solve_ivp.rs:271)
     dense_output: bool = False
     # GPU-only
     fp_mode: FpMode = FpMode.STRICT
@@ -254,6 +271,8 @@ class Options:
         if self.max_step is not None:
             o.has_max_step, o.max_step = 1, float(self.max_step)
         o.dense_output = int(bool(self.dense_output))
+        if self.min_step is not None:
+            o.has_min_step, o.min_step = 1, float(self.min_step)
         o.fp_mode = int(self.fp_mode)
         o.chunk_attempts = int(self.chunk_attempts)
         o.max_log = int(self.max_log)
@@ -326,6 +345,20 @@ def _interpolate(method: Method, xi: float, cont: np.ndarray, n: int, xold: floa
         s1 = 1.0 - s
         conpar = c[4] + s * (c[5] + s1 * (c[6] + s * c[7]))
         return c[0] + s * (c[1] + s1 * (c[2] + s * (c[3] + s1 * conpar)))
+    if method == Method.BDF:  # bdf.rs:618-656; per-state blocks [D0, D1..D5, order]
+        if h == 0.0:
+            return np.zeros(n)
+        blk = cont.reshape(n, 7)
+        order = int(min(max(round(blk[0, 6]), 1), 5))
+        x_new = xold + h
+        p = np.zeros(5)
+        for k in range(order):
+            xf = (xi - (x_new - h * k)) / (h * (k + 1.0))
+            p[k] = xf if k == 0 else p[k - 1] * xf
+        out = blk[:, 0].copy()
+        for k in range(order):
+            out = out + blk[:, 1 + k] * p[k]
+        return out
     if method == Method.RK4:  # rk4.rs:229-244
         t = (xi - xold) / h
         t2 = t * t
@@ -355,8 +388,13 @@ class ContinuousOutput:
     @staticmethod
     def constant(method: Method, x0: float, y0: np.ndarray) -> "ContinuousOutput":
         n = len(y0)
-        cont = np.zeros((1, method.coeffs_per_state() * n))
-        cont[0, :n] = y0
+        nc = method.coeffs_per_state()
+        cont = np.zeros((1, nc * n))
+        if method == Method.BDF:   # cont.rs:44-51
+            cont[0, 0::nc] = y0
+            cont[0, nc - 1::nc] = 1.0
+        else:
+            cont[0, :n] = y0
         return ContinuousOutput(method, n, cont, np.array([x0]), np.array([1e-15]))
 
     def t_span(self):
@@ -463,6 +501,8 @@ class BatchSolution:
     seg_xold: object = None
     seg_h: object = None
     n_seg: object = None
+    njev: object = None
+    nlu: object = None
     stats: dict = field(default_factory=dict)
 
 
@@ -532,12 +572,15 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
     method = options.method_enum
     ne = 0 if options.t_eval is None else len(options.t_eval)
     ml = int(options.max_log)
-    nc = method.coeffs_per_state() * n if method in (Method.RK23, Method.DOPRI5, Method.DOP853, Method.RK4) else 0
+    nc = method.coeffs_per_state() * n if method != Method.RADAU else 0
 
     res = out or BatchSolution(
         y_end=xp_zeros((n, B), f64), t_end=xp_zeros((B,), f64), status=xp_zeros((B,), i32),
         nfev=xp_zeros((B,), u64), nstep=xp_zeros((B,), u64), naccpt=xp_zeros((B,), u64),
         nrejct=xp_zeros((B,), u64), h_next=xp_zeros((B,), f64))
+    if res.njev is None:
+        res.njev = xp_zeros((B,), u64)
+        res.nlu = xp_zeros((B,), u64)
     if options.t_eval is not None and res.y_eval is None:
         res.y_eval = xp_zeros((max(ne, 1), n, B), f64)
         res.eval_idx = xp_zeros((max(ne, 1), B), i32)
@@ -625,6 +668,6 @@ def solve_ivp(f: IVP, x0: float, xend: float, y0: Sequence[float], options: Opti
         ns = int(r.n_seg[0])
         cs = ContinuousOutput(method, n, r.seg_cont[:ns, :, 0].copy(), r.seg_xold[:ns, 0].copy(), r.seg_h[:ns, 0].copy())
     return Solution(t=t, y=y, t_events=[[] for _ in range(n_events)], y_events=[[] for _ in range(n_events)],
-                    nfev=int(r.nfev[0]), njev=0, nlu=0, nstep=int(r.nstep[0]), naccpt=int(r.naccpt[0]),
+                    nfev=int(r.nfev[0]), njev=int(r.njev[0]), nlu=int(r.nlu[0]), nstep=int(r.nstep[0]), naccpt=int(r.naccpt[0]),
                     nrejct=int(r.nrejct[0]), status=Status(int(r.status[0])), continuous_sol=cs,
                     h_next=float(r.h_next[0]))

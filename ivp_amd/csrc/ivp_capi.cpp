@@ -23,9 +23,9 @@
 namespace {
 
 struct RhsDim { int n, p; };
-const RhsDim kRhsDims[IVP_RHS_BUILTIN_COUNT] = {{1, 1}, {2, 0}, {2, 1}, {6, 1}, {3, 3}, {3, 0}, {2, 0}, {2, 0}};
+const RhsDim kRhsDims[IVP_RHS_BUILTIN_COUNT] = {{1, 1}, {2, 0}, {2, 1}, {6, 1}, {3, 3}, {3, 0}, {2, 0}, {2, 0}, {2, 0}, {3, 0}, {2, 1}};
 
-int ncoef_of(int method) { return method == IVP_DOPRI5 ? 5 : method == IVP_DOP853 ? 8 : 4; }
+int ncoef_of(int method) { return method == IVP_DOPRI5 ? 5 : method == IVP_DOP853 ? 8 : method == IVP_BDF ? 7 : 4; }
 
 // grow-only device buffer
 struct DevBuf {
@@ -58,9 +58,10 @@ struct ivp_ctx {
     DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval;
     DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
     DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
+    DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu;
     // staging for the host-pointer entry point
     DevBuf st_y0, st_params, st_t0, st_t1;
-    DevBuf st_out[18];
+    DevBuf st_out[20];
     uint32_t *pinned = nullptr;  // host-pinned: active count + misc
     std::vector<hipEvent_t> events;
     ivp_run_stats_t stats{};
@@ -107,9 +108,16 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "problem dims (n=%d,p=%d) do not match rhs (n=%d,p=%d)", prob->n, prob->n_params, n, p);
     if (n < 1 || n > IVP_MAX_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
     if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
-    if (opt->method == IVP_RADAU || opt->method == IVP_BDF)
-        return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "method %d is not on the accelerated explicit-RK path", opt->method);
-    if (opt->method < IVP_RK23 || opt->method > IVP_RK4) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown method %d", opt->method);
+    if (opt->method == IVP_RADAU)
+        return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "method %d (RADAU) is not on the accelerated path", opt->method);
+    if (opt->method < IVP_RK23 || opt->method > IVP_BDF) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown method %d", opt->method);
+    if (opt->method == IVP_BDF) {   // BDF::solve validates tolerances, bdf.rs:112-128
+        for (int i = 0; i < n; ++i) {
+            const double rt = opt->rtol_vec ? opt->rtol_vec[i < opt->rtol_vec_len ? i : 0] : opt->rtol;
+            const double at = opt->atol_vec ? opt->atol_vec[i < opt->atol_vec_len ? i : 0] : opt->atol;
+            if (rt < 0.0 || at < 0.0) return fail(ctx, IVP_ERR_NEGATIVE_TOLERANCE, "negative tolerance at component %d", i);
+        }
+    }
     if (opt->rtol_vec && opt->rtol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "rtol: expected %d, got %d", n, opt->rtol_vec_len);
     if (opt->atol_vec && opt->atol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "atol: expected %d, got %d", n, opt->atol_vec_len);
     if (opt->t_eval && opt->n_eval < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative n_eval");
@@ -159,6 +167,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
     DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval,
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
+                      &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu,
                       &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
@@ -234,6 +243,8 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     a.has_first_step = opt->has_first_step ? 1 : 0;
     a.has_max_step = opt->has_max_step ? 1 : 0;
     a.nmax = opt->max_steps ? opt->max_steps : UINT64_MAX;  // None => usize::MAX, solve_ivp.rs:218
+    a.min_step = opt->min_step;
+    a.has_min_step = opt->has_min_step ? 1 : 0;
 
     // ---- state / result arrays: the caller's buffers where given, context scratch otherwise ----
 #define BIND(field, userptr, scratch, bytes)                                   \
@@ -252,6 +263,21 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     BIND(nstep, out->nstep, sc_nstep, sizeof(uint64_t) * B);
     BIND(naccpt, out->naccpt, sc_naccpt, sizeof(uint64_t) * B);
     BIND(nrejct, out->nrejct, sc_nrejct, sizeof(uint64_t) * B);
+    if (opt->method == IVP_BDF) {
+        BIND(njev, out->njev, sc_njev, sizeof(uint64_t) * B);
+        BIND(nlu, out->nlu, sc_nlu, sizeof(uint64_t) * B);
+        HIP_TRY(ctx, ctx->bdf_d.reserve(sizeof(double) * 8 * n * B));
+        HIP_TRY(ctx, ctx->bdf_jac.reserve(sizeof(double) * n * n * B));
+        HIP_TRY(ctx, ctx->bdf_lu.reserve(sizeof(double) * n * n * B));
+        HIP_TRY(ctx, ctx->bdf_piv.reserve(sizeof(uint32_t) * B));
+        a.bdf_d = (double *)ctx->bdf_d.p;
+        a.bdf_jac = (double *)ctx->bdf_jac.p;
+        a.bdf_lu = (double *)ctx->bdf_lu.p;
+        a.bdf_piv = (uint32_t *)ctx->bdf_piv.p;
+    } else {
+        if (out->njev) HIP_TRY(ctx, hipMemsetAsync(out->njev, 0, sizeof(uint64_t) * B, s));   // njev = nlu = 0 for explicit RK
+        if (out->nlu) HIP_TRY(ctx, hipMemsetAsync(out->nlu, 0, sizeof(uint64_t) * B, s));
+    }
     HIP_TRY(ctx, ctx->k1.reserve(sizeof(double) * n * B));
     HIP_TRY(ctx, ctx->facold.reserve(sizeof(double) * B));
     HIP_TRY(ctx, ctx->hlamb.reserve(sizeof(double) * B));
@@ -461,7 +487,7 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
     struct Slot { void *host; size_t bytes; void **dev; };
     ivp_batch_result_t d;
     std::memset(&d, 0, sizeof d);
-    Slot slots[18] = {
+    Slot slots[20] = {
         {out->y_end, sizeof(double) * n * B, (void **)&d.y_end},
         {out->t_end, sizeof(double) * B, (void **)&d.t_end},
         {out->status, sizeof(int32_t) * B, (void **)&d.status},
@@ -480,8 +506,10 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
         {out->seg_xold, sizeof(double) * ml * B, (void **)&d.seg_xold},
         {out->seg_h, sizeof(double) * ml * B, (void **)&d.seg_h},
         {out->n_seg, sizeof(uint32_t) * B, (void **)&d.n_seg},
+        {out->njev, sizeof(uint64_t) * B, (void **)&d.njev},
+        {out->nlu, sizeof(uint64_t) * B, (void **)&d.nlu},
     };
-    for (int i = 0; i < 18; ++i) {
+    for (int i = 0; i < 20; ++i) {
         if (slots[i].host && slots[i].bytes) {
             HIP_TRY(ctx, ctx->st_out[i].reserve(slots[i].bytes));
             *slots[i].dev = ctx->st_out[i].p;
@@ -490,7 +518,7 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
     rc = ivp_batch_solve_device(ctx, prob, B, (const double *)ctx->st_y0.p, np > 0 ? (const double *)ctx->st_params.p : nullptr,
                                 (const double *)ctx->st_t0.p, t0_len, (const double *)ctx->st_t1.p, t1_len, opt, &d, nullptr);
     if (rc != IVP_OK) return rc;
-    for (int i = 0; i < 18; ++i)
+    for (int i = 0; i < 20; ++i)
         if (slots[i].host && slots[i].bytes)
             HIP_TRY(ctx, hipMemcpy(slots[i].host, *slots[i].dev, slots[i].bytes, hipMemcpyDeviceToHost));
     return IVP_OK;

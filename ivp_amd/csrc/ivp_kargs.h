@@ -68,6 +68,14 @@ struct IvpKArgs {
     double *seg_xold;         // [max_log][B]
     double *seg_h;            // [max_log][B]
     uint32_t *n_seg;          // [B]
+    // ---- BDF (variable-order implicit) state ----
+    double min_step;          // Options.min_step
+    int32_t has_min_step;
+    double *bdf_d;            // [8*N][B]   differences array D (bdf.rs:220)
+    double *bdf_jac;          // [N*N][B]   Jacobian
+    double *bdf_lu;           // [N*N][B]   LU of (I - c J)
+    uint32_t *bdf_piv;        // [B]        pivot rows, 4 bits each
+    uint64_t *njev, *nlu;     // [B]
     uint32_t *err_flag;       // device word: IVP_ERRFLAG_* bits raised by the init kernel
     // ---- profiling ----
     unsigned long long *slot_counter;  // optional: += lanes x attempts the wave executed

@@ -226,6 +226,33 @@ struct RhsExp2 {     // tests/ivp.rs:291-298
     static IVP_HD void ode(double, const double *y, double *d, const double *) { d[0] = y[0]; d[1] = y[1]; }
 };
 
+struct RhsLinear {   // tests/test_helpers.py:11-12
+    enum { N = 2, P = 0 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *)
+    {
+        d[0] = -y[0] - 5.0 * y[1];
+        d[1] = y[0] + y[1];
+    }
+};
+struct RhsRobertson {   // tests/test_ivp.py:327-333
+    enum { N = 3, P = 0 };
+    static IVP_HD void ode(double, const double *s, double *d, const double *)
+    {
+        const double x = s[0], y = s[1], z = s[2];
+        d[0] = -0.04 * x + 1e4 * y * z;
+        d[1] = 0.04 * x - 1e4 * y * z - 3e7 * y * y;
+        d[2] = 3e7 * y * y;
+    }
+};
+struct RhsVdpEps {   // examples/van_der_pol.rs:9-14
+    enum { N = 2, P = 1 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *p)
+    {
+        d[0] = y[1];
+        d[1] = ((1.0 - y[0] * y[0]) * y[1] - y[0]) / p[0];
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Per-lane state
 // ------------------------------------------------------------------------------------------------
@@ -316,13 +343,44 @@ IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L,
 // ------------------------------------------------------------------------------------------------
 // Dense-output polynomials (dopri5.rs:467-478, dop853.rs:659-670, rk23.rs:313-321)
 // ------------------------------------------------------------------------------------------------
-enum { M_RK23 = 0, M_DOPRI5 = 1, M_DOP853 = 2, M_RK4 = 3 };   // Method order, options.rs:14-27
-template <int M> struct NCoef { enum { v = (M == M_DOPRI5) ? 5 : (M == M_DOP853) ? 8 : 4 }; };
+enum { M_RK23 = 0, M_DOPRI5 = 1, M_DOP853 = 2, M_RK4 = 3, M_RADAU = 4, M_BDF = 5 };   // Method order, options.rs:14-27
+template <int M> struct NCoef { enum { v = (M == M_DOPRI5) ? 5 : (M == M_DOP853) ? 8 : (M == M_BDF) ? 7 : 4 }; };
+
+// BDF dense output (bdf.rs:618-656); cont is per-state blocks [D0, D1..D5, order]
+template <int N>
+IVP_HD void bdf_interpolate(double xi, double *yi, const double *cont, double xold, double h)
+{
+    if (h == 0.0) return;
+    double ordf = rint(cont[6]);   // order is an exact small integer: round() == rint()
+    ordf = ordf < 1.0 ? 1.0 : (ordf > 5.0 ? 5.0 : ordf);
+    const int order = (int)ordf;
+    const double x_new = xold + h;
+    double pk[5];
+    double prev = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double denom = h * ((double)k + 1.0);
+        const double t_shift = x_new - h * (double)k;
+        const double xf = (xi - t_shift) / denom;
+        pk[k] = k == 0 ? xf : prev * xf;
+        prev = pk[k];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double sum = cont[i * 7];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (k < order) sum += cont[i * 7 + 1 + k] * pk[k];
+        yi[i] = sum;
+    }
+}
 
 template <int M, int N>
 IVP_HD void interpolate(double xi, double *yi, const double *cont, double xold, double h)
 {
-    if constexpr (M == M_DOPRI5) {
+    if constexpr (M == M_BDF) {
+        bdf_interpolate<N>(xi, yi, cont, xold, h);
+    } else if constexpr (M == M_DOPRI5) {
         const double theta = (xi - xold) / h;
         const double theta1 = 1.0 - theta;
 #pragma unroll
@@ -388,7 +446,18 @@ IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, 
 
 template <int M, int N, int P>
 IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
+                        const double *y, const double *cont, double h, double ixold);
+template <int M, int N, int P>
+IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
                         const double *y, const double *cont, double h)
+{
+    solout_full<M, N, P>(a, j, L, xold, x, y, cont, h, xold);
+}
+// `xold` is the callback's first argument, `ixold`/`h` the interpolant's own anchor (StepInterpolant.xold/.h):
+// identical for the RK methods, different for BDF (bdf.rs:518-519).
+template <int M, int N, int P>
+IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
+                        const double *y, const double *cont, double h, double ixold)
 {
     constexpr int NC = NCoef<M>::v * N;
     const double tol = 1e-12;
@@ -399,7 +468,7 @@ IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xol
             const size_t k = L.n_seg;
 #pragma unroll
             for (int c = 0; c < NC; ++c) a.seg_cont[(k * NC + c) * B + j] = cont[c];
-            a.seg_xold[k * B + j] = xold;
+            a.seg_xold[k * B + j] = ixold;
             a.seg_h[k * B + j] = h;
         }
         L.n_seg += 1;
@@ -413,13 +482,13 @@ IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xol
         } else if (x > xold) {
             while (i < ne && a.t_eval[i] <= x + tol) {
                 const double te = a.t_eval[i];
-                if (te >= xold - tol) { interpolate<M, N>(te, yi, cont, xold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
+                if (te >= xold - tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
                 ++i;
             }
         } else {
             while (i < ne && a.t_eval[i] >= x - tol) {
                 const double te = a.t_eval[i];
-                if (te <= xold + tol) { interpolate<M, N>(te, yi, cont, xold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
+                if (te <= xold + tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
                 ++i;
             }
         }
@@ -431,7 +500,7 @@ IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xol
                 const double target = L.x0 + direction * a.first_step;
                 if (direction * (x - target) >= -tol) {
                     if (cont != nullptr) {
-                        interpolate<M, N>(target, yi, cont, xold, h);
+                        interpolate<M, N>(target, yi, cont, ixold, h);
                         so_push_log<M, N, P>(a, j, L, target, yi);
                         L.flags |= IVP_F_FIRSTOUT;
                     }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(IVP_WAVE) void init_kernel_t(const IvpKArgs a)
     const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x;
     const bool valid = i < a.B;
     int32_t st = 0;
-    if (valid) st = init_body<M, R, FULL>(a, i);
+    if (valid) st = any_init_body<M, R, FULL>(a, i);
     if (a.perm_out) compact_append(a, i, valid && st == IVP_RUNNING);
 }
 
@@ -50,7 +50,7 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
     }
     uint32_t it = 0;
     int32_t st = 0;
-    if (active) it = chunk_body<M, R, FULL>(a, j, st);
+    if (active) it = any_chunk_body<M, R, FULL>(a, j, st);
     const bool still = active && st == IVP_RUNNING;
     compact_append(a, j, still);
     if (a.slot_counter) {

@@ -33,6 +33,7 @@
 #define IVP_LAUNCH_NAME ivp_launch_strict
 #endif
 #include "rk_core.h"
+#include "bdf_core.h"
 #include "rk_global.h"
 #include "rk_launch.h"
 
@@ -62,6 +63,8 @@ hipError_t launch_rhs(int what, int method, bool full, const IvpKArgs &a, uint32
         return full ? launch_one<M_DOP853, R, true>(what, a, lanes, s) : launch_one<M_DOP853, R, false>(what, a, lanes, s);
     case M_RK4:
         return full ? launch_one<M_RK4, R, true>(what, a, lanes, s) : launch_one<M_RK4, R, false>(what, a, lanes, s);
+    case M_BDF:
+        return full ? launch_one<M_BDF, R, true>(what, a, lanes, s) : launch_one<M_BDF, R, false>(what, a, lanes, s);
     }
     return hipErrorInvalidValue;
 }
@@ -79,6 +82,9 @@ hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const Iv
     case 5: return launch_rhs<IVP_NS::RhsZero>(what, method, full, a, lanes, s);
     case 6: return launch_rhs<IVP_NS::RhsRational>(what, method, full, a, lanes, s);
     case 7: return launch_rhs<IVP_NS::RhsExp2>(what, method, full, a, lanes, s);
+    case 8: return launch_rhs<IVP_NS::RhsLinear>(what, method, full, a, lanes, s);
+    case 9: return launch_rhs<IVP_NS::RhsRobertson>(what, method, full, a, lanes, s);
+    case 10: return launch_rhs<IVP_NS::RhsVdpEps>(what, method, full, a, lanes, s);
     }
     return hipErrorInvalidValue;
 }

@@ -43,6 +43,21 @@ def vdp_batch(B: int, seed: int = 20260103):
     return y0, np.ones((1, B)), 0.0, t1
 
 
+def vdp_stiff_batch(B: int, seed: int = 20260105):
+    """C5: B stiff Van der Pol oscillators (mu ~ 1000), t in [0, 3000] (benches/benchmark.py:118-126), for BDF.
+
+    Returns (y0[2,B], params[1,B], t0, t1).  Trajectory 0 is the benchmark's own problem (y0 = [2, 0], mu = 1000).
+    """
+    rng = np.random.default_rng(seed)
+    y0 = np.zeros((2, B))
+    y0[0] = 2.0 * (1.0 + 0.05 * rng.standard_normal(B))
+    y0[1] = 0.05 * rng.standard_normal(B)
+    mu = 1000.0 * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, B))
+    y0[:, 0] = [2.0, 0.0]
+    mu[0] = 1000.0
+    return y0, mu.reshape(1, B).copy(), 0.0, 3000.0
+
+
 def shard_permutation(B: int, seed: int = 20260104) -> np.ndarray:
     """C4: fixed permutation applied before contiguous sharding (equalises step-count skew)."""
     return np.random.default_rng(seed).permutation(B)

@@ -1584,7 +1584,7 @@ int64_t orc_batch_solve(int rhs_id, size_t B, const double *y0, const double *pa
                         const orc_options *opt, int threads,
                         double *y_end, double *t_end, int32_t *status,
                         uint64_t *nfev, uint64_t *nstep, uint64_t *naccpt, uint64_t *nrejct,
-                        double *h_next, double *y_eval, int32_t *n_filled)
+                        double *h_next, double *y_eval, int32_t *n_filled, uint64_t *njev, uint64_t *nlu)
 {
     int n = 0, np = 0;
     orc_ode_fn f = orc_builtin_rhs(rhs_id, &n, &np);
@@ -1619,6 +1619,8 @@ int64_t orc_batch_solve(int rhs_id, size_t B, const double *y0, const double *pa
         if (naccpt) naccpt[b] = s.naccpt;
         if (nrejct) nrejct[b] = s.nrejct;
         if (h_next) h_next[b] = s.h_next;
+        if (njev) njev[b] = s.njev;
+        if (nlu) nlu[b] = s.nlu;
         if (y_eval && opt->n_eval > 0) {
             size_t m = s.len < (size_t)opt->n_eval ? s.len : (size_t)opt->n_eval;
             for (size_t k = 0; k < m; k++)

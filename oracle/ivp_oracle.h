@@ -149,7 +149,7 @@ int64_t orc_batch_solve(int rhs_id, size_t B, const double *y0, const double *pa
                         const orc_options *opt, int threads,
                         double *y_end, double *t_end, int32_t *status,
                         uint64_t *nfev, uint64_t *nstep, uint64_t *naccpt, uint64_t *nrejct,
-                        double *h_next, double *y_eval, int32_t *n_filled);
+                        double *h_next, double *y_eval, int32_t *n_filled, uint64_t *njev, uint64_t *nlu);
 
 /* Step-controller power function. Default build: libm pow (what Rust's f64::powf calls on
  * Linux). Built with -DORC_DETPOW the oracle uses orc_detpow instead: a portable, branch-light

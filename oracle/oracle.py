@@ -92,7 +92,7 @@ def lib(detpow: bool = False):
             C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
             C.POINTER(_Options), C.c_int,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-            C.c_void_p, C.c_void_p, C.c_void_p]
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.orc_uses_detpow() == int(detpow)
         _libs[key] = L
     return _libs[key]
@@ -246,7 +246,7 @@ def solve_batch(rhs: str, y0: np.ndarray, params: Optional[np.ndarray], t0, t1, 
         "y_end": np.zeros((n, B)), "t_end": np.zeros(B), "status": np.zeros(B, dtype=np.int32),
         "nfev": np.zeros(B, dtype=np.uint64), "nstep": np.zeros(B, dtype=np.uint64),
         "naccpt": np.zeros(B, dtype=np.uint64), "nrejct": np.zeros(B, dtype=np.uint64),
-        "h_next": np.zeros(B),
+        "h_next": np.zeros(B), "njev": np.zeros(B, dtype=np.uint64), "nlu": np.zeros(B, dtype=np.uint64),
     }
     y_eval = n_filled = None
     if oh.t_eval is not None and oh.t_eval.size:
@@ -258,7 +258,7 @@ def solve_batch(rhs: str, y0: np.ndarray, params: Optional[np.ndarray], t0, t1, 
                               C.byref(oh.c), int(threads),
                               vp(res["y_end"]), vp(res["t_end"]), vp(res["status"]), vp(res["nfev"]),
                               vp(res["nstep"]), vp(res["naccpt"]), vp(res["nrejct"]), vp(res["h_next"]),
-                              vp(y_eval), vp(n_filled))
+                              vp(y_eval), vp(n_filled), vp(res["njev"]), vp(res["nlu"]))
     if total < 0:
         raise ValueError(f"oracle config error {total}")
     res["total_accepted"] = int(total)

@@ -150,4 +150,37 @@ CASES.append(("rk4-sho-maxsteps", "sho", sho("RK4", 0.0, 3.0, max_steps=30)))
 CASES.append(("rk4-mixed-intervals", "sho", mixed_intervals("RK4")))
 CASES.append(("rk4-zero-teval", "zero", zero_rhs("RK4")))
 
+# BDF 1..5 (bdf.rs): the "next" row, incl. BASELINE C5's stiff Van der Pol (mu = 1000)
+def bdf_vdp_stiff(B=24):
+    def b():
+        rng = np.random.default_rng(8)
+        y0 = _rep([2.0, 0.0], B) * (1.0 + 0.05 * rng.standard_normal((2, B)))
+        y0[:, 0] = [2.0, 0.0]
+        p = np.full((1, B), 1000.0) * (1.0 + 0.1 * rng.uniform(-1, 1, (1, B)))
+        p[0, 0] = 1000.0
+        return y0, p, 0.0, 3000.0, dict(method="BDF", rtol=1e-4, atol=1e-6)   # benches/benchmark.py:118-126
+    return b
+
+
+def bdf_robertson():
+    B = 6
+    y0 = _rep([1e4, 0.0, 0.0], B)
+    y0[0] *= 1.0 + 0.01 * np.arange(B)
+    return y0, None, 0.0, 1e8, dict(method="BDF", rtol=1e-6, atol=1e-6)
+
+
+CASES.append(("bdf-C5-vdp-mu1000", "vdp", bdf_vdp_stiff()))
+CASES.append(("bdf-robertson", "robertson", bdf_robertson))
+CASES.append(("bdf-vdp-eps", "vdp_eps", lambda: (_rep([2.0, 0.0], 5), np.array([[1e-3, 2e-3, 5e-3, 1e-2, 1e-1]]), 0.0, 2.0,
+                                                dict(method="BDF", rtol=1e-6, atol=1e-8))))
+CASES.append(("bdf-linear", "linear", lambda: (_rep([0.0, 2.0], 3), None, 0.0, 2.0, dict(method="BDF", rtol=1e-3, atol=1e-6))))
+CASES.append(("bdf-sho-fwd", "sho", sho("BDF", B=20)))
+CASES.append(("bdf-sho-bwd", "sho", sho("BDF", 2 * np.pi, 0.0, B=20, rtol=1e-6, atol=1e-9)))
+CASES.append(("bdf-sho-maxstep-minstep", "sho", sho("BDF", 0.0, 3.0, B=20, rtol=1e-6, atol=1e-9, max_step=0.05, min_step=1e-4)))
+CASES.append(("bdf-rational-firststep", "rational", lambda: (*rational("BDF", 9.0)()[:4], dict(method="BDF", rtol=1e-3, atol=1e-6, max_step=0.5, first_step=0.1))))
+CASES.append(("bdf-sho-maxsteps", "sho", sho("BDF", 0.0, 30.0, B=20, max_steps=40)))
+CASES.append(("bdf-mixed-intervals", "sho", mixed_intervals("BDF")))
+CASES.append(("bdf-cr3bp-short", "cr3bp", lambda: (*W.cr3bp_batch(16)[:3], 2.0, dict(method="BDF", rtol=1e-6, atol=1e-9))))
+CASES.append(("bdf-zero-rhs", "zero", lambda: (np.ones((3, 2)), None, 0.0, 10.0, dict(method="BDF", rtol=1e-6, atol=1e-9, max_steps=5000))))
+
 CASE_IDS = [c[0] for c in CASES]

@@ -8,7 +8,7 @@ import numpy as np
 
 from oracle import oracle as O
 
-KEYS_INT = ("status", "nfev", "nstep", "naccpt", "nrejct")
+KEYS_INT = ("status", "nfev", "nstep", "naccpt", "nrejct", "njev", "nlu")
 
 
 def oracle_batch(rhs, y0, params, t0, t1, detpow=True, **opts):
@@ -35,7 +35,7 @@ def gpu_batch(rhs, y0, params, t0, t1, *, fast=False, chunk=0, device_arrays=Fal
     r = ivp_amd.solve_ivp_batch(f, t0, t1, y0, params if f.n_params else None, o)
     out = {}
     for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct", "y_eval", "eval_idx",
-              "n_filled", "t_log", "y_log", "n_log", "seg_cont", "seg_xold", "seg_h", "n_seg"):
+              "n_filled", "t_log", "y_log", "n_log", "seg_cont", "seg_xold", "seg_h", "n_seg", "njev", "nlu"):
         v = getattr(r, k)
         if v is None:
             continue
@@ -53,5 +53,7 @@ def assert_bitexact(got, ref, what=""):
         same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), f"{what}{k}: {np.count_nonzero(~same)} of {same.size} values differ; max |d| = {np.nanmax(np.abs(a - b))}"
     for k in KEYS_INT:
+        if k not in got or k not in ref:
+            continue
         a, b = np.asarray(got[k]).astype(np.int64), np.asarray(ref[k]).astype(np.int64)
         assert np.array_equal(a, b), f"{what}{k}: {np.count_nonzero(a != b)} of {a.size} differ"

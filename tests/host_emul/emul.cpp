@@ -13,6 +13,7 @@
 #define IVP_HD inline
 #define IVP_NS ivp_emul
 #include "../../ivp_amd/csrc/rk_core.h"
+#include "../../ivp_amd/csrc/bdf_core.h"
 
 using namespace ivp_emul;
 
@@ -21,9 +22,9 @@ static void run_all(IvpKArgs a, uint64_t *chunks_out)
 {
     uint64_t chunks = 0;
     for (uint32_t j = 0; j < a.B; ++j) {
-        int32_t st = init_body<M, R, FULL>(a, j);
+        int32_t st = any_init_body<M, R, FULL>(a, j);
         while (st == IVP_RUNNING) {
-            chunk_body<M, R, FULL>(a, j, st);
+            any_chunk_body<M, R, FULL>(a, j, st);
             ++chunks;
         }
     }
@@ -38,6 +39,7 @@ static int run_rhs(int method, bool full, const IvpKArgs &a, uint64_t *chunks)
     case 1: full ? run_all<1, R, true>(a, chunks) : run_all<1, R, false>(a, chunks); return 0;
     case 2: full ? run_all<2, R, true>(a, chunks) : run_all<2, R, false>(a, chunks); return 0;
     case 3: full ? run_all<3, R, true>(a, chunks) : run_all<3, R, false>(a, chunks); return 0;
+    case 5: full ? run_all<5, R, true>(a, chunks) : run_all<5, R, false>(a, chunks); return 0;
     }
     return -1;
 }
@@ -54,6 +56,9 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
     std::vector<int32_t> next_idx(B);
     uint32_t err_flag = 0;
     a.err_flag = &err_flag;
+    std::vector<double> bdf_d(8 * 8 * B), bdf_jac(64 * B), bdf_lu(64 * B);
+    std::vector<uint32_t> bdf_piv(B);
+    a.bdf_d = bdf_d.data(); a.bdf_jac = bdf_jac.data(); a.bdf_lu = bdf_lu.data(); a.bdf_piv = bdf_piv.data();
     a.k1 = k1.data(); a.facold = facold.data(); a.hlamb = hlamb.data(); a.flags = flags.data();
     a.t_last = t_last.data(); a.next_idx = next_idx.data();
     int rc = -1;
@@ -66,6 +71,9 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
     case 5: rc = run_rhs<RhsZero>(method, full, a, chunks); break;
     case 6: rc = run_rhs<RhsRational>(method, full, a, chunks); break;
     case 7: rc = run_rhs<RhsExp2>(method, full, a, chunks); break;
+    case 8: rc = run_rhs<RhsLinear>(method, full, a, chunks); break;
+    case 9: rc = run_rhs<RhsRobertson>(method, full, a, chunks); break;
+    case 10: rc = run_rhs<RhsVdpEps>(method, full, a, chunks); break;
     }
     if (rc == 0 && (err_flag & 0x1u)) return -5;  // IVP_ERR_INVALID_STEP_SIZE
     return rc;

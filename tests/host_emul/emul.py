@@ -29,16 +29,20 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("t_log", VP), ("y_log", VP), ("n_log", VP), ("t_last", VP),
         ("collect_dense", C.c_int32),
         ("seg_cont", VP), ("seg_xold", VP), ("seg_h", VP), ("n_seg", VP),
+        ("min_step", C.c_double), ("has_min_step", C.c_int32),
+        ("bdf_d", VP), ("bdf_jac", VP), ("bdf_lu", VP), ("bdf_piv", VP), ("njev", VP), ("nlu", VP),
         ("err_flag", VP),
         ("slot_counter", VP),
     ]
 
 
 _libs = {}
-RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7}
-RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0)}
-METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3}
-NCOEF = {0: 4, 1: 5, 2: 8, 3: 4}
+RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
+       "linear": 8, "robertson": 9, "vdp_eps": 10}
+RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0),
+            8: (2, 0), 9: (3, 0), 10: (2, 1)}
+METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3, "BDF": 5}
+NCOEF = {0: 4, 1: 5, 2: 8, 3: 4, 5: 7}
 
 
 def build():
@@ -60,7 +64,7 @@ def lib(fast=False):
 
 
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
-                first_step=None, max_step=None, dense_output=False, max_log=0, chunk=64, fast=False):
+                first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False):
     L = lib(fast)
     rid = RHS[rhs]
     n, npar = RHS_DIMS[rid]
@@ -85,13 +89,17 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     a.max_step = float(max_step or 0.0)
     a.has_max_step = int(max_step is not None)
     a.nmax = int(max_steps) if max_steps else 2 ** 64 - 1
+    a.min_step = float(min_step or 0.0)
+    a.has_min_step = int(min_step is not None)
     res = {
         "y_end": np.zeros((n, B)), "t_end": np.zeros(B), "h_next": np.zeros(B), "status": np.zeros(B, dtype=np.int32),
         "nfev": np.zeros(B, dtype=np.uint64), "nstep": np.zeros(B, dtype=np.uint64),
         "naccpt": np.zeros(B, dtype=np.uint64), "nrejct": np.zeros(B, dtype=np.uint64),
+        "njev": np.zeros(B, dtype=np.uint64), "nlu": np.zeros(B, dtype=np.uint64),
     }
     a.y, a.x, a.h, a.status = p(res["y_end"]), p(res["t_end"]), p(res["h_next"]), p(res["status"])
     a.nfev, a.nstep, a.naccpt, a.nrejct = p(res["nfev"]), p(res["nstep"]), p(res["naccpt"]), p(res["nrejct"])
+    a.njev, a.nlu = p(res["njev"]), p(res["nlu"])
     a.chunk = chunk
     a.n_eval = -1
     full = t_eval is not None or max_log > 0

@@ -29,6 +29,11 @@ if __name__ == "__main__":
                 r = run(f"C2 {fp.name} variant={variant}", ivp_amd.CR3BP(), y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp, variant=variant)
         ns = r.nstep.cpu().numpy()
         print("attempt percentiles", np.percentile(ns, [0, 50, 90, 99, 99.9, 99.99, 100]), "count>256", (ns > 256).sum(), ">384", (ns > 384).sum())
+    if "c5" in which:
+        y0, p, t0, t1 = W.vdp_stiff_batch(10_000)
+        for variant in (1, 2):
+            r = run(f"C5 BDF variant={variant}", ivp_amd.VanDerPol(1000.0), y0, p, t0, t1, reps=3, method="BDF", rtol=1e-4, atol=1e-6, variant=variant)
+        print("njev", int(r.njev.sum().item()), "nlu", int(r.nlu.sum().item()), "nfev", int(r.nfev.sum().item()))
     if "c3" in which:
         y0, p, t0, t1 = W.vdp_batch(1_000_000)
         for fp in (ivp_amd.FpMode.STRICT, ivp_amd.FpMode.FAST):

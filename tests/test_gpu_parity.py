@@ -70,7 +70,7 @@ def test_nan_and_inf_lanes_retire_without_poisoning_neighbours():
     assert (g["status"][good] == 0).all()
 
 
-@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853", "RK4", "BDF"])
 @pytest.mark.parametrize("direction", ["fwd", "bwd"])
 def test_t_eval_sampling_matches_oracle(method, direction):
     B = 130
@@ -92,7 +92,7 @@ def test_t_eval_sampling_matches_oracle(method, direction):
         assert np.array_equal(g["y_eval"][:m, :, b], s.y)
 
 
-@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853", "BDF"])
 @pytest.mark.parametrize("first_step", [None, 0.1])
 def test_step_log_and_dense_segments_match_oracle(method, first_step):
     B = 70
@@ -194,6 +194,22 @@ def test_c3_full_size_1m_vdp_dop853():
     r = oracle_batch("vdp", y0[:, idx], p[:, idx], t0, t1[idx], threads=8, **o)
     for k in ("y_end", "t_end", "h_next", "nfev", "nstep", "naccpt", "nrejct", "status"):
         assert np.array_equal(np.asarray(g[k])[..., idx].astype(r[k].dtype), r[k]), k
+
+
+def test_c5_full_size_10k_stiff_vdp_bdf():
+    """BASELINE config C5: 10k stiff Van der Pol (mu ~ 1000), BDF order 1-5, per-trajectory LU in registers."""
+    B = 10_000
+    y0, p, t0, t1 = W.vdp_stiff_batch(B)
+    o = dict(method="BDF", rtol=1e-4, atol=1e-6)
+    g = gpu_batch("vdp", y0, p, t0, t1, device_arrays=True, **o)
+    assert (g["status"] == 0).all() and (g["t_end"] == t1).all()
+    assert (g["njev"] > 0).all() and (g["nlu"] > 0).all() and (g["nstep"] == g["naccpt"] + g["nrejct"]).all()
+    truth = json.load(open(os.path.join(GOLD, "scipy_stiff_truth.json")))["truth"]["vdp_mu1000_t3000"]
+    assert np.abs(g["y_end"][:, 0] - truth).max() < 1e-2         # SciPy Radau @1e-10
+    idx = np.concatenate(([0], np.random.default_rng(2).choice(B, 95, replace=False)))
+    r = oracle_batch("vdp", y0[:, idx], p[:, idx], t0, t1, threads=8, **o)
+    sub = {k: np.asarray(v)[..., idx] for k, v in g.items() if k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct", "njev", "nlu")}
+    assert_bitexact(sub, r)
 
 
 # ---- user-defined right-hand side (hiprtc): the device-side `impl IVP` -----------------------------------

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 import ivp_amd
-from ivp_amd import SHO, ExponentialDecay, Exp2, Method, Options, Rational, Status, ZeroRhs, solve_ivp
+from ivp_amd import (SHO, ExponentialDecay, Exp2, LinearSystem, Method, Options, Rational, Robertson, Status,
+                     StiffVanDerPol, VanDerPol, ZeroRhs, solve_ivp)
 
 pytestmark = pytest.mark.gpu
 EXPLICIT = [Method.RK23, Method.DOPRI5, Method.DOP853]
@@ -198,9 +199,58 @@ def test_rk4_invalid_step_size_is_a_config_error():  # rk4.rs:81-87
     assert sol.nstep == 100 and sol.nfev == 400 and sol.naccpt == 0 and len(sol.t) == 101
 
 
+# ---- BDF (src/methods/bdf.rs): the reference's tests that include Method::BDF ----------------------------------
+
+def sol_linear(t):
+    return np.vstack((-5 * np.sin(2 * t), 2 * np.cos(2 * t) + np.sin(2 * t)))
+
+
+def test_bdf_harmonic_accuracy_backward_t_eval_max_step():  # accuracy.rs:18-77, backward_and_bounds.rs:7-32, ivp.rs:49-76
+    sol = solve_ivp(SHO(), 0.0, 2 * np.pi, [1.0, 0.0], default_opts(Method.BDF))
+    assert abs(sol.y[-1][0] - 1.0) < 1e-5 and abs(sol.y[-1][1]) < 1e-5 and sol.njev > 0 and sol.nlu > 0
+    sol = solve_ivp(SHO(), 2 * np.pi, 0.0, [1.0, 0.0], default_opts(Method.BDF, dense_output=True))
+    t0, t1 = sol.sol_span()
+    mid = 0.5 * (t0 + t1)
+    assert t0 > t1 and abs(sol.sol(mid)[0] - np.cos(mid)) < 1e-6
+    te = [i / 10.0 for i in range(11)]
+    sol = solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method=Method.BDF, rtol=1e-9, atol=1e-9, t_eval=te))
+    assert all(np.any(np.abs(sol.t - t) <= 1e-9) for t in te)
+    sol = solve_ivp(SHO(), 0.0, 3.0, [1.0, 0.0], Options(method=Method.BDF, rtol=1e-6, atol=1e-9, max_step=0.05))
+    assert np.abs(np.diff(sol.t)).max() <= 0.05 + 1e-12
+
+
+@pytest.mark.parametrize("t_span", [(5.0, 9.0), (5.0, 1.0)])
+def test_bdf_integration_rational(t_span):  # tests/test_ivp.py:173-241, tests/test_basic_integration.py:89-104
+    res = solve_ivp(Rational(), t_span[0], t_span[1], [1 / 3, 2 / 9], Options(method="BDF", rtol=1e-3, atol=1e-6, dense_output=True))
+    assert res.t[0] == t_span[0] and res.status == Status.Success and 0 < res.njev and 0 < res.nlu
+    assert np.all(compute_error(res.y.T, sol_rational(res.t), 1e-3, 1e-6) < 5)
+    ys = np.array([res.continuous_sol.evaluate_extrapolate(t) for t in res.t])
+    np.testing.assert_allclose(ys, res.y, rtol=1e-15, atol=1e-15)
+
+
+def test_bdf_const_jac_linear_and_robertson():  # tests/test_ivp.py:273-342, tests/test_stiff.py:35-53
+    res = solve_ivp(LinearSystem(), 0.0, 2.0, [0.0, 2.0], Options(method="BDF", rtol=1e-3, atol=1e-6, dense_output=True))
+    assert res.status == Status.Success and res.nfev < 100
+    assert np.all(compute_error(res.y.T, sol_linear(res.t), 1e-3, 1e-6) < 10)
+    tc = np.linspace(0.0, 2.0)
+    yc = np.array([res.continuous_sol.evaluate_extrapolate(t) for t in tc]).T
+    assert np.all(compute_error(yc, sol_linear(tc), 1e-3, 1e-6) < 60)
+    res = solve_ivp(Robertson(), 0.0, 1e8, [1e4, 0.0, 0.0], Options(method="BDF", rtol=1e-6, atol=1e-6))
+    assert res.status == Status.Success and res.nfev < 5000 and res.njev < 200
+
+
+def test_bdf_examples_van_der_pol():  # examples/van_der_pol.rs:16-41 and benches/benchmark.py:118-126
+    te = [i * 0.1 for i in range(21)]
+    sol = solve_ivp(StiffVanDerPol(1e-3), 0.0, 2.0, [2.0, 0.0], Options(method=Method.BDF, rtol=1e-6, atol=1e-8, t_eval=te))
+    assert sol.status == Status.Success and np.array_equal(sol.t, te)
+    assert np.abs(sol.y[-1] - [1.7632345402033993, -0.8356886816853318]).max() < 1e-4     # SciPy Radau @1e-10
+    sol = solve_ivp(VanDerPol(1000.0), 0.0, 3000.0, [2.0, 0.0], Options(method="BDF", rtol=1e-4, atol=1e-6))
+    assert sol.status == Status.Success and np.abs(sol.y[-1] - [-1.5106069367440045, 0.0011783800007311195]).max() < 1e-2
+
+
 def test_unsupported_methods_and_bad_tolerances_are_config_errors():
     with pytest.raises(ivp_amd.ConfigError) as e:
-        solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method="BDF"))
+        solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(method="RADAU"))
     assert e.value.code == -101
     with pytest.raises(ivp_amd.ConfigError) as e:      # Tolerance::Vector length mismatch (mod.rs:156-161)
         solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(rtol=[1e-3, 1e-3, 1e-3]))

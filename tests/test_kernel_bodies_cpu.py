@@ -69,7 +69,7 @@ def test_nan_and_inf_lanes_retire_without_poisoning_neighbours():
         assert np.array_equal(np.asarray(g[k])[..., good], r[k])
 
 
-@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853", "RK4", "BDF"])
 @pytest.mark.parametrize("direction", ["fwd", "bwd"])
 def test_t_eval_sampling_matches_oracle(method, direction):
     """DefaultSolOut mode 1 on the device (solout.rs:344-386): emitted samples, their order and values."""
@@ -92,7 +92,7 @@ def test_t_eval_sampling_matches_oracle(method, direction):
         assert np.array_equal(g["y_eval"][:m, :, b], s.y)
 
 
-@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853", "BDF"])
 @pytest.mark.parametrize("first_step", [None, 0.1])
 def test_step_log_and_dense_segments_match_oracle(method, first_step):
     """DefaultSolOut mode 2 (solout.rs:387-428, incl. first_step enforcement) and dense-segment collection
