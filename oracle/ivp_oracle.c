@@ -198,12 +198,48 @@ static void rhs_vdp_eps(double t, const double *y, double *d, const double *p)
     d[1] = ((1.0 - y[0] * y[0]) * y[1] - y[0]) / p[0];
 }
 
+static void rhs_ball(double t, const double *s, double *d, const double *p)
+{   /* examples/bouncing_ball.rs:10-15  p = {gravity, drag} */
+    (void)t;
+    double vy = s[1];
+    d[0] = vy;
+    d[1] = -p[0] - p[1] * vy * fabs(vy);
+}
+static void rhs_cannon(double t, const double *y, double *d, const double *p)
+{   /* tests/test_ivp.py:153-154 */
+    (void)t; (void)p;
+    d[0] = y[1];
+    d[1] = -9.80665;
+}
+/* event functions: trait IVP::events (src/ivp.rs:31-40) */
+static void ev_y0(double x, const double *y, double *g, const double *p)
+{   /* tests/ivp.rs:157-159, examples/bouncing_ball.rs:17-19, tests/test_ivp.py:156-157 */
+    (void)x; (void)p;
+    g[0] = y[0];
+}
+static void ev_rational3(double t, const double *y, double *g, const double *p)
+{   /* tests/test_ivp.py:346-353 */
+    (void)p;
+    g[0] = y[0] - pow(y[1], 0.7);
+    g[1] = pow(y[1], 0.6) - y[0];
+    g[2] = t - 7.4;
+}
+orc_event_fn orc_builtin_events(int rhs_id, int *n_events)
+{
+    switch (rhs_id) {
+    case ORC_RHS_SHO_EV: case ORC_RHS_BALL: case ORC_RHS_CANNON: *n_events = 1; return ev_y0;
+    case ORC_RHS_RATIONAL_EV: *n_events = 3; return ev_rational3;
+    default: *n_events = 0; return NULL;
+    }
+}
+
 orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *np_out)
 {
     static const struct { orc_ode_fn f; int n, np; } tab[ORC_RHS_COUNT] = {
         {rhs_decay, 1, 1}, {rhs_sho, 2, 0}, {rhs_vdp, 2, 1}, {rhs_cr3bp, 6, 1},
         {rhs_lorenz, 3, 3}, {rhs_zero, 3, 0}, {rhs_rational, 2, 0}, {rhs_exp2, 2, 0},
         {rhs_linear, 2, 0}, {rhs_robertson, 3, 0}, {rhs_vdp_eps, 2, 1},
+        {rhs_sho, 2, 0}, {rhs_ball, 2, 2}, {rhs_cannon, 2, 0}, {rhs_rational, 2, 0},
     };
     if (rhs_id < 0 || rhs_id >= ORC_RHS_COUNT) return NULL;
     if (n_out) *n_out = tab[rhs_id].n;
@@ -310,6 +346,19 @@ typedef struct {
     int has_first_step; double first_step;
     double x0;
     int first_output_done;
+    /* events (solout.rs:158-331) */
+    int n_events;
+    orc_event_fn ev;
+    const double *ev_params;
+    int ev_direction[ORC_MAX_EVENTS];       /* 0 All, >0 Positive, <0 Negative (event.rs:59-77) */
+    uint64_t ev_terminal[ORC_MAX_EVENTS];   /* terminal_count, 0 = None */
+    double prev_event[ORC_MAX_EVENTS];
+    uint64_t event_hits[ORC_MAX_EVENTS];
+    int has_yold;
+    double yold[64];
+    size_t ev_len[ORC_MAX_EVENTS], ev_cap[ORC_MAX_EVENTS];
+    double *t_events[ORC_MAX_EVENTS];
+    double *y_events[ORC_MAX_EVENTS];
 } solout_t;
 
 static void so_push(solout_t *s, double t, const double *y)
@@ -353,6 +402,98 @@ static int so_call2(solout_t *s, double xold, double x, const double *y,
             s->nseg++;
         }
     }
+
+    /* Event detection, solout.rs:158-331 */
+    if (s->n_events > 0) {
+        double g_curr[ORC_MAX_EVENTS];
+        s->ev(x, y, g_curr, s->ev_params);
+        if (!s->has_yold) {
+            memcpy(s->prev_event, g_curr, sizeof(double) * (size_t)s->n_events);
+        } else {
+            double det_t[ORC_MAX_EVENTS], det_y[ORC_MAX_EVENTS][64];
+            int det_i[ORC_MAX_EVENTS], ndet = 0;
+            for (int i = 0; i < s->n_events; i++) {
+                double g_prev = s->prev_event[i], g_cur = g_curr[i];
+                int dir = s->ev_direction[i], crossed;
+                if (dir == 0) crossed = (g_prev <= 0.0 && g_cur >= 0.0) || (g_prev >= 0.0 && g_cur <= 0.0);
+                else if (dir > 0) crossed = g_prev < 0.0 && g_cur >= 0.0;
+                else crossed = g_prev > 0.0 && g_cur <= 0.0;
+                if (!crossed) continue;
+                const double XTOL = 2e-12, RTOL = 2.220446049250313e-16;
+                double a = xold, b = x, fa = g_prev, fb = g_cur;
+                double ymid[64], gmid[ORC_MAX_EVENTS];
+                if (fabs(fa) <= XTOL) { det_t[ndet] = a; memcpy(det_y[ndet], s->yold, sizeof(double) * (size_t)n); }
+                else if (fabs(fb) <= XTOL) { det_t[ndet] = b; memcpy(det_y[ndet], y, sizeof(double) * (size_t)n); }
+                else {   /* Brent's method (matches SciPy's brentq), solout.rs:204-291 */
+                    double c = a, fc = fa, d = b - a, e = d;
+                    for (int it = 0; it < 100; it++) {
+                        if (fb * fc > 0.0) { c = a; fc = fa; d = b - a; e = d; }
+                        if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+                        double tol1 = 2.0 * RTOL * fabs(b) + 0.5 * XTOL;
+                        double xm = 0.5 * (c - b);
+                        if (fabs(xm) <= tol1 || fb == 0.0) break;
+                        if (fabs(e) >= tol1 && fabs(fa) > fabs(fb)) {
+                            double sq, pp, qq;
+                            if (a == c) {
+                                sq = fb / fa;
+                                pp = 2.0 * xm * sq;
+                                qq = 1.0 - sq;
+                            } else {
+                                double q_val = fa / fc, r = fb / fc;
+                                sq = fb / fa;
+                                pp = sq * (2.0 * xm * q_val * (q_val - r) - (b - a) * (r - 1.0));
+                                qq = (q_val - 1.0) * (r - 1.0) * (sq - 1.0);
+                            }
+                            if (qq > 0.0) pp = -pp; else qq = -qq;
+                            if (2.0 * pp < fmin(3.0 * xm * qq - fabs(tol1 * qq), fabs(e * qq))) { e = d; d = pp / qq; }
+                            else { d = xm; e = d; }
+                        } else { d = xm; e = d; }
+                        a = b; fa = fb;
+                        if (fabs(d) > tol1) b += d;
+                        else b += xm > 0.0 ? tol1 : -tol1;
+                        interp_any(s->method, b, ymid, cont, n, ixold, h);
+                        s->ev(b, ymid, gmid, s->ev_params);
+                        fb = gmid[i];
+                    }
+                    interp_any(s->method, b, ymid, cont, n, ixold, h);
+                    det_t[ndet] = b;
+                    memcpy(det_y[ndet], ymid, sizeof(double) * (size_t)n);
+                }
+                det_i[ndet] = i;
+                ndet++;
+            }
+            /* stable sort by time: ascending when integrating forward, descending backward (solout.rs:297-303) */
+            int forward = x > xold;
+            for (int u = 1; u < ndet; u++)
+                for (int v = u; v > 0; v--) {
+                    int swap = forward ? (det_t[v] < det_t[v - 1]) : (det_t[v] > det_t[v - 1]);
+                    if (!swap) break;
+                    double tt = det_t[v]; det_t[v] = det_t[v - 1]; det_t[v - 1] = tt;
+                    int ti = det_i[v]; det_i[v] = det_i[v - 1]; det_i[v - 1] = ti;
+                    double ty[64]; memcpy(ty, det_y[v], sizeof ty); memcpy(det_y[v], det_y[v - 1], sizeof ty); memcpy(det_y[v - 1], ty, sizeof ty);
+                }
+            for (int u = 0; u < ndet; u++) {
+                int i = det_i[u];
+                if (s->ev_len[i] == s->ev_cap[i]) {
+                    s->ev_cap[i] = s->ev_cap[i] ? 2 * s->ev_cap[i] : 8;
+                    s->t_events[i] = (double *)realloc(s->t_events[i], s->ev_cap[i] * sizeof(double));
+                    s->y_events[i] = (double *)realloc(s->y_events[i], s->ev_cap[i] * (size_t)n * sizeof(double));
+                }
+                s->t_events[i][s->ev_len[i]] = det_t[u];
+                memcpy(s->y_events[i] + s->ev_len[i] * (size_t)n, det_y[u], sizeof(double) * (size_t)n);
+                s->ev_len[i]++;
+                s->event_hits[i]++;
+                if (s->ev_terminal[i] && s->event_hits[i] >= s->ev_terminal[i]) {
+                    so_push(s, det_t[u], det_y[u]);
+                    memcpy(s->prev_event, g_curr, sizeof(double) * (size_t)s->n_events);
+                    return 1;   /* ControlFlag::Interrupt */
+                }
+            }
+            memcpy(s->prev_event, g_curr, sizeof(double) * (size_t)s->n_events);
+        }
+    }
+    memcpy(s->yold, y, sizeof(double) * (size_t)n);
+    s->has_yold = 1;
 
     double yi[64];
     if (s->n_eval >= 0) {
@@ -590,7 +731,7 @@ static int dopri5_solve(orc_ode_fn f, const double *p, int n, double x0, const d
             xold = x;
             x = xph;
 
-            so_call(so, xold, x, y, cont, h);
+            if (so_call(so, xold, x, y, cont, h)) { status = ORC_USER_INTERRUPT; break; }   /* dopri5.rs:418-421 */
 
             if (last) { h = hnew; status = ORC_SUCCESS; break; }
             if (fabs(hnew) > fabs(h_max)) hnew = posneg * fabs(h_max);
@@ -868,7 +1009,7 @@ static int dop853_solve(orc_ode_fn f, const double *p, int n, double x0, const d
             xold = x;
             x = xph;
 
-            so_call(so, xold, x, y, cont, h);
+            if (so_call(so, xold, x, y, cont, h)) { status = ORC_USER_INTERRUPT; break; }   /* dop853.rs:609-612 */
 
             if (last) { h = hnew; status = ORC_SUCCESS; break; }
             if (fabs(hnew) > fabs(h_max)) hnew = posneg * fabs(h_max);
@@ -968,7 +1109,7 @@ static int rk23_solve(orc_ode_fn f, const double *p, int n, double x0, const dou
                 cont[2 * n + i] = D21 * k1[i] + D22 * k2[i] + D23 * k3[i] + D24 * k4[i];
                 cont[3 * n + i] = D31 * k1[i] + D32 * k2[i] + D33 * k3[i] + D34 * k4[i];
             }
-            so_call(so, xold, x, y, cont, h);
+            if (so_call(so, xold, x, y, cont, h)) { status = ORC_USER_INTERRUPT; break; }   /* rk23.rs:266-269 */
             memcpy(k1, k4, (size_t)n * sizeof(double)); /* ControlFlag::Continue arm, rk23.rs:281-284 */
 
             h *= fmax(fmin(safety * ORC_POW(err, error_exponent), scale_max), scale_min);
@@ -1037,7 +1178,7 @@ static int rk4_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
         memcpy(cont, yt, (size_t)n * sizeof(double));
         for (int i = 0; i < n; i++) { cont[n + i] = k4[i]; cont[2 * n + i] = k1[i]; }
         memcpy(cont + 3 * n, y, (size_t)n * sizeof(double));
-        so_call(so, xold, x, y, cont, h);
+        if (so_call(so, xold, x, y, cont, h)) { status = ORC_USER_INTERRUPT; break; }   /* rk4.rs:201-204 */
         if (last) break;
     }
     res->h = h; res->status = status;
@@ -1364,7 +1505,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
             b[6] = (double)order;
         }
         /* bdf.rs:518-519: interpolant anchored at x_start, callback xold = x - h_signed */
-        so_call2(so, x - h_signed, x, y, cont, x_start, h_signed);
+        if (so_call2(so, x - h_signed, x, y, cont, x_start, h_signed)) { status = ORC_USER_INTERRUPT; break; }   /* bdf.rs:521-524 */
         if (direction * (x - xend) >= 0.0) { status = ORC_SUCCESS; break; }
 
         if (n_equal_steps >= order + 1) {
@@ -1487,6 +1628,10 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     so.collect_dense = opt->dense_output;
     so.has_first_step = opt->has_first_step; so.first_step = opt->first_step;
     so.x0 = x0;
+    so.n_events = opt->events ? opt->n_events : 0;
+    so.ev = opt->events;
+    so.ev_params = params;
+    for (int i = 0; i < ORC_MAX_EVENTS; i++) { so.ev_direction[i] = opt->ev_direction[i]; so.ev_terminal[i] = opt->ev_terminal[i]; }
 
     int_result r;
     double yf[64], xf = x0;
@@ -1505,8 +1650,11 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     else rc = rk23_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
     if (rc != ORC_OK) {
         free(so.t); free(so.y); free(so.seg_cont); free(so.seg_xold); free(so.seg_h);
+        for (int i = 0; i < ORC_MAX_EVENTS; i++) { free(so.t_events[i]); free(so.y_events[i]); }
         return rc;
     }
+    sol->n_events = so.n_events;
+    for (int i = 0; i < ORC_MAX_EVENTS; i++) { sol->ev_len[i] = so.ev_len[i]; sol->t_events[i] = so.t_events[i]; sol->y_events[i] = so.y_events[i]; }
     sol->len = so.len; sol->t = so.t; sol->y = so.y;
     sol->nfev = r.nfev;
     sol->nstep = r.nstep; sol->naccpt = r.naccpt; sol->nrejct = r.nrejct;
@@ -1532,6 +1680,7 @@ int orc_solve_ivp(orc_ode_fn f, const double *params, int n, double x0, double x
 void orc_solution_free(orc_solution *sol)
 {
     free(sol->t); free(sol->y); free(sol->seg_cont); free(sol->seg_xold); free(sol->seg_h);
+    for (int i = 0; i < ORC_MAX_EVENTS; i++) { free(sol->t_events[i]); free(sol->y_events[i]); }
     memset(sol, 0, sizeof(*sol));
 }
 

@@ -66,10 +66,16 @@ enum {
     ORC_RHS_LINEAR = 8,   /* tests/test_helpers.py:11-12                         n=2 */
     ORC_RHS_ROBERTSON = 9,/* tests/test_ivp.py:327-333                           n=3 */
     ORC_RHS_VDP_EPS = 10, /* examples/van_der_pol.rs:9-14         p={eps}        n=2 */
-    ORC_RHS_COUNT = 11
+    ORC_RHS_SHO_EV = 11,  /* tests/ivp.rs:151-221: SHO + event g = y0           n=2 */
+    ORC_RHS_BALL = 12,    /* examples/bouncing_ball.rs            p={g,drag}     n=2, event g = y0 */
+    ORC_RHS_CANNON = 13,  /* tests/test_ivp.py:152-170                           n=2, event g = y0 */
+    ORC_RHS_RATIONAL_EV = 14, /* tests/test_ivp.py:345-353: rational + 3 events  n=2 */
+    ORC_RHS_COUNT = 15
 };
 
 typedef void (*orc_ode_fn)(double x, const double *y, double *dydx, const double *p);
+typedef void (*orc_event_fn)(double x, const double *y, double *g, const double *p);   /* IVP::events, src/ivp.rs:31-40 */
+#define ORC_MAX_EVENTS 4
 
 typedef struct {
     int method;           /* ORC_RK23 / ORC_DOPRI5 / ORC_DOP853 */
@@ -88,6 +94,11 @@ typedef struct {
     int dense_output;     /* Options.dense_output: collect per-step interpolants */
     int has_min_step;     /* Options.min_step (BDF only) */
     double min_step;
+    /* events (trait IVP::events / n_events / event_config, src/ivp.rs:31-52, src/solve/event.rs) */
+    orc_event_fn events;  /* NULL = none */
+    int n_events;
+    int ev_direction[ORC_MAX_EVENTS];      /* 0 All, >0 Positive, <0 Negative */
+    uint64_t ev_terminal[ORC_MAX_EVENTS];  /* EventConfig.terminal_count, 0 = None */
     /* Oracle-only guard (not in the reference): stop after this many step attempts
      * with ORC_NEED_LARGER_NMAX.  0 => no guard.  Needed because RK23 in the reference
      * never terminates when the error estimate is NaN (rk23.rs:300-306 leaves h unchanged). */
@@ -110,6 +121,11 @@ typedef struct {
     double *seg_cont;  /* [nseg][ncoef*n] */
     double *seg_xold;  /* [nseg] */
     double *seg_h;     /* [nseg] */
+    /* Solution.t_events / y_events */
+    int n_events;
+    size_t ev_len[ORC_MAX_EVENTS];
+    double *t_events[ORC_MAX_EVENTS];   /* [ev_len[i]] */
+    double *y_events[ORC_MAX_EVENTS];   /* [ev_len[i]][n] */
 } orc_solution;
 
 /* Error codes for whole-call validation failures (Error::Config, src/error.rs:18-60). */
@@ -125,6 +141,7 @@ enum {
 };
 
 orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *n_params_out);
+orc_event_fn orc_builtin_events(int rhs_id, int *n_events);
 
 /* solve_ivp (src/solve/solve_ivp.rs:99-313) for one trajectory. Returns ORC_OK or a negative error. */
 int orc_solve_ivp(orc_ode_fn f, const double *params, int n, double x0, double xend,

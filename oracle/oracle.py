@@ -17,9 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3, "BDF": 5}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
-       "linear": 8, "robertson": 9, "vdp_eps": 10}
+       "linear": 8, "robertson": 9, "vdp_eps": 10, "sho_ev": 11, "ball": 12, "cannon": 13, "rational_ev": 14}
 RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0),
-            8: (2, 0), 9: (3, 0), 10: (2, 1)}
+            8: (2, 0), 9: (3, 0), 10: (2, 1), 11: (2, 0), 12: (2, 2), 13: (2, 0), 14: (2, 0)}
 STATUS = ["Success", "UserInterrupt", "NeedLargerNMax", "StepSizeTooSmall", "ProbablyStiff",
           "SingularMatrix", "PoorConvergence"]
 
@@ -35,6 +35,7 @@ class _Options(C.Structure):
         ("has_max_step", C.c_int), ("max_step", C.c_double),
         ("dense_output", C.c_int),
         ("has_min_step", C.c_int), ("min_step", C.c_double),
+        ("events", C.c_void_p), ("n_events", C.c_int), ("ev_direction", C.c_int * 4), ("ev_terminal", C.c_uint64 * 4),
         ("attempt_guard", C.c_uint64),
     ]
 
@@ -48,6 +49,8 @@ class _Solution(C.Structure):
         ("has_dense", C.c_int), ("ncoef", C.c_int), ("n", C.c_int),
         ("nseg", C.c_size_t), ("seg_cont", C.POINTER(C.c_double)),
         ("seg_xold", C.POINTER(C.c_double)), ("seg_h", C.POINTER(C.c_double)),
+        ("n_events", C.c_int), ("ev_len", C.c_size_t * 4),
+        ("t_events", C.POINTER(C.c_double) * 4), ("y_events", C.POINTER(C.c_double) * 4),
     ]
 
 
@@ -76,6 +79,8 @@ def lib(detpow: bool = False):
         L = C.CDLL(path)
         L.orc_builtin_rhs.restype = C.c_void_p
         L.orc_builtin_rhs.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_builtin_events.restype = C.c_void_p
+        L.orc_builtin_events.argtypes = [C.c_int, C.POINTER(C.c_int)]
         L.orc_solve_ivp.restype = C.c_int
         L.orc_solve_ivp.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double,
                                     C.POINTER(C.c_double), C.POINTER(_Options), C.POINTER(_Solution)]
@@ -106,7 +111,8 @@ class _OptHolder:
     """Builds the C options struct and keeps the numpy buffers it points at alive."""
 
     def __init__(self, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
-                 first_step=None, max_step=None, min_step=None, dense_output=False, attempt_guard=0):
+                 first_step=None, max_step=None, min_step=None, dense_output=False, attempt_guard=0,
+                 event_direction=None, event_terminal=None):
         m = METHODS[method.upper()] if isinstance(method, str) else int(method)
         self.rtol = np.atleast_1d(np.asarray(rtol, dtype=np.float64)).copy()
         self.atol = np.atleast_1d(np.asarray(atol, dtype=np.float64)).copy()
@@ -129,6 +135,12 @@ class _OptHolder:
         o.has_min_step = int(min_step is not None)
         o.min_step = float(min_step or 0.0)
         o.attempt_guard = int(attempt_guard)
+        self.event_direction = list(event_direction or [])
+        self.event_terminal = list(event_terminal or [])
+        for i, d in enumerate(self.event_direction[:4]):
+            o.ev_direction[i] = int(d)
+        for i, t in enumerate(self.event_terminal[:4]):
+            o.ev_terminal[i] = int(t or 0)
         self.c = o
         self.method = m
 
@@ -151,6 +163,8 @@ class OracleSolution:
     seg_xold: Optional[np.ndarray] = None
     seg_h: Optional[np.ndarray] = None
     seg_cont: Optional[np.ndarray] = None
+    t_events: Optional[list] = None
+    y_events: Optional[list] = None
 
     @property
     def status_name(self) -> str:
@@ -207,6 +221,11 @@ def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Seque
         keep = _ODE_FN(_tramp)
         fptr = C.cast(keep, C.c_void_p).value
     oh = _OptHolder(**options)
+    if isinstance(fun, str):
+        ne = C.c_int()
+        evp = L.orc_builtin_events(RHS[fun], C.byref(ne))
+        if evp:
+            oh.c.events, oh.c.n_events = evp, ne.value
     s = _Solution()
     rc = L.orc_solve_ivp(fptr, _dptr(pa), n, float(x0), float(xend), _dptr(y0a), C.byref(oh.c), C.byref(s))
     if rc != 0:
@@ -220,6 +239,11 @@ def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Seque
         out.seg_h = np.ctypeslib.as_array(s.seg_h, shape=(s.nseg,)).copy()
         if n:
             out.seg_cont = np.ctypeslib.as_array(s.seg_cont, shape=(s.nseg, s.ncoef * n)).copy()
+    out.t_events, out.y_events = [], []
+    for i in range(s.n_events):
+        m = s.ev_len[i]
+        out.t_events.append(np.ctypeslib.as_array(s.t_events[i], shape=(m,)).copy() if m else np.zeros(0))
+        out.y_events.append(np.ctypeslib.as_array(s.y_events[i], shape=(m, n)).copy() if m else np.zeros((0, n)))
     del keep
     return out
 
@@ -242,6 +266,10 @@ def solve_batch(rhs: str, y0: np.ndarray, params: Optional[np.ndarray], t0, t1, 
     t1 = np.atleast_1d(np.asarray(t1, dtype=np.float64)).copy()
     assert t0.size in (1, B) and t1.size in (1, B)
     oh = _OptHolder(**options)
+    ne = C.c_int()
+    evp = L.orc_builtin_events(rid, C.byref(ne))
+    if evp:
+        oh.c.events, oh.c.n_events = evp, ne.value
     res = {
         "y_end": np.zeros((n, B)), "t_end": np.zeros(B), "status": np.zeros(B, dtype=np.int32),
         "nfev": np.zeros(B, dtype=np.uint64), "nstep": np.zeros(B, dtype=np.uint64),

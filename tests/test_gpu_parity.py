@@ -202,11 +202,15 @@ def test_c5_full_size_10k_stiff_vdp_bdf():
     y0, p, t0, t1 = W.vdp_stiff_batch(B)
     o = dict(method="BDF", rtol=1e-4, atol=1e-6)
     g = gpu_batch("vdp", y0, p, t0, t1, device_arrays=True, **o)
-    assert (g["status"] == 0).all() and (g["t_end"] == t1).all()
+    # a handful of trajectories stop one rounding error short of t1 and trip the stagnation guard
+    # `x + 0.1|h| == x` (bdf.rs:325-328) with StepSizeTooSmall -- the reference does the same (the oracle comparison
+    # below includes trajectory-for-trajectory status equality)
+    assert np.isin(g["status"], (0, 3)).all() and np.mean(g["status"] != 0) < 0.01
+    assert np.abs(g["t_end"] - t1).max() < 1e-9
     assert (g["njev"] > 0).all() and (g["nlu"] > 0).all() and (g["nstep"] == g["naccpt"] + g["nrejct"]).all()
     truth = json.load(open(os.path.join(GOLD, "scipy_stiff_truth.json")))["truth"]["vdp_mu1000_t3000"]
     assert np.abs(g["y_end"][:, 0] - truth).max() < 1e-2         # SciPy Radau @1e-10
-    idx = np.concatenate(([0], np.random.default_rng(2).choice(B, 95, replace=False)))
+    idx = np.unique(np.concatenate(([0], np.nonzero(g["status"] != 0)[0], np.random.default_rng(2).choice(B, 95, replace=False))))
     r = oracle_batch("vdp", y0[:, idx], p[:, idx], t0, t1, threads=8, **o)
     sub = {k: np.asarray(v)[..., idx] for k, v in g.items() if k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct", "njev", "nlu")}
     assert_bitexact(sub, r)

@@ -282,3 +282,59 @@ def test_bdf_against_independent_stiff_truth():
     te = np.arange(21) * 0.1
     s = O.solve_ivp("vdp_eps", 0.0, 2.0, [2.0, 0.0], params=[1e-3], method="BDF", rtol=1e-6, atol=1e-8, t_eval=te)
     assert np.array_equal(s.t, te) and np.abs(s.y[-1] - tr["vdp_eps1e-3_t2"]).max() < 1e-4
+
+
+# ---- events ("next" row): src/solve/solout.rs:158-331 -----------------------------------
+
+def test_event_detection_all_and_directional():  # tests/ivp.rs:223-275
+    kw = dict(method="DOPRI5", rtol=1e-9, atol=1e-9)
+    s = O.solve_ivp("sho_ev", 0.0, 6.0, [1.0, 0.0], event_direction=[0], event_terminal=[2], **kw)
+    assert len(s.t_events[0]) >= 2 and np.abs(s.y_events[0][:, 0]).max() <= 1e-8
+    assert abs(s.t_events[0][0] - np.pi / 2) < 5e-3 and abs(s.t_events[0][-1] - 3 * np.pi / 2) < 5e-3
+    s = O.solve_ivp("sho_ev", 0.0, 6.0, [1.0, 0.0], event_direction=[1], event_terminal=[1], **kw)
+    assert abs(s.t_events[0][0] - 3 * np.pi / 2) < 5e-3
+    s = O.solve_ivp("sho_ev", 0.0, 6.0, [1.0, 0.0], event_direction=[-1], event_terminal=[1], **kw)
+    assert abs(s.t_events[0][0] - np.pi / 2) < 5e-3
+
+
+def test_duplicate_timestamps_known_answers():  # tests/test_ivp.py:152-170 -- the reference's golden numbers
+    s = O.solve_ivp("cannon", 0.0, np.inf, [0.0, 0.01], method="DOPRI5", max_step=0.05 * 0.001 / 9.80665,
+                    event_direction=[-1], event_terminal=[1], dense_output=True)
+    np.testing.assert_allclose(s.sol_extrapolate(0.01), [-0.00039033, -0.08806632], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(s.t_events[0], [0.00203943], rtol=1e-5, atol=1e-8)
+    assert s.status == 1   # terminal event
+
+
+@pytest.mark.parametrize("method", EXPLICIT + ["BDF"])
+def test_events_rational(method):  # tests/test_ivp.py:345-445
+    ev1 = lambda t, y: y[0] - y[1] ** 0.7
+    ev2 = lambda t, y: y[1] ** 0.6 - y[0]
+    kw = dict(method=method)
+    s = O.solve_ivp("rational_ev", 5.0, 8.0, [1 / 3, 2 / 9], event_direction=[0, 0, 0], event_terminal=[0, 0, 0], **kw)
+    # third event (t - 7.4, non-terminal here) also fires; the reference test registers only the first two
+    assert s.status == 0 and len(s.t_events[0]) == 1 and len(s.t_events[1]) == 1
+    assert 5.3 < s.t_events[0][0] < 5.7 and 7.3 < s.t_events[1][0] < 7.7
+    assert abs(ev1(s.t_events[0][0], s.y_events[0][0])) < 1e-5 and abs(ev2(s.t_events[1][0], s.y_events[1][0])) < 1e-5
+    s = O.solve_ivp("rational_ev", 5.0, 8.0, [1 / 3, 2 / 9], event_direction=[1, 1, 0], **kw)
+    assert len(s.t_events[0]) == 1 and len(s.t_events[1]) == 0
+    s = O.solve_ivp("rational_ev", 5.0, 8.0, [1 / 3, 2 / 9], event_direction=[-1, -1, 0], **kw)
+    assert len(s.t_events[0]) == 0 and len(s.t_events[1]) == 1
+    s = O.solve_ivp("rational_ev", 5.0, 8.0, [1 / 3, 2 / 9], event_direction=[0, 0, 0], event_terminal=[0, 0, 1],
+                    dense_output=True, **kw)
+    assert s.status == 1 and len(s.t_events[0]) == 1 and len(s.t_events[1]) == 0 and len(s.t_events[2]) == 1
+    assert 7.3 < s.t_events[2][0] < 7.5
+    np.testing.assert_allclose(sol_rational(s.t_events[0][0]), s.y_events[0][0], rtol=1e-3, atol=1e-6)
+    tc = np.linspace(s.t[0], s.t[-1])
+    yc = np.array([s.sol_extrapolate(t) for t in tc]).T
+    assert np.all(compute_error(yc, sol_rational(tc), 1e-3, 1e-6) < 5)
+    # backward, tests/test_ivp.py:441-460
+    s = O.solve_ivp("rational_ev", 8.0, 5.0, [4 / 9, 20 / 81], event_direction=[0, 0, 0], **kw)
+    assert len(s.t_events[0]) == 1 and len(s.t_events[1]) == 1
+    assert 5.3 < s.t_events[0][0] < 5.7 and 7.3 < s.t_events[1][0] < 7.7
+
+
+def test_bouncing_ball_example():  # examples/bouncing_ball.rs
+    s = O.solve_ivp("ball", 0.0, 10.0, [10.0, 5.0], params=[9.81, 0.02], method="DOPRI5", rtol=1e-8, atol=1e-10,
+                    event_direction=[-1], event_terminal=[1])
+    assert s.status == 1 and len(s.t_events[0]) == 1 and abs(s.y_events[0][0][0]) < 1e-9
+    assert s.t[-1] == s.t_events[0][0]      # terminal event point is appended to the output (solout.rs:317-319)
