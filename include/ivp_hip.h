@@ -86,7 +86,12 @@ typedef enum {
     IVP_RHS_LINEAR = 8,   /* y' = A y, A = [[-1,-5],[1,1]]            n=2  tests/test_helpers.py:11-12        */
     IVP_RHS_ROBERTSON = 9,/* Robertson kinetics                        n=3  tests/test_ivp.py:327-333          */
     IVP_RHS_VDP_EPS = 10, /* stiff Van der Pol        p={eps}          n=2  examples/van_der_pol.rs:9-14       */
-    IVP_RHS_BUILTIN_COUNT = 11,
+    /* problems that carry event functions (trait IVP::events / n_events, src/ivp.rs:31-46) */
+    IVP_RHS_SHO_EV = 11,  /* SHO, event g = y0                          n=2  tests/ivp.rs:151-221               */
+    IVP_RHS_BALL = 12,    /* bouncing ball  p={gravity,drag}, g = height n=2  examples/bouncing_ball.rs:5-31     */
+    IVP_RHS_CANNON = 13,  /* y'' = -9.80665, g = y0                     n=2  tests/test_ivp.py:152-160          */
+    IVP_RHS_RATIONAL_EV = 14, /* rational problem + 3 events            n=2  tests/test_ivp.py:345-353          */
+    IVP_RHS_BUILTIN_COUNT = 15,
     IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */
 } ivp_rhs_id_t;
 
@@ -125,6 +130,10 @@ typedef struct {
     int32_t has_max_step;   /* Options.max_step is Some(..) */
     double max_step;
     int32_t dense_output;   /* Options.dense_output: record per-step interpolants (needs max_log > 0) */
+    /* event_config(i) of the problem (src/solve/event.rs:5-77), for problems whose functor defines events */
+    int32_t ev_direction[4];  /* Direction: 0 All, > 0 Positive, < 0 Negative                     */
+    uint32_t ev_terminal[4];  /* terminal_count: 0 = None, k = interrupt at the k-th occurrence   */
+    uint32_t max_events;      /* capacity of t_events / y_events per event and trajectory          */
     int32_t has_min_step;   /* Options.min_step is Some(..) (read by BDF only, src/solve/solve_ivp.rs:271) */
     double min_step;
     /* ---- knobs that exist only on the GPU path ---- */
@@ -150,8 +159,8 @@ typedef struct {
     uint64_t *nrejct;   /* [B]     Solution.nrejct                                              */
     double *h_next;     /* [B]     IntegrationResult.h: the step the controller would try next  */
     /* t_eval mode (Options.t_eval = Some): Solution.t/y hold the sampled points, in order */
-    double *y_eval;     /* [n_eval][n][B]  k-th emitted sample of trajectory b                  */
-    int32_t *eval_idx;  /* [n_eval][B]     index into t_eval of the k-th emitted sample         */
+    double *y_eval;     /* [n_eval (+1 if the problem has events)][n][B]  k-th emitted sample   */
+    int32_t *eval_idx;  /* [same rows][B]  index into t_eval of the k-th emitted sample; -1 = the terminal-event point */
     int32_t *n_filled;  /* [B]             number of emitted samples                            */
     /* accepted-step mode (Options.t_eval = None, max_log > 0): Solution.t/y, capped at max_log */
     double *t_log;      /* [max_log][B]                                                         */
@@ -162,6 +171,11 @@ typedef struct {
     double *seg_xold;   /* [max_log][B]                                                         */
     double *seg_h;      /* [max_log][B]                                                         */
     uint32_t *n_seg;    /* [B]                                                                  */
+    /* events: Solution.t_events / Solution.y_events (src/solve/solution.rs:10-11), capped at max_events */
+    double *t_events;   /* [n_events][max_events][B]                                            */
+    double *y_events;   /* [n_events][max_events][n][B]                                         */
+    uint32_t *n_event_hits; /* [n_events][B] occurrences detected (may exceed max_events)       */
+    double *t_term;     /* [B] t_eval mode: time of the appended terminal-event sample (eval_idx = -1) */
     /* implicit methods (BDF): Solution.njev / Solution.nlu; zero for the explicit RK methods  */
     uint64_t *njev;     /* [B]                                                                  */
     uint64_t *nlu;      /* [B]                                                                  */
@@ -197,8 +211,9 @@ int ivp_ctx_get_stats(const ivp_ctx_t *ctx, ivp_run_stats_t *stats);
 /* Options::builder().build() defaults (src/solve/options.rs:75-123). */
 void ivp_options_default(ivp_options_t *opt);
 
-/* Dimension lookup for built-in right-hand sides. */
+/* Dimension lookup for built-in right-hand sides; ivp_rhs_n_events = IVP::n_events() (src/ivp.rs:42-46). */
 int ivp_rhs_dims(int32_t rhs_id, int32_t *n, int32_t *n_params);
+int ivp_rhs_n_events(int32_t rhs_id);
 
 /*
  * B independent solve_ivp() calls (src/solve/solve_ivp.rs:99-108:
@@ -228,8 +243,11 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
  *     __device__ void ode(double x, const double* y, double* dydx, const double* p);
  * for state dimension n and n_params parameters; it is compiled with hiprtc for the context's
  * device and instantiates the same stepping kernels as the built-ins.  Free with ivp_rhs_free().
+ * ivp_rhs_compile_events: the snippet additionally defines the trait's event functions
+ *     __device__ void events(double x, const double* y, double* g, const double* p);   // g[0..n_events)
  */
 int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, void **handle);
+int ivp_rhs_compile_events(ivp_ctx_t *ctx, const char *source, int32_t n, int32_t n_params, int32_t n_events, void **handle);
 void ivp_rhs_free(void *handle);
 
 #ifdef __cplusplus

@@ -5,14 +5,14 @@ behind ``solve_ivp``): hand-written HIP kernels for gfx950 behind a C ABI (inclu
 package being the host-side mirror of the reference's ``solve_ivp`` / ``IVP`` / ``Options`` surface.
 """
 from .api import (  # noqa: F401
-    BUILTIN, CR3BP, BatchSolution, ConfigError, Context, ContinuousOutput, DeviceIVP, Exp2, ExponentialDecay,
+    BUILTIN, BouncingBall, Cannon, CR3BP, Direction, EventConfig, RationalEvents, SHOZeroEvent, BatchSolution, ConfigError, Context, ContinuousOutput, DeviceIVP, Exp2, ExponentialDecay,
     FpMode, InterpolationError, IVP, IvpError, LinearSystem, Lorenz, Method, Options, Rational, Robertson, SHO, Solution, Status, StiffVanDerPol,
     VanDerPol, ZeroRhs, default_context, solve_ivp, solve_ivp_batch,
 )
 from . import workloads  # noqa: F401
 
 __all__ = [
-    "BUILTIN", "CR3BP", "BatchSolution", "ConfigError", "Context", "ContinuousOutput", "DeviceIVP", "Exp2",
+    "BUILTIN", "BouncingBall", "Cannon", "CR3BP", "Direction", "EventConfig", "RationalEvents", "SHOZeroEvent", "BatchSolution", "ConfigError", "Context", "ContinuousOutput", "DeviceIVP", "Exp2",
     "ExponentialDecay", "FpMode", "InterpolationError", "IVP", "IvpError", "LinearSystem", "Lorenz", "Method", "Options",
     "Rational", "Robertson", "SHO", "Solution", "Status", "StiffVanDerPol", "VanDerPol", "ZeroRhs", "default_context", "solve_ivp",
     "solve_ivp_batch", "workloads",

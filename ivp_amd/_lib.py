@@ -32,6 +32,7 @@ class OptionsT(C.Structure):
         ("has_first_step", C.c_int32), ("first_step", C.c_double),
         ("has_max_step", C.c_int32), ("max_step", C.c_double),
         ("dense_output", C.c_int32),
+        ("ev_direction", C.c_int32 * 4), ("ev_terminal", C.c_uint32 * 4), ("max_events", C.c_uint32),
         ("has_min_step", C.c_int32), ("min_step", C.c_double),
         ("fp_mode", C.c_int32), ("chunk_attempts", C.c_int32), ("max_log", C.c_uint32), ("variant", C.c_int32), ("profile", C.c_int32),
     ]
@@ -41,7 +42,7 @@ class BatchResultT(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in (
         "y_end", "t_end", "status", "nfev", "nstep", "naccpt", "nrejct", "h_next",
         "y_eval", "eval_idx", "n_filled", "t_log", "y_log", "n_log",
-        "seg_cont", "seg_xold", "seg_h", "n_seg", "njev", "nlu")]
+        "seg_cont", "seg_xold", "seg_h", "n_seg", "t_events", "y_events", "n_event_hits", "t_term", "njev", "nlu")]
 
 
 class RunStatsT(C.Structure):
@@ -56,8 +57,8 @@ class RunStatsT(C.Structure):
 # every symbol include/ivp_hip.h declares
 EXPORTS = (
     "ivp_abi_version", "ivp_device_count", "ivp_ctx_create", "ivp_ctx_destroy", "ivp_last_error_string",
-    "ivp_ctx_get_stats", "ivp_options_default", "ivp_rhs_dims", "ivp_batch_solve", "ivp_batch_solve_device",
-    "ivp_rhs_compile", "ivp_rhs_free",
+    "ivp_ctx_get_stats", "ivp_options_default", "ivp_rhs_dims", "ivp_rhs_n_events", "ivp_batch_solve",
+    "ivp_batch_solve_device", "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_free",
 )
 
 ERRORS = {
@@ -118,6 +119,10 @@ def load():
     L.ivp_batch_solve_device.argtypes = solve_args + [C.c_void_p]
     L.ivp_rhs_compile.restype = C.c_int
     L.ivp_rhs_compile.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.ivp_rhs_compile_events.restype = C.c_int
+    L.ivp_rhs_compile_events.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.ivp_rhs_n_events.restype = C.c_int
+    L.ivp_rhs_n_events.argtypes = [C.c_int32]
     L.ivp_rhs_free.restype = None
     L.ivp_rhs_free.argtypes = [C.c_void_p]
     _lib = L

@@ -88,6 +88,36 @@ class InterpolationError(IvpError):
     """``Error::Interpolation`` (src/error.rs:72-80)."""
 
 
+class Direction(enum.IntEnum):
+    """``enum Direction`` (src/solve/event.rs:59-77); the values are the C ABI's ev_direction encoding."""
+    All = 0
+    Positive = 1
+    Negative = -1
+
+
+@dataclass
+class EventConfig:
+    """``struct EventConfig`` (src/solve/event.rs:5-57)."""
+    direction: Direction = Direction.All
+    terminal_count: Optional[int] = None
+
+    def terminal(self):
+        self.terminal_count = 1
+        return self
+
+    def positive(self):
+        self.direction = Direction.Positive
+        return self
+
+    def negative(self):
+        self.direction = Direction.Negative
+        return self
+
+    def all(self):
+        self.direction = Direction.All
+        return self
+
+
 # ------------------------------------------------------------------------------------------------
 # IVP: device right-hand sides
 # ------------------------------------------------------------------------------------------------
@@ -104,8 +134,11 @@ class IVP:
     def params(self) -> Sequence[float]:
         return ()
 
-    def n_events(self) -> int:  # events are not on the accelerated path
+    def n_events(self) -> int:  # trait IVP::n_events (src/ivp.rs:42-46); the event functions are device code
         return 0
+
+    def event_config(self, index: int) -> EventConfig:  # trait IVP::event_config (src/ivp.rs:48-52)
+        return EventConfig()
 
 
 @dataclass
@@ -182,7 +215,46 @@ class StiffVanDerPol(IVP):  # examples/van_der_pol.rs:5-15
     def params(self): return (self.eps,)
 
 
-BUILTIN = {"linear": LinearSystem, "robertson": Robertson, "vdp_eps": StiffVanDerPol, "decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
+class _EventProblem(IVP):
+    """Built-in problems that carry event functions; ``configs`` are the per-event EventConfig values."""
+    _ne = 1
+
+    def __init__(self, *configs: EventConfig):
+        self.configs = list(configs) + [EventConfig() for _ in range(self._ne - len(configs))]
+
+    def n_events(self) -> int:
+        return self._ne
+
+    def event_config(self, index: int) -> EventConfig:
+        return self.configs[index]
+
+
+class SHOZeroEvent(_EventProblem):  # tests/ivp.rs:151-221: SHO with event y[0]
+    rhs_id = 11; n = 2; n_params = 0
+
+
+class BouncingBall(_EventProblem):  # examples/bouncing_ball.rs:5-31
+    rhs_id = 12; n = 2; n_params = 2
+
+    def __init__(self, gravity: float = 9.81, drag: float = 0.02, *configs: EventConfig):
+        super().__init__(*(configs or (EventConfig().terminal().negative(),)))
+        self.gravity, self.drag = gravity, drag
+
+    def params(self):
+        return (self.gravity, self.drag)
+
+
+class Cannon(_EventProblem):  # tests/test_ivp.py:152-160
+    rhs_id = 13; n = 2; n_params = 0
+
+
+class RationalEvents(_EventProblem):  # tests/test_ivp.py:345-353
+    rhs_id = 14; n = 2; n_params = 0
+    _ne = 3
+
+
+BUILTIN = {"sho_ev": SHOZeroEvent, "ball": BouncingBall, "cannon": Cannon, "rational_ev": RationalEvents,
+           "linear": LinearSystem, "robertson": Robertson, "vdp_eps": StiffVanDerPol, "decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
            "zero": ZeroRhs, "rational": Rational, "exp2": Exp2}
 
 
@@ -195,20 +267,31 @@ class DeviceIVP(IVP):
     """
     rhs_id = 1000
 
-    def __init__(self, source: str, n: int, params: Sequence[float] = (), ctx: "Context" = None):
+    def __init__(self, source: str, n: int, params: Sequence[float] = (), ctx: "Context" = None,
+                 events: Sequence[EventConfig] = ()):
+        """``events``: one EventConfig per event function; ``source`` must then also define
+        ``__device__ void events(double x, const double* y, double* g, const double* p)``."""
         self.source = source
         self.n = int(n)
         self._params = tuple(float(v) for v in params)
         self.n_params = len(self._params)
+        self._events = list(events)
         self._ctx = ctx or default_context()
         h = C.c_void_p()
-        rc = self._ctx.lib.ivp_rhs_compile(self._ctx.handle, source.encode(), self.n, self.n_params, C.byref(h))
+        rc = self._ctx.lib.ivp_rhs_compile_events(self._ctx.handle, source.encode(), self.n, self.n_params,
+                                                  len(self._events), C.byref(h))
         if rc != 0:
             raise ConfigError(rc, self._ctx.last_error())
         self.handle = h
 
     def params(self):
         return self._params
+
+    def n_events(self):
+        return len(self._events)
+
+    def event_config(self, index):
+        return self._events[index]
 
     def __del__(self):
         try:
@@ -239,6 +322,7 @@ class Options:
     fp_mode: FpMode = FpMode.STRICT
     chunk_attempts: int = 0
     max_log: int = 0
+    max_events: int = 64               # capacity of t_events / y_events per event and trajectory
     variant: int = 0                   # stepping-kernel variant: 0 auto, 1 lean registers, 2 coefficients resident
     profile: int = 0                   # 1: HIP-event kernel timing, 2: + batch totals (see ivp_run_stats_t)
 
@@ -276,6 +360,7 @@ class Options:
         o.fp_mode = int(self.fp_mode)
         o.chunk_attempts = int(self.chunk_attempts)
         o.max_log = int(self.max_log)
+        o.max_events = int(self.max_events)
         o.variant = int(self.variant)
         o.profile = int(self.profile)
         return o
@@ -501,6 +586,10 @@ class BatchSolution:
     seg_xold: object = None
     seg_h: object = None
     n_seg: object = None
+    t_events: object = None
+    y_events: object = None
+    n_event_hits: object = None
+    t_term: object = None
     njev: object = None
     nlu: object = None
     stats: dict = field(default_factory=dict)
@@ -582,8 +671,9 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         res.njev = xp_zeros((B,), u64)
         res.nlu = xp_zeros((B,), u64)
     if options.t_eval is not None and res.y_eval is None:
-        res.y_eval = xp_zeros((max(ne, 1), n, B), f64)
-        res.eval_idx = xp_zeros((max(ne, 1), B), i32)
+        rows = max(ne + (1 if f.n_events() else 0), 1)     # a terminal event appends its own sample
+        res.y_eval = xp_zeros((rows, n, B), f64)
+        res.eval_idx = xp_zeros((rows, B), i32)
         res.n_filled = xp_zeros((B,), i32)
     if options.t_eval is None and ml > 0 and res.t_log is None:
         res.t_log = xp_zeros((ml, B), f64)
@@ -595,6 +685,18 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         res.seg_h = xp_zeros((ml, B), f64)
         res.n_seg = xp_zeros((B,), u32)
 
+    ne_ev = f.n_events()
+    if ne_ev:
+        for i in range(min(ne_ev, 4)):
+            cfg = f.event_config(i)
+            copt.ev_direction[i] = int(cfg.direction)
+            copt.ev_terminal[i] = int(cfg.terminal_count or 0)
+        mev = max(int(options.max_events), 1)
+        if res.t_events is None:
+            res.t_events = xp_zeros((ne_ev, mev, B), f64)
+            res.y_events = xp_zeros((ne_ev, mev, n, B), f64)
+            res.n_event_hits = xp_zeros((ne_ev, B), u32)
+            res.t_term = xp_zeros((B,), f64)
     r = _lib.BatchResultT()
     for name, _ in _lib.BatchResultT._fields_:
         setattr(r, name, ptr(getattr(res, name)))
@@ -657,7 +759,8 @@ def solve_ivp(f: IVP, x0: float, xend: float, y0: Sequence[float], options: Opti
     if options.t_eval is not None:
         m = int(r.n_filled[0])
         te = np.asarray(options.t_eval, dtype=np.float64)
-        t = te[r.eval_idx[:m, 0]] if m else np.zeros(0)
+        idx = r.eval_idx[:m, 0]
+        t = np.where(idx >= 0, te[np.maximum(idx, 0)], r.t_term[0] if r.t_term is not None else np.nan) if m else np.zeros(0)
         y = r.y_eval[:m, :, 0].copy()
     else:
         m = int(r.n_log[0])
@@ -667,7 +770,12 @@ def solve_ivp(f: IVP, x0: float, xend: float, y0: Sequence[float], options: Opti
     if options.dense_output:
         ns = int(r.n_seg[0])
         cs = ContinuousOutput(method, n, r.seg_cont[:ns, :, 0].copy(), r.seg_xold[:ns, 0].copy(), r.seg_h[:ns, 0].copy())
-    return Solution(t=t, y=y, t_events=[[] for _ in range(n_events)], y_events=[[] for _ in range(n_events)],
+    t_events, y_events = [], []
+    for i in range(n_events):
+        k = min(int(r.n_event_hits[i, 0]), r.t_events.shape[1])
+        t_events.append(r.t_events[i, :k, 0].copy())
+        y_events.append(r.y_events[i, :k, :, 0].copy())
+    return Solution(t=t, y=y, t_events=t_events, y_events=y_events,
                     nfev=int(r.nfev[0]), njev=int(r.njev[0]), nlu=int(r.nlu[0]), nstep=int(r.nstep[0]), naccpt=int(r.naccpt[0]),
                     nrejct=int(r.nrejct[0]), status=Status(int(r.status[0])), continuous_sol=cs,
                     h_next=float(r.h_next[0]))

@@ -11,7 +11,9 @@
 // All call sites of the expensive helpers are single: D-rescalings requested by a rejected attempt are deferred to
 // the top of the next attempt (nothing reads D in between), so `change_d` is instantiated once inside a 4-pass loop.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include "rk_core.h"
+#endif
 
 namespace IVP_NS {
 
@@ -289,7 +291,7 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
 #pragma unroll
         for (int c = 0; c < N; ++c) { a.bdf_jac[(size_t)(r * N + c) * B + j] = jac[r][c]; a.bdf_lu[(size_t)(r * N + c) * B + j] = 0.0; }
     L.x = L.x0;
-    if (FULL) solout_full<M_BDF, N, P>(a, j, L, L.x0, L.x0, y, nullptr, 0.0);
+    if (FULL) (void)solout_full<M_BDF, R>(a, j, L, L.x0, L.x0, y, y, nullptr, 0.0, L.x0);
     store_so();
     a.nfev[j] = 1; a.njev[j] = 1;
     a.x[j] = L.x0; a.h[j] = h_abs;
@@ -477,8 +479,9 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     S.d_naccpt += 1;
     n_equal += 1;
     S.x = x_new;
+    double yold[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) S.y[i] = y_new[i];
+    for (int i = 0; i < N; ++i) { yold[i] = S.y[i]; S.y[i] = y_new[i]; }
     // d[order+2] = delta - d[order+1]; d[order+1] = delta; d[k] += d[k+1] for k = order..0
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -506,7 +509,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         }
         L.x0 = S.x0;
         // bdf.rs:518-519: the interpolant is anchored at x_start, the callback's xold argument is x - h_signed
-        solout_full<M_BDF, N, P>(a, j, L, S.x - h_signed, S.x, S.y, cont, h_signed, x_start);
+        if (solout_full<M_BDF, R>(a, j, L, S.x - h_signed, S.x, S.y, yold, cont, h_signed, x_start)) { pack(); S.status = 1; return false; }   // bdf.rs:521-524
     }
     if (S.direction * (S.x - S.xend) >= 0.0) { pack(); S.status = 0; return false; }
 

@@ -23,7 +23,9 @@
 namespace {
 
 struct RhsDim { int n, p; };
-const RhsDim kRhsDims[IVP_RHS_BUILTIN_COUNT] = {{1, 1}, {2, 0}, {2, 1}, {6, 1}, {3, 3}, {3, 0}, {2, 0}, {2, 0}, {2, 0}, {3, 0}, {2, 1}};
+const RhsDim kRhsDims[IVP_RHS_BUILTIN_COUNT] = {{1, 1}, {2, 0}, {2, 1}, {6, 1}, {3, 3}, {3, 0}, {2, 0}, {2, 0}, {2, 0}, {3, 0}, {2, 1},
+                                                {2, 0}, {2, 2}, {2, 0}, {2, 0}};
+const int kRhsEvents[IVP_RHS_BUILTIN_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 3};
 
 int ncoef_of(int method) { return method == IVP_DOPRI5 ? 5 : method == IVP_DOP853 ? 8 : method == IVP_BDF ? 7 : 4; }
 
@@ -58,10 +60,10 @@ struct ivp_ctx {
     DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval;
     DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
     DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
-    DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu;
+    DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu, prev_event, sc_n_ev;
     // staging for the host-pointer entry point
     DevBuf st_y0, st_params, st_t0, st_t1;
-    DevBuf st_out[20];
+    DevBuf st_out[24];
     uint32_t *pinned = nullptr;  // host-pinned: active count + misc
     std::vector<hipEvent_t> events;
     ivp_run_stats_t stats{};
@@ -167,7 +169,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
     DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval,
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
-                      &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu,
+                      &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
                       &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
@@ -203,6 +205,12 @@ int ivp_rhs_dims(int32_t rhs_id, int32_t *n, int32_t *np)
     return IVP_OK;
 }
 
+int ivp_rhs_n_events(int32_t rhs_id)
+{
+    if (rhs_id < 0 || rhs_id >= IVP_RHS_BUILTIN_COUNT) return 0;
+    return kRhsEvents[rhs_id];
+}
+
 int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0, const double *params,
                            const double *t0, size_t t0_len, const double *t1, size_t t1_len, const ivp_options_t *opt,
                            ivp_batch_result_t *out, void *hip_stream)
@@ -221,7 +229,9 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     const bool want_eval = opt->t_eval != nullptr;
     const bool want_log = !want_eval && opt->max_log > 0 && out->t_log && out->y_log;
     const bool want_dense = opt->dense_output && opt->max_log > 0 && out->seg_cont && out->seg_xold && out->seg_h;
-    const bool full = want_eval || want_log || want_dense;
+    const int n_events = prob->rhs_id == IVP_RHS_JIT ? ivp_jit_n_events(prob->jit) : kRhsEvents[prob->rhs_id];
+    if (n_events > 4) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "at most 4 event functions");
+    const bool full = want_eval || want_log || want_dense || n_events > 0;
     if (want_eval && opt->n_eval > 0 && !out->y_eval) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t_eval given but out.y_eval is NULL");
     if (opt->dense_output && !want_dense) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "dense_output needs max_log > 0 and seg_cont/seg_xold/seg_h");
 
@@ -291,6 +301,19 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     a.flags = (uint32_t *)ctx->flags.p;
 
     a.n_eval = -1;
+    if (n_events > 0) {   // event state: prev_event, hit counters; outputs where given
+        for (int i = 0; i < 4; ++i) { a.ev_direction[i] = opt->ev_direction[i]; a.ev_terminal[i] = opt->ev_terminal[i]; }
+        const bool store = out->t_events && out->y_events && opt->max_events > 0;
+        a.max_events = store ? opt->max_events : 0;
+        a.t_events = out->t_events;
+        a.y_events = out->y_events;
+        a.t_term = out->t_term;
+        HIP_TRY(ctx, ctx->prev_event.reserve(sizeof(double) * n_events * B));
+        a.prev_event = (double *)ctx->prev_event.p;
+        if (out->n_event_hits) a.n_ev = out->n_event_hits;
+        else { HIP_TRY(ctx, ctx->sc_n_ev.reserve(sizeof(uint32_t) * n_events * B)); a.n_ev = (uint32_t *)ctx->sc_n_ev.p; }
+        HIP_TRY(ctx, hipMemsetAsync(a.n_ev, 0, sizeof(uint32_t) * n_events * B, s));
+    }
     if (full) {
         if (want_eval) {
             a.n_eval = (int32_t)opt->n_eval;
@@ -487,7 +510,10 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
     struct Slot { void *host; size_t bytes; void **dev; };
     ivp_batch_result_t d;
     std::memset(&d, 0, sizeof d);
-    Slot slots[20] = {
+    const size_t nev = prob->rhs_id == IVP_RHS_JIT ? (size_t)ivp_jit_n_events(prob->jit) : (size_t)kRhsEvents[prob->rhs_id];
+    const size_t mev = opt->max_events;
+    const size_t ne_rows = opt->t_eval ? ne + (nev > 0 ? 1 : 0) : 0;   // a terminal event appends one more sample
+    Slot slots[24] = {
         {out->y_end, sizeof(double) * n * B, (void **)&d.y_end},
         {out->t_end, sizeof(double) * B, (void **)&d.t_end},
         {out->status, sizeof(int32_t) * B, (void **)&d.status},
@@ -496,8 +522,8 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
         {out->naccpt, sizeof(uint64_t) * B, (void **)&d.naccpt},
         {out->nrejct, sizeof(uint64_t) * B, (void **)&d.nrejct},
         {out->h_next, sizeof(double) * B, (void **)&d.h_next},
-        {out->y_eval, sizeof(double) * ne * n * B, (void **)&d.y_eval},
-        {out->eval_idx, sizeof(int32_t) * ne * B, (void **)&d.eval_idx},
+        {out->y_eval, sizeof(double) * ne_rows * n * B, (void **)&d.y_eval},
+        {out->eval_idx, sizeof(int32_t) * ne_rows * B, (void **)&d.eval_idx},
         {out->n_filled, sizeof(int32_t) * B, (void **)&d.n_filled},
         {out->t_log, sizeof(double) * ml * B, (void **)&d.t_log},
         {out->y_log, sizeof(double) * ml * n * B, (void **)&d.y_log},
@@ -508,8 +534,12 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
         {out->n_seg, sizeof(uint32_t) * B, (void **)&d.n_seg},
         {out->njev, sizeof(uint64_t) * B, (void **)&d.njev},
         {out->nlu, sizeof(uint64_t) * B, (void **)&d.nlu},
+        {out->t_events, sizeof(double) * nev * mev * B, (void **)&d.t_events},
+        {out->y_events, sizeof(double) * nev * mev * n * B, (void **)&d.y_events},
+        {out->n_event_hits, sizeof(uint32_t) * nev * B, (void **)&d.n_event_hits},
+        {out->t_term, sizeof(double) * B, (void **)&d.t_term},
     };
-    for (int i = 0; i < 20; ++i) {
+    for (int i = 0; i < 24; ++i) {
         if (slots[i].host && slots[i].bytes) {
             HIP_TRY(ctx, ctx->st_out[i].reserve(slots[i].bytes));
             *slots[i].dev = ctx->st_out[i].p;
@@ -518,7 +548,7 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
     rc = ivp_batch_solve_device(ctx, prob, B, (const double *)ctx->st_y0.p, np > 0 ? (const double *)ctx->st_params.p : nullptr,
                                 (const double *)ctx->st_t0.p, t0_len, (const double *)ctx->st_t1.p, t1_len, opt, &d, nullptr);
     if (rc != IVP_OK) return rc;
-    for (int i = 0; i < 20; ++i)
+    for (int i = 0; i < 24; ++i)
         if (slots[i].host && slots[i].bytes)
             HIP_TRY(ctx, hipMemcpy(slots[i].host, *slots[i].dev, slots[i].bytes, hipMemcpyDeviceToHost));
     return IVP_OK;
@@ -526,10 +556,16 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
 
 int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, void **handle)
 {
+    return ivp_rhs_compile_events(ctx, ode_source, n, n_params, 0, handle);
+}
+
+int ivp_rhs_compile_events(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, int32_t n_events, void **handle)
+{
     if (!ctx || !ode_source || !handle) return IVP_ERR_BAD_ARGUMENT;
-    if (n < 1 || n > IVP_MAX_N || n_params < 0 || n_params > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
+    if (n < 1 || n > IVP_MAX_N || n_params < 0 || n_params > IVP_MAX_P || n_events < 0 || n_events > 4)
+        return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
     std::string log;
-    int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, handle, &log);
+    int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, n_events, handle, &log);
     if (rc != IVP_OK) ctx->err = log;
     return rc;
 }

@@ -30,7 +30,7 @@ struct JitModule {
 };
 
 struct JitRhs {
-    int device, n, np;
+    int device, n, np, ne;
     std::string ode_source;
     std::string arch;
     std::mutex mu;
@@ -51,18 +51,24 @@ std::string build_source(const JitRhs &r, int method, bool full)
     s += "typedef unsigned int uint32_t;\ntypedef int int32_t;\ntypedef unsigned long long uint64_t;\ntypedef long long int64_t;\n";
     s += "#define IVP_HD __device__ __forceinline__\n";
     s += "#define IVP_NS ivp_jit\n";
+    s += "#define IVP_USER_NE " + std::to_string(r.ne) + "\n";
     s += join(k_src_ivp_kargs_h);
     s += "\n// ---- user right-hand side ----\n";
     s += r.ode_source;
     s += "\n// ---- integrator ----\n";
     s += join(k_src_rk_core_h);
+    s += join(k_src_bdf_core_h);
     s += join(k_src_rk_global_h);
-    char buf[1024];
+    char buf[4096];
     std::snprintf(buf, sizeof buf,
-                  "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d };\n"
-                  "  static IVP_HD void ode(double x, const double* y, double* d, const double* p) { ::ode(x, y, d, p); } }; }\n"
+                  "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d, NE = IVP_USER_NE };\n"
+                  "  static IVP_HD void ode(double x, const double* y, double* d, const double* p) { ::ode(x, y, d, p); }\n"
+                  "#if IVP_USER_NE > 0\n"
+                  "  static IVP_HD void events(double x, const double* y, double* g, const double* p) { ::events(x, y, g, p); }\n"
+                  "#endif\n"
+                  "}; }\n"
                   "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a)\n"
-                  "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
+                  "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::any_init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
                   "extern \"C\" __global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void ivp_jit_chunk(const IvpKArgs a)\n"
                   "{ ivp_jit::chunk_kernel_body<%d, ivp_jit::RhsUser, %s>(a); }\n",
                   r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false");
@@ -109,12 +115,15 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, JitModule *out
 
 }  // namespace
 
-int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, void **handle, std::string *log)
+int ivp_jit_n_events(void *handle) { return handle ? ((JitRhs *)handle)->ne : 0; }
+
+int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, int n_events, void **handle, std::string *log)
 {
     JitRhs *r = new JitRhs();
     r->device = device;
     r->n = n;
     r->np = n_params;
+    r->ne = n_events;
     r->ode_source = ode_source;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0]) {
@@ -125,7 +134,7 @@ int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, voi
         r->arch = "gfx950";
     }
     // compile the default configuration now so that syntax errors surface at ivp_rhs_compile() time
-    const int rc = compile_module(*r, IVP_DOPRI5, IVP_FP_STRICT, false, nullptr);
+    const int rc = compile_module(*r, IVP_DOPRI5, IVP_FP_STRICT, n_events > 0, nullptr);
     if (rc != IVP_OK) {
         if (log) *log = r->log;
         delete r;

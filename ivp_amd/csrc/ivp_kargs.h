@@ -68,6 +68,15 @@ struct IvpKArgs {
     double *seg_xold;         // [max_log][B]
     double *seg_h;            // [max_log][B]
     uint32_t *n_seg;          // [B]
+    // ---- events (trait IVP::events / event_config; FULL kernels of problems with NE > 0) ----
+    int32_t ev_direction[4];  // 0 All, > 0 Positive, < 0 Negative (event.rs:59-77)
+    uint32_t ev_terminal[4];  // EventConfig.terminal_count, 0 = None
+    uint32_t max_events;      // capacity of t_events / y_events per event and trajectory
+    double *t_events;         // [NE][max_events][B]
+    double *y_events;         // [NE][max_events][N][B]
+    uint32_t *n_ev;           // [NE][B]  event_hits
+    double *prev_event;       // [NE][B]
+    double *t_term;           // [B] time of the terminal-event sample in t_eval mode (eval_idx = -1)
     // ---- BDF (variable-order implicit) state ----
     double min_step;          // Options.min_step
     int32_t has_min_step;

@@ -154,15 +154,15 @@ IVP_HD double ivp_pow(double x, double e)
 // Right-hand sides: the device-side `impl IVP for T { fn ode(&self, x, y, dydx) }` (src/ivp.rs:29).
 // ------------------------------------------------------------------------------------------------
 struct RhsDecay {    // examples/exponential_decay.rs:9-13
-    enum { N = 1, P = 1 };
+    enum { N = 1, P = 1, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *p) { d[0] = -p[0] * y[0]; }
 };
 struct RhsSho {      // tests/common.rs:3-9
-    enum { N = 2, P = 0 };
+    enum { N = 2, P = 0, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *) { d[0] = y[1]; d[1] = -y[0]; }
 };
 struct RhsVdp {      // benches/benchmark.py:22-27
-    enum { N = 2, P = 1 };
+    enum { N = 2, P = 1, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *p)
     {
         d[0] = y[1];
@@ -170,7 +170,7 @@ struct RhsVdp {      // benches/benchmark.py:22-27
     }
 };
 struct RhsCr3bp {    // examples/cr3bp.rs:23-36
-    enum { N = 6, P = 1 };
+    enum { N = 6, P = 1, NE = 0 };
     static IVP_HD void ode(double, const double *s, double *d, const double *p)
     {
         const double mu = p[0];
@@ -201,7 +201,7 @@ struct RhsCr3bp {    // examples/cr3bp.rs:23-36
     }
 };
 struct RhsLorenz {   // benches/benchmark.py:30-37
-    enum { N = 3, P = 3 };
+    enum { N = 3, P = 3, NE = 0 };
     static IVP_HD void ode(double, const double *s, double *d, const double *p)
     {
         d[0] = p[0] * (s[1] - s[0]);
@@ -210,11 +210,11 @@ struct RhsLorenz {   // benches/benchmark.py:30-37
     }
 };
 struct RhsZero {     // tests/ivp.rs:11-19
-    enum { N = 3, P = 0 };
+    enum { N = 3, P = 0, NE = 0 };
     static IVP_HD void ode(double, const double *, double *d, const double *) { d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; }
 };
 struct RhsRational { // tests/test_helpers.py:23-25
-    enum { N = 2, P = 0 };
+    enum { N = 2, P = 0, NE = 0 };
     static IVP_HD void ode(double t, const double *y, double *d, const double *)
     {
         d[0] = y[1] / t;
@@ -222,12 +222,12 @@ struct RhsRational { // tests/test_helpers.py:23-25
     }
 };
 struct RhsExp2 {     // tests/ivp.rs:291-298
-    enum { N = 2, P = 0 };
+    enum { N = 2, P = 0, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *) { d[0] = y[0]; d[1] = y[1]; }
 };
 
 struct RhsLinear {   // tests/test_helpers.py:11-12
-    enum { N = 2, P = 0 };
+    enum { N = 2, P = 0, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *)
     {
         d[0] = -y[0] - 5.0 * y[1];
@@ -235,7 +235,7 @@ struct RhsLinear {   // tests/test_helpers.py:11-12
     }
 };
 struct RhsRobertson {   // tests/test_ivp.py:327-333
-    enum { N = 3, P = 0 };
+    enum { N = 3, P = 0, NE = 0 };
     static IVP_HD void ode(double, const double *s, double *d, const double *)
     {
         const double x = s[0], y = s[1], z = s[2];
@@ -245,11 +245,47 @@ struct RhsRobertson {   // tests/test_ivp.py:327-333
     }
 };
 struct RhsVdpEps {   // examples/van_der_pol.rs:9-14
-    enum { N = 2, P = 1 };
+    enum { N = 2, P = 1, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *p)
     {
         d[0] = y[1];
         d[1] = ((1.0 - y[0] * y[0]) * y[1] - y[0]) / p[0];
+    }
+};
+
+// Problems with event functions: trait IVP::events / n_events (src/ivp.rs:31-46). NE = n_events().
+struct RhsShoEv {    // tests/ivp.rs:151-221: SHO with g = y0
+    enum { N = 2, P = 0, NE = 1 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *) { d[0] = y[1]; d[1] = -y[0]; }
+    static IVP_HD void events(double, const double *y, double *g, const double *) { g[0] = y[0]; }
+};
+struct RhsBall {     // examples/bouncing_ball.rs:5-31  p = {gravity, drag}
+    enum { N = 2, P = 2, NE = 1 };
+    static IVP_HD void ode(double, const double *s, double *d, const double *p)
+    {
+        const double vy = s[1];
+        d[0] = vy;
+        d[1] = -p[0] - p[1] * vy * fabs(vy);
+    }
+    static IVP_HD void events(double, const double *y, double *g, const double *) { g[0] = y[0]; }
+};
+struct RhsCannon {   // tests/test_ivp.py:152-160
+    enum { N = 2, P = 0, NE = 1 };
+    static IVP_HD void ode(double, const double *y, double *d, const double *) { d[0] = y[1]; d[1] = -9.80665; }
+    static IVP_HD void events(double, const double *y, double *g, const double *) { g[0] = y[0]; }
+};
+struct RhsRationalEv {   // tests/test_ivp.py:345-353
+    enum { N = 2, P = 0, NE = 3 };
+    static IVP_HD void ode(double t, const double *y, double *d, const double *)
+    {
+        d[0] = y[1] / t;
+        d[1] = y[1] * (y[0] + 2.0 * y[1] - 1.0) / (t * (y[0] - 1.0));
+    }
+    static IVP_HD void events(double t, const double *y, double *g, const double *)
+    {
+        g[0] = y[0] - pow(y[1], 0.7);
+        g[1] = pow(y[1], 0.6) - y[0];
+        g[2] = t - 7.4;
     }
 };
 
@@ -445,22 +481,10 @@ IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, 
 }
 
 template <int M, int N, int P>
-IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
-                        const double *y, const double *cont, double h, double ixold);
-template <int M, int N, int P>
-IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
-                        const double *y, const double *cont, double h)
-{
-    solout_full<M, N, P>(a, j, L, xold, x, y, cont, h, xold);
-}
-// `xold` is the callback's first argument, `ixold`/`h` the interpolant's own anchor (StepInterpolant.xold/.h):
-// identical for the RK methods, different for BDF (bdf.rs:518-519).
-template <int M, int N, int P>
-IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
-                        const double *y, const double *cont, double h, double ixold)
+IVP_HD void so_collect_dense(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
+                             const double *cont, double h, double ixold)
 {
     constexpr int NC = NCoef<M>::v * N;
-    const double tol = 1e-12;
     const size_t B = a.B;
     // dense collection, solout.rs:141-146
     if (a.collect_dense && x != xold && cont != nullptr && h != 0.0) {
@@ -473,6 +497,17 @@ IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xol
         }
         L.n_seg += 1;
     }
+}
+
+// t_eval sampling / accepted-step recording (solout.rs:344-428). `xold` is the callback's first argument,
+// `ixold`/`h` the interpolant's own anchor (StepInterpolant.xold/.h): identical for the RK methods, different for
+// BDF (bdf.rs:518-519).
+template <int M, int N, int P>
+IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
+                      const double *y, const double *cont, double h, double ixold)
+{
+    const double tol = 1e-12;
+    (void)tol;
     double yi[N];
     if (a.n_eval >= 0) {  // Mode 1, solout.rs:344-386
         int32_t i = L.next_idx;
@@ -511,6 +546,151 @@ IVP_HD void solout_full(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xol
         }
         if (L.n_log == 0 || fabs(L.t_last - x) > tol) so_push_log<M, N, P>(a, j, L, x, y);
     }
+}
+
+
+// Event detection (solout.rs:158-331): zero crossings of R::events between the previous and the current accepted
+// point, refined with Brent's method on the step interpolant (xtol 2e-12, rtol eps, <= 100 iterations), processed
+// in chronological order; a terminal event appends its point to the output and interrupts the integration.
+template <int M, class R>
+IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
+                      const double *y, const double *yold, const double *cont, double h, double ixold)
+{
+    constexpr int N = R::N, P = R::P, NE = R::NE > 0 ? R::NE : 1;
+    const size_t B = a.B;
+    double g_curr[NE];
+    R::events(x, y, g_curr, L.p);
+    if (cont == nullptr) {   // initial callback: DefaultSolOut.yold is still empty (solout.rs:163-164)
+#pragma unroll
+        for (int i = 0; i < NE; ++i) a.prev_event[(size_t)i * B + j] = g_curr[i];
+        return false;
+    }
+    double det_t[NE], det_y[NE][N];
+    int det_i[NE];
+    int ndet = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const double g_prev = a.prev_event[(size_t)i * B + j], g_cur = g_curr[i];
+        const int dir = a.ev_direction[i];
+        bool crossed;
+        if (dir == 0) crossed = (g_prev <= 0.0 && g_cur >= 0.0) || (g_prev >= 0.0 && g_cur <= 0.0);
+        else if (dir > 0) crossed = g_prev < 0.0 && g_cur >= 0.0;
+        else crossed = g_prev > 0.0 && g_cur <= 0.0;
+        if (crossed) {
+            const double XTOL = 2e-12, RTOL = 2.220446049250313e-16;
+            double ea = xold, eb = x, fa = g_prev, fb = g_cur;
+            double ymid[N], gmid[NE];
+            double et;
+            if (fabs(fa) <= XTOL) {
+                et = ea;
+#pragma unroll
+                for (int c = 0; c < N; ++c) ymid[c] = yold[c];
+            } else if (fabs(fb) <= XTOL) {
+                et = eb;
+#pragma unroll
+                for (int c = 0; c < N; ++c) ymid[c] = y[c];
+            } else {
+                double ec = ea, fc = fa, ed = eb - ea, ee = ed;
+#pragma unroll 1
+                for (int it = 0; it < 100; ++it) {
+                    if (fb * fc > 0.0) { ec = ea; fc = fa; ed = eb - ea; ee = ed; }
+                    if (fabs(fc) < fabs(fb)) { ea = eb; eb = ec; ec = ea; fa = fb; fb = fc; fc = fa; }
+                    const double tol1 = 2.0 * RTOL * fabs(eb) + 0.5 * XTOL;
+                    const double xm = 0.5 * (ec - eb);
+                    if (fabs(xm) <= tol1 || fb == 0.0) break;
+                    if (fabs(ee) >= tol1 && fabs(fa) > fabs(fb)) {
+                        double sq, pp, qq;
+                        if (ea == ec) {
+                            sq = fb / fa;
+                            pp = 2.0 * xm * sq;
+                            qq = 1.0 - sq;
+                        } else {
+                            const double q_val = fa / fc, rr = fb / fc;
+                            sq = fb / fa;
+                            pp = sq * (2.0 * xm * q_val * (q_val - rr) - (eb - ea) * (rr - 1.0));
+                            qq = (q_val - 1.0) * (rr - 1.0) * (sq - 1.0);
+                        }
+                        if (qq > 0.0) pp = -pp; else qq = -qq;
+                        if (2.0 * pp < fmin(3.0 * xm * qq - fabs(tol1 * qq), fabs(ee * qq))) { ee = ed; ed = pp / qq; }
+                        else { ed = xm; ee = ed; }
+                    } else { ed = xm; ee = ed; }
+                    ea = eb; fa = fb;
+                    if (fabs(ed) > tol1) eb += ed;
+                    else eb += xm > 0.0 ? tol1 : -tol1;
+                    interpolate<M, N>(eb, ymid, cont, ixold, h);
+                    R::events(eb, ymid, gmid, L.p);
+                    double fnew = gmid[0];
+#pragma unroll
+                    for (int q = 1; q < NE; ++q) fnew = (q == i) ? gmid[q] : fnew;
+                    fb = fnew;
+                }
+                interpolate<M, N>(eb, ymid, cont, ixold, h);
+                et = eb;
+            }
+            // append to the detected list (ndet is a run-time count: guarded static slots)
+#pragma unroll
+            for (int q = 0; q < NE; ++q)
+                if (q == ndet) {
+                    det_t[q] = et; det_i[q] = i;
+#pragma unroll
+                    for (int c = 0; c < N; ++c) det_y[q][c] = ymid[c];
+                }
+            ndet += 1;
+        }
+    }
+    // stable insertion sort by time (ascending forward, descending backward), solout.rs:297-303
+    const bool forward = x > xold;
+#pragma unroll
+    for (int u = 1; u < NE; ++u) {
+        bool moving = u < ndet;
+#pragma unroll
+        for (int v = u; v > 0; --v) {
+            const bool sw = moving && (forward ? (det_t[v] < det_t[v - 1]) : (det_t[v] > det_t[v - 1]));
+            if (sw) {
+                const double tt = det_t[v]; det_t[v] = det_t[v - 1]; det_t[v - 1] = tt;
+                const int ti = det_i[v]; det_i[v] = det_i[v - 1]; det_i[v - 1] = ti;
+#pragma unroll
+                for (int c = 0; c < N; ++c) { const double ty = det_y[v][c]; det_y[v][c] = det_y[v - 1][c]; det_y[v - 1][c] = ty; }
+            } else moving = false;
+        }
+    }
+    bool interrupt = false;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        if (u < ndet && !interrupt) {
+            const int i = det_i[u];
+            const uint32_t k = a.n_ev[(size_t)i * B + j];
+            if (k < a.max_events) {
+                a.t_events[((size_t)i * a.max_events + k) * B + j] = det_t[u];
+#pragma unroll
+                for (int c = 0; c < N; ++c) a.y_events[(((size_t)i * a.max_events + k) * N + c) * B + j] = det_y[u][c];
+            }
+            a.n_ev[(size_t)i * B + j] = k + 1;   // event_hits
+            const uint32_t term = a.ev_terminal[i];
+            if (term != 0 && k + 1 >= term) {
+                // the terminal event point is appended to Solution.t / Solution.y (solout.rs:316-319)
+                if (a.n_eval >= 0) { so_emit_eval<M, N, P>(a, j, L, -1, det_y[u]); if (a.t_term) a.t_term[j] = det_t[u]; }
+                else if (a.t_log != nullptr) so_push_log<M, N, P>(a, j, L, det_t[u], det_y[u]);
+                interrupt = true;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) a.prev_event[(size_t)i * B + j] = g_curr[i];
+    return interrupt;
+}
+
+// DefaultSolOut::solout on the device. Returns true for ControlFlag::Interrupt (terminal event).
+template <int M, class R>
+IVP_HD bool solout_full(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
+                        const double *y, const double *yold, const double *cont, double h, double ixold)
+{
+    so_collect_dense<M, R::N, R::P>(a, j, L, xold, x, cont, h, ixold);
+    if constexpr (R::NE > 0) {
+        if (so_events<M, R>(a, j, L, xold, x, y, yold, cont, h, ixold)) return true;
+    }
+    so_sample<M, R::N, R::P>(a, j, L, xold, x, y, cont, h, ixold);
+    return false;
 }
 
 // does the accepted step [xold, xph] need dense coefficients? (lazy DOP853 dense stages)
@@ -646,7 +826,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         nfev += 2;  // f(x0, y0) and hinit's Euler probe
         L.h = hinit<R>(a, L.x, L.y, L.posneg, L.k1, L.p, M == M_DOPRI5 ? 5 : (M == M_DOP853 ? 8 : 3), L.hmax);
     }
-    if (FULL) solout_full<M, N, P>(a, j, L, L.x, L.x, L.y, nullptr, 0.0);
+    if (FULL) (void)solout_full<M, R>(a, j, L, L.x, L.x, L.y, L.y, nullptr, 0.0, L.x);
 
 #pragma unroll
     for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = L.k1[c]; }
@@ -815,7 +995,9 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
         for (int i = 0; i < N; ++i) { L.k1[i] = k2[i]; L.y[i] = y1[i]; }
         L.x = xph;
-        if (FULL) solout_full<M_DOPRI5, N, P>(a, j, L, x, xph, L.y, cont, h);
+        if (FULL) {   // ControlFlag::Interrupt => status = UserInterrupt, break before h = hnew (dopri5.rs:418-421)
+            if (solout_full<M_DOPRI5, R>(a, j, L, x, xph, L.y, cont, cont, h, x)) { L.h = h; L.status = 1; return false; }
+        }
         if (last) { L.h = hnew; L.status = 0; return false; }                          // Success
         if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
         if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
@@ -1027,7 +1209,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         // this step's interpolant is actually consumed, and always counts the 3 evaluations.
         L.d_nfev += 3;
         double cont[FULL ? 8 * N : 1];
-        const bool need_dense = FULL && so_needs_dense<N, P>(a, L, x, xph);
+        const bool need_dense = FULL && (R::NE > 0 || so_needs_dense<N, P>(a, L, x, xph));
         if (FULL && need_dense) {
 { const double cD41 = KC(D41), cD46 = KC(D46), cD47 = KC(D47), cD48 = KC(D48), cD49 = KC(D49), cD410 = KC(D410), cD411 = KC(D411), cD412 = KC(D412), cD51 = KC(D51), cD56 = KC(D56), cD57 = KC(D57), cD58 = KC(D58), cD59 = KC(D59), cD510 = KC(D510), cD511 = KC(D511), cD512 = KC(D512), cD61 = KC(D61), cD66 = KC(D66), cD67 = KC(D67), cD68 = KC(D68), cD69 = KC(D69), cD610 = KC(D610), cD611 = KC(D611), cD612 = KC(D612), cD71 = KC(D71), cD76 = KC(D76), cD77 = KC(D77), cD78 = KC(D78), cD79 = KC(D79), cD710 = KC(D710), cD711 = KC(D711), cD712 = KC(D712);
 #pragma unroll
@@ -1075,7 +1257,9 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
         for (int i = 0; i < N; ++i) { L.k1[i] = k4[i]; L.y[i] = k5[i]; }
         L.x = xph;
-        if (FULL) solout_full<M_DOP853, N, P>(a, j, L, x, xph, L.y, need_dense ? cont : nullptr, h);
+        if (FULL) {
+            if (solout_full<M_DOP853, R>(a, j, L, x, xph, L.y, cont, need_dense ? cont : nullptr, h, x)) { L.h = h; L.status = 1; return false; }
+        }
         if (last) { L.h = hnew; L.status = 0; return false; }
         if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
         if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
@@ -1161,7 +1345,7 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
             for (int i = 0; i < N; ++i) L.y[i] = yt[i];
             L.x = xnew;
-            solout_full<M_RK23, N, P>(a, j, L, x, xnew, L.y, cont, h);
+            if (solout_full<M_RK23, R>(a, j, L, x, xnew, L.y, cont, cont, h, x)) { L.h = h; L.status = 1; return false; }   // rk23.rs:266-269
         } else {
 #pragma unroll
             for (int i = 0; i < N; ++i) L.y[i] = yt[i];
@@ -1236,7 +1420,7 @@ IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
             cont[2 * N + i] = L.k1[i];
             cont[3 * N + i] = L.y[i];
         }
-        solout_full<M_RK4, N, P>(a, j, L, x, xnew, L.y, cont, h);
+        if (solout_full<M_RK4, R>(a, j, L, x, xnew, L.y, cont, cont, h, x)) { L.status = 1; return false; }   // rk4.rs:201-204
     }
     if (last) { L.status = 0; return false; }
     return true;

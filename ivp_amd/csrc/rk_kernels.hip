@@ -85,6 +85,10 @@ hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const Iv
     case 8: return launch_rhs<IVP_NS::RhsLinear>(what, method, full, a, lanes, s);
     case 9: return launch_rhs<IVP_NS::RhsRobertson>(what, method, full, a, lanes, s);
     case 10: return launch_rhs<IVP_NS::RhsVdpEps>(what, method, full, a, lanes, s);
+    case 11: return launch_rhs<IVP_NS::RhsShoEv>(what, method, full, a, lanes, s);
+    case 12: return launch_rhs<IVP_NS::RhsBall>(what, method, full, a, lanes, s);
+    case 13: return launch_rhs<IVP_NS::RhsCannon>(what, method, full, a, lanes, s);
+    case 14: return launch_rhs<IVP_NS::RhsRationalEv>(what, method, full, a, lanes, s);
     }
     return hipErrorInvalidValue;
 }

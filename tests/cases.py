@@ -184,3 +184,58 @@ CASES.append(("bdf-cr3bp-short", "cr3bp", lambda: (*W.cr3bp_batch(16)[:3], 2.0, 
 CASES.append(("bdf-zero-rhs", "zero", lambda: (np.ones((3, 2)), None, 0.0, 10.0, dict(method="BDF", rtol=1e-6, atol=1e-9, max_steps=5000))))
 
 CASE_IDS = [c[0] for c in CASES]
+
+
+EVENT_CASES = []
+for _m in ("RK23", "DOPRI5", "DOP853", "RK4", "BDF"):
+    _kw = dict(method=_m) if _m == "RK4" else dict(method=_m, rtol=1e-9 if _m != "BDF" else 1e-6, atol=1e-9)
+    EVENT_CASES += [
+        (f"sho-all-term2-{_m}", "sho_ev", 0.0, 6.0, [1.0, 0.0], (), dict(event_direction=[0], event_terminal=[2], **_kw)),
+        (f"sho-pos-{_m}", "sho_ev", 0.0, 6.0, [1.0, 0.0], (), dict(event_direction=[1], event_terminal=[0], **_kw)),
+        (f"sho-neg-term-bwd-{_m}", "sho_ev", 6.0, 0.0, [1.0, 0.0], (), dict(event_direction=[-1], event_terminal=[1], **_kw)),
+        (f"sho-teval-term-{_m}", "sho_ev", 0.0, 6.0, [1.0, 0.0], (),
+         dict(event_direction=[0], event_terminal=[2], t_eval=np.linspace(0, 6, 13), **_kw)),
+    ]
+    if _m != "RK4":
+        EVENT_CASES += [
+            (f"rational-3ev-term-{_m}", "rational_ev", 5.0, 8.0, [1 / 3, 2 / 9], (),
+             dict(method=_m, event_direction=[0, 0, 0], event_terminal=[0, 0, 1], dense_output=True)),
+            (f"rational-3ev-bwd-{_m}", "rational_ev", 8.0, 5.0, [4 / 9, 20 / 81], (),
+             dict(method=_m, event_direction=[0, 0, 0], event_terminal=[0, 0, 0])),
+        ]
+EVENT_CASES += [
+    ("ball", "ball", 0.0, 10.0, [10.0, 5.0], (9.81, 0.02),
+     dict(method="DOPRI5", rtol=1e-8, atol=1e-10, event_direction=[-1], event_terminal=[1])),
+    ("cannon", "cannon", 0.0, np.inf, [0.0, 0.01], (),
+     dict(method="DOPRI5", max_step=0.05 * 0.001 / 9.80665, event_direction=[-1], event_terminal=[1], dense_output=True)),
+]
+
+
+def check_events_against_oracle(solve, case, exact=True):
+    """Events, outputs and statistics of a 3-trajectory batch vs one oracle solve_ivp call per trajectory."""
+    from oracle import oracle as O
+    name, rhs, t0, t1, y0, params, kw = case
+    y0a = np.asarray(y0, float).reshape(-1, 1).repeat(3, axis=1)
+    y0a[:, 1] *= 1.001
+    y0a[:, 2] *= 0.999
+    par = np.asarray(params, float).reshape(-1, 1).repeat(3, axis=1) if len(params) else None
+    gkw = dict(kw)
+    if "t_eval" not in gkw:
+        gkw["max_log"] = 4096
+    g = solve(rhs, y0a, par, t0, t1, **gkw)
+    eq = np.array_equal if exact else (lambda a, b: np.allclose(a, b, rtol=1e-9, atol=1e-11))
+    for b in range(3):
+        s = O.solve_ivp(rhs, t0, t1, y0a[:, b], params=params, detpow=True, **kw)
+        for i in range(len(s.t_events)):
+            m = int(g["n_ev"][i, b])
+            assert m == len(s.t_events[i]), (name, b, i)
+            assert eq(g["t_events"][i, :m, b], s.t_events[i]) and eq(g["y_events"][i, :m, :, b], s.y_events[i]), (name, b, i)
+        assert int(g["status"][b]) == s.status and int(g["nfev"][b]) == s.nfev and g["h_next"][b] == s.h_next or not exact
+        if "t_eval" in kw:
+            m = g["n_filled"][b]
+            assert m == len(s.t) and eq(g["y_eval"][:m, :, b], s.y)
+            if s.status == 1:
+                assert eq(g["t_term"][b], s.t[-1]) and g["eval_idx"][m - 1, b] == -1
+        else:
+            m = g["n_log"][b]
+            assert m == len(s.t) and eq(g["t_log"][:m, b], s.t) and eq(g["y_log"][:m, :, b], s.y)

@@ -14,6 +14,7 @@ KEYS_INT = ("status", "nfev", "nstep", "naccpt", "nrejct", "njev", "nlu")
 def oracle_batch(rhs, y0, params, t0, t1, detpow=True, **opts):
     opts = dict(opts)
     opts.pop("max_log", None)
+    opts.pop("max_events", None)
     opts.pop("chunk", None)
     return O.solve_batch(rhs, y0, params, t0, t1, detpow=detpow, **opts)
 
@@ -23,9 +24,16 @@ def emul_batch(rhs, y0, params, t0, t1, **opts):
     return E.solve_batch(rhs, y0, params, t0, t1, **opts)
 
 
-def gpu_batch(rhs, y0, params, t0, t1, *, fast=False, chunk=0, device_arrays=False, **opts):
+def gpu_batch(rhs, y0, params, t0, t1, *, fast=False, chunk=0, device_arrays=False, event_direction=None,
+              event_terminal=None, **opts):
     import ivp_amd
-    f = ivp_amd.BUILTIN[rhs]()
+    if event_direction is not None or event_terminal is not None:
+        ne = len(event_direction or event_terminal)
+        cfgs = [ivp_amd.EventConfig(ivp_amd.Direction(int(np.sign((event_direction or [0] * ne)[i]))),
+                                    (event_terminal or [0] * ne)[i] or None) for i in range(ne)]
+        f = ivp_amd.BUILTIN[rhs](*cfgs) if rhs != "ball" else ivp_amd.BUILTIN[rhs](9.81, 0.02, *cfgs)
+    else:
+        f = ivp_amd.BUILTIN[rhs]()
     o = ivp_amd.Options(fp_mode=ivp_amd.FpMode.FAST if fast else ivp_amd.FpMode.STRICT, chunk_attempts=chunk, **opts)
     if device_arrays:
         import torch
@@ -35,13 +43,16 @@ def gpu_batch(rhs, y0, params, t0, t1, *, fast=False, chunk=0, device_arrays=Fal
     r = ivp_amd.solve_ivp_batch(f, t0, t1, y0, params if f.n_params else None, o)
     out = {}
     for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct", "y_eval", "eval_idx",
-              "n_filled", "t_log", "y_log", "n_log", "seg_cont", "seg_xold", "seg_h", "n_seg", "njev", "nlu"):
+              "n_filled", "t_log", "y_log", "n_log", "seg_cont", "seg_xold", "seg_h", "n_seg", "njev", "nlu",
+              "t_events", "y_events", "n_event_hits", "t_term"):
         v = getattr(r, k)
         if v is None:
             continue
         if device_arrays:
             v = v.cpu().numpy()
         out[k] = v
+    if "n_event_hits" in out:
+        out["n_ev"] = out["n_event_hits"]
     out["stats"] = r.stats
     return out
 

@@ -58,6 +58,8 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
     a.err_flag = &err_flag;
     std::vector<double> bdf_d(8 * 8 * B), bdf_jac(64 * B), bdf_lu(64 * B);
     std::vector<uint32_t> bdf_piv(B);
+    std::vector<double> prev_event(4 * B);
+    a.prev_event = prev_event.data();
     a.bdf_d = bdf_d.data(); a.bdf_jac = bdf_jac.data(); a.bdf_lu = bdf_lu.data(); a.bdf_piv = bdf_piv.data();
     a.k1 = k1.data(); a.facold = facold.data(); a.hlamb = hlamb.data(); a.flags = flags.data();
     a.t_last = t_last.data(); a.next_idx = next_idx.data();
@@ -74,6 +76,10 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
     case 8: rc = run_rhs<RhsLinear>(method, full, a, chunks); break;
     case 9: rc = run_rhs<RhsRobertson>(method, full, a, chunks); break;
     case 10: rc = run_rhs<RhsVdpEps>(method, full, a, chunks); break;
+    case 11: rc = run_rhs<RhsShoEv>(method, full, a, chunks); break;
+    case 12: rc = run_rhs<RhsBall>(method, full, a, chunks); break;
+    case 13: rc = run_rhs<RhsCannon>(method, full, a, chunks); break;
+    case 14: rc = run_rhs<RhsRationalEv>(method, full, a, chunks); break;
     }
     if (rc == 0 && (err_flag & 0x1u)) return -5;  // IVP_ERR_INVALID_STEP_SIZE
     return rc;

@@ -29,6 +29,8 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("t_log", VP), ("y_log", VP), ("n_log", VP), ("t_last", VP),
         ("collect_dense", C.c_int32),
         ("seg_cont", VP), ("seg_xold", VP), ("seg_h", VP), ("n_seg", VP),
+        ("ev_direction", C.c_int32 * 4), ("ev_terminal", C.c_uint32 * 4), ("max_events", C.c_uint32),
+        ("t_events", VP), ("y_events", VP), ("n_ev", VP), ("prev_event", VP), ("t_term", VP),
         ("min_step", C.c_double), ("has_min_step", C.c_int32),
         ("bdf_d", VP), ("bdf_jac", VP), ("bdf_lu", VP), ("bdf_piv", VP), ("njev", VP), ("nlu", VP),
         ("err_flag", VP),
@@ -38,9 +40,10 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
 
 _libs = {}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
-       "linear": 8, "robertson": 9, "vdp_eps": 10}
+       "linear": 8, "robertson": 9, "vdp_eps": 10, "sho_ev": 11, "ball": 12, "cannon": 13, "rational_ev": 14}
 RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0),
-            8: (2, 0), 9: (3, 0), 10: (2, 1)}
+            8: (2, 0), 9: (3, 0), 10: (2, 1), 11: (2, 0), 12: (2, 2), 13: (2, 0), 14: (2, 0)}
+RHS_NE = {11: 1, 12: 1, 13: 1, 14: 3}
 METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3, "BDF": 5}
 NCOEF = {0: 4, 1: 5, 2: 8, 3: 4, 5: 7}
 
@@ -64,7 +67,8 @@ def lib(fast=False):
 
 
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
-                first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False):
+                first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False,
+                event_direction=None, event_terminal=None, max_events=16):
     L = lib(fast)
     rid = RHS[rhs]
     n, npar = RHS_DIMS[rid]
@@ -102,7 +106,8 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     a.njev, a.nlu = p(res["njev"]), p(res["nlu"])
     a.chunk = chunk
     a.n_eval = -1
-    full = t_eval is not None or max_log > 0
+    ne_ev = RHS_NE.get(rid, 0)
+    full = t_eval is not None or max_log > 0 or ne_ev > 0
     keep = []
     if full:
         res["n_filled"] = np.zeros(B, dtype=np.int32)
@@ -130,6 +135,17 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
             res["seg_h"] = np.full((max_log, B), np.nan)
             a.seg_cont, a.seg_xold, a.seg_h = p(res["seg_cont"]), p(res["seg_xold"]), p(res["seg_h"])
             a.collect_dense = 1
+    if ne_ev:
+        for i, d in enumerate((event_direction or [])[:4]):
+            a.ev_direction[i] = int(d)
+        for i, t in enumerate((event_terminal or [])[:4]):
+            a.ev_terminal[i] = int(t or 0)
+        a.max_events = max_events
+        res["t_events"] = np.full((ne_ev, max_events, B), np.nan)
+        res["y_events"] = np.full((ne_ev, max_events, n, B), np.nan)
+        res["n_ev"] = np.zeros((ne_ev, B), dtype=np.uint32)
+        res["t_term"] = np.full(B, np.nan)
+        a.t_events, a.y_events, a.n_ev, a.t_term = p(res["t_events"]), p(res["y_events"]), p(res["n_ev"]), p(res["t_term"])
     chunks = C.c_uint64(0)
     rc = L.emul_solve(m, rid, int(full), C.byref(a), C.byref(chunks))
     if rc == -5:

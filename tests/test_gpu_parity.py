@@ -16,7 +16,7 @@ import pytest
 
 from ivp_amd import workloads as W
 from oracle import oracle as O
-from tests.cases import CASES, CASE_IDS, c2_cr3bp, c3_vdp
+from tests.cases import CASES, CASE_IDS, EVENT_CASES, c2_cr3bp, c3_vdp, check_events_against_oracle
 from tests.common import assert_bitexact, gpu_batch, oracle_batch
 
 pytestmark = pytest.mark.gpu
@@ -114,6 +114,13 @@ def test_step_log_and_dense_segments_match_oracle(method, first_step):
             assert np.array_equal(g["seg_xold"][:ns, b], s.seg_xold)
             assert np.array_equal(g["seg_h"][:ns, b], s.seg_h)
             assert np.array_equal(g["seg_cont"][:ns, :, b], s.seg_cont)
+
+
+@pytest.mark.parametrize("case", EVENT_CASES, ids=[c[0] for c in EVENT_CASES])
+def test_event_detection_matches_oracle(case):
+    """Bit-exact except where the event functions themselves call pow (rational problem: ocml vs glibc pow)."""
+    exact = not case[1].startswith("rational")
+    check_events_against_oracle(lambda rhs, y0, p, t0, t1, **kw: gpu_batch(rhs, y0, p, t0, t1, chunk=7, **kw), case, exact=exact)
 
 
 # ---- against the libm-pow oracle (the faithful restatement) and against independent truth --------------

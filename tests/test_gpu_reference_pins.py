@@ -256,3 +256,69 @@ def test_unsupported_methods_and_bad_tolerances_are_config_errors():
         solve_ivp(SHO(), 0.0, 1.0, [1.0, 0.0], Options(rtol=[1e-3, 1e-3, 1e-3]))
     assert e.value.code == -4
     assert Method.from_str("rk45") == Method.DOPRI5 and Method.from_str("nonsense") == Method.DOPRI5  # options.rs:61-73
+
+
+# ---- events (src/solve/solout.rs:158-331) ------------------------------------------------------------------------
+from ivp_amd import BouncingBall, Cannon, Direction, EventConfig, RationalEvents, SHOZeroEvent  # noqa: E402
+
+
+def test_event_detection_all_and_directional():  # tests/ivp.rs:223-275
+    cfg = EventConfig(); cfg.all(); cfg.terminal_count = 2
+    sol = solve_ivp(SHOZeroEvent(cfg), 0.0, 6.0, [1.0, 0.0], default_opts(Method.DOPRI5))
+    zeros = [t for t, y in zip(sol.t_events[0], sol.y_events[0]) if abs(y[0]) <= 1e-8]
+    assert len(zeros) >= 2 and abs(zeros[0] - np.pi / 2) < 5e-3 and abs(zeros[-1] - 3 * np.pi / 2) < 5e-3
+    assert sol.status == Status.UserInterrupt and sol.status.is_success()
+    sol = solve_ivp(SHOZeroEvent(EventConfig().positive().terminal()), 0.0, 6.0, [1.0, 0.0], default_opts(Method.DOPRI5))
+    assert abs(sol.t_events[0][0] - 3 * np.pi / 2) < 5e-3
+    sol = solve_ivp(SHOZeroEvent(EventConfig().negative().terminal()), 0.0, 6.0, [1.0, 0.0], default_opts(Method.DOPRI5))
+    assert abs(sol.t_events[0][0] - np.pi / 2) < 5e-3
+
+
+def test_duplicate_timestamps_known_answers():  # tests/test_ivp.py:152-170: the reference's golden numbers
+    sol = solve_ivp(Cannon(EventConfig(Direction.Negative, 1)), 0.0, np.inf, [0.0, 0.01],
+                    Options(method="RK45", max_step=0.05 * 0.001 / 9.80665, dense_output=True))
+    np.testing.assert_allclose(sol.continuous_sol.evaluate_extrapolate(0.01), [-0.00039033, -0.08806632], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(sol.t_events[0], [0.00203943], rtol=1e-5, atol=1e-8)
+    assert sol.status == Status.UserInterrupt
+
+
+@pytest.mark.parametrize("method", EXPLICIT + [Method.BDF])
+def test_events_rational(method):  # tests/test_ivp.py:345-460
+    ev1 = lambda t, y: y[0] - y[1] ** 0.7
+    ev3 = lambda t, y: t - 7.4
+    y0 = [1 / 3, 2 / 9]
+    res = solve_ivp(RationalEvents(), 5.0, 8.0, y0, Options(method=method))
+    assert res.status == Status.Success and len(res.t_events[0]) == 1 and len(res.t_events[1]) == 1
+    assert 5.3 < res.t_events[0][0] < 5.7 and 7.3 < res.t_events[1][0] < 7.7
+    assert res.y_events[0].shape == (1, 2) and abs(ev1(res.t_events[0][0], res.y_events[0][0])) < 1e-5
+    res = solve_ivp(RationalEvents(EventConfig().positive(), EventConfig().positive()), 5.0, 8.0, y0, Options(method=method))
+    assert len(res.t_events[0]) == 1 and len(res.t_events[1]) == 0
+    res = solve_ivp(RationalEvents(EventConfig().negative(), EventConfig().negative()), 5.0, 8.0, y0, Options(method=method))
+    assert len(res.t_events[0]) == 0 and len(res.t_events[1]) == 1
+    res = solve_ivp(RationalEvents(EventConfig(), EventConfig(), EventConfig().terminal()), 5.0, 8.0, y0,
+                    Options(method=method, dense_output=True))
+    assert res.status == Status.UserInterrupt
+    assert len(res.t_events[0]) == 1 and len(res.t_events[1]) == 0 and len(res.t_events[2]) == 1
+    assert 7.3 < res.t_events[2][0] < 7.5 and abs(ev3(res.t_events[2][0], res.y_events[2][0])) < 1e-5
+    np.testing.assert_allclose(sol_rational(res.t_events[0][0]), res.y_events[0][0], rtol=1e-3, atol=1e-6)
+    tc = np.linspace(res.t[0], res.t[-1])
+    yc = np.array([res.continuous_sol.evaluate_extrapolate(t) for t in tc]).T
+    assert np.all(compute_error(yc, sol_rational(tc), 1e-3, 1e-6) < 5)
+    res = solve_ivp(RationalEvents(), 8.0, 5.0, [4 / 9, 20 / 81], Options(method=method))      # backward
+    assert len(res.t_events[0]) == 1 and len(res.t_events[1]) == 1
+
+
+def test_bouncing_ball_example_and_user_defined_events():  # examples/bouncing_ball.rs
+    sol = solve_ivp(BouncingBall(9.81, 0.02), 0.0, 10.0, [10.0, 5.0], Options(method=Method.DOPRI5, rtol=1e-8, atol=1e-10))
+    assert sol.status == Status.UserInterrupt and len(sol.t_events[0]) == 1 and abs(sol.y_events[0][0][0]) < 1e-9
+    assert sol.t[-1] == sol.t_events[0][0]
+    # the same system as a user-defined (hiprtc) problem with its own event function
+    src = r"""
+    __device__ void ode(double t, const double* s, double* d, const double* p)
+    { const double vy = s[1]; d[0] = vy; d[1] = -p[0] - p[1] * vy * fabs(vy); }
+    __device__ void events(double t, const double* s, double* g, const double* p) { g[0] = s[0]; }
+    """
+    f = ivp_amd.DeviceIVP(src, n=2, params=(9.81, 0.02), events=[EventConfig().terminal().negative()])
+    s2 = solve_ivp(f, 0.0, 10.0, [10.0, 5.0], Options(method=Method.DOPRI5, rtol=1e-8, atol=1e-10))
+    assert s2.status == Status.UserInterrupt and np.array_equal(s2.t_events[0], sol.t_events[0])
+    assert np.array_equal(s2.y, sol.y)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.cases import CASES, CASE_IDS
+from tests.cases import CASES, CASE_IDS, EVENT_CASES, check_events_against_oracle
 from tests.common import assert_bitexact, emul_batch, oracle_batch
 
 
@@ -135,3 +135,10 @@ def test_fast_mode_tracks_strict_mode(method, rtol, atol):
     assert (b["status"] == 0).all()
     assert np.abs(a["y_end"] - b["y_end"]).max() < 1e-9   # states are O(1)
     assert np.mean(a["naccpt"] == b["naccpt"]) > 0.95
+
+
+@pytest.mark.parametrize("case", EVENT_CASES, ids=[c[0] for c in EVENT_CASES])
+def test_event_detection_matches_oracle(case):
+    """Device event detection (Brent on the step interpolant, direction filter, chronological processing, terminal
+    counts, the appended terminal sample in both output modes) record for record, all five methods."""
+    check_events_against_oracle(lambda rhs, y0, p, t0, t1, **kw: emul_batch(rhs, y0, p, t0, t1, chunk=7, **kw), case)
