@@ -184,6 +184,8 @@ def main():
         }
         if args.fp == "strict" and not args.no_fast and dist is None:   # single process only (it synchronises)
             res["fast_fp_mode"] = fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all)
+        if not args.no_fast and dist is None:
+            res["pipelined"] = pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, opts.fp_mode, args)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
         sys.stdout.flush()
@@ -211,6 +213,25 @@ def fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all):
     dt = time.perf_counter() - t
     acc = float(out.naccpt.sum().item())
     return {"value": acc * k / dt, "unit": "steps/s", "ms_per_step": dt / k * 1e3, "steps": k, "this_rank_only": True}
+
+
+def pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp_mode, args, streams=4):
+    """Secondary, informational: the same K complete solves with `streams` batches in flight (ivp_amd/pipeline.py).
+    The headline `value` above keeps ONE batch in flight, i.e. it pays the full latency of every batch's tail."""
+    from ivp_amd.pipeline import BatchPipeline
+    opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp_mode, chunk_attempts=args.chunk)
+    pipe = BatchPipeline(streams, y0d.device.index or 0)
+    k = max(streams * 4, (args.steps // streams) * streams)
+    outs = [None] * streams
+    batches = [dict(t0=t0, t1=t1, y0=y0d, params=pd) for _ in range(streams)]
+    res = pipe.map(prob, batches, opts)                       # warm-up, allocates the result buffers
+    batches = [dict(t0=t0, t1=t1, y0=y0d, params=pd, out=res[i % streams]) for i in range(k)]
+    t = time.perf_counter()
+    res = pipe.map(prob, batches, opts)
+    dt = time.perf_counter() - t
+    acc = float(res[-1].naccpt.sum().item())
+    return {"streams": streams, "steps": k, "value": acc * k / dt, "unit": "steps/s", "ms_per_step": dt / k * 1e3,
+            "note": "independent batches overlapped on separate HIP streams; every solve is complete and unshared"}
 
 
 def cpu_baseline(y0, p, t0, t1):

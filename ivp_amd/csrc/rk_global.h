@@ -67,7 +67,7 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 }
 
 template <int M, class R, bool FULL>
-__global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void chunk_kernel_t(const IvpKArgs a)
+__global__ __launch_bounds__(IVP_WAVE, (M == M_BDF) ? 1 : IVP_MIN_WAVES) void chunk_kernel_t(const IvpKArgs a)
 {
     chunk_kernel_body<M, R, FULL>(a);
 }

@@ -279,3 +279,22 @@ def test_jit_syntax_error_is_reported_not_fatal():
     with pytest.raises(ivp_amd.ConfigError) as e:
         ivp_amd.DeviceIVP("__device__ void ode(double t, const double* y, double* d, const double* p) { d[0] = ; }", n=1)
     assert e.value.code == -104
+
+
+def test_pipelined_batches_give_the_same_bits_as_sequential_solves():
+    """Throughput mode (ivp_amd/pipeline.py): batches in flight on separate streams do not interact."""
+    import torch
+    import ivp_amd
+    from ivp_amd.pipeline import BatchPipeline
+    dev = torch.device("cuda:0")
+    opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9)
+    batches, refs = [], []
+    for k in range(6):
+        y0, p, t0, t1 = W.cr3bp_batch(3000 + 500 * k, seed=100 + k)
+        b = dict(t0=t0, t1=t1, y0=torch.as_tensor(y0, device=dev), params=torch.as_tensor(p, device=dev))
+        batches.append(b)
+        refs.append(ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, b["y0"], b["params"], opts))
+    res = BatchPipeline(3).map(ivp_amd.CR3BP(), batches, opts)
+    for r, ref in zip(res, refs):
+        for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct"):
+            assert torch.equal(getattr(r, k), getattr(ref, k)), k
