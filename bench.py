@@ -42,6 +42,34 @@ FLOP_PER_ATTEMPT = 86 * 6 + 6 * 45 + 13 + 38 + 2
 BYTES_PER_LANE_LAUNCH = (16 * 8 + 8 + 8 + 16 + 4) + (16 * 8 + 8 + 64 + 4)
 
 
+WORKLOADS = {
+    "c2": dict(gen="cr3bp_batch", seed=20260102, B=100_000, problem="CR3BP", method="DOPRI5", rtol=1e-6, atol=1e-9,
+               flop_per_attempt=FLOP_PER_ATTEMPT, kernel="chunk_kernel_t<DOPRI5, RhsCr3bp, lean>",
+               metric="accepted RK steps/sec (aggregate), batched CR3BP DOPRI5 @ rtol=1e-6",
+               desc="C2: 100k independent 6-state CR3BP trajectories (perturbed Arenstorf orbits, one period), "
+                    "DOPRI5 rtol=1e-6 atol=1e-9; one step = whole batch integrated to t_end"),
+    # DOP853 on the 2-state Van der Pol system: ~0.4 kFLOP per attempt (dense stages elided)
+    "c3": dict(gen="vdp_batch", seed=20260103, B=1_000_000, problem="VanDerPol", method="DOP853", rtol=1e-8, atol=1e-10,
+               flop_per_attempt=400, kernel="chunk_kernel_t<DOP853, RhsVdp, lean>",
+               metric="accepted RK steps/sec (aggregate), batched Van der Pol DOP853 @ rtol=1e-8",
+               desc="C3: 1M independent 2-state Van der Pol (mu=1) trajectories, per-trajectory t_end in [50,100], "
+                    "DOP853 rtol=1e-8 atol=1e-10"),
+    "c5": dict(gen="vdp_stiff_batch", seed=20260105, B=10_000, problem="VanDerPol", method="BDF", rtol=1e-4, atol=1e-6,
+               flop_per_attempt=None, kernel="chunk_kernel_t<BDF, RhsVdp, lean>",
+               metric="accepted BDF steps/sec (aggregate), batched stiff Van der Pol (mu~1000) @ rtol=1e-4",
+               desc="C5: 10k stiff Van der Pol (mu ~ 1000) trajectories, t in [0,3000], BDF order 1-5, rtol=1e-4 atol=1e-6"),
+}
+
+
+def bytes_per_lane_launch(n, n_params, workload):
+    """Algorithmic HBM bytes per trajectory per stepping-kernel launch: state in + state out."""
+    if workload == "c5":   # BDF: y, D[8][n], J, LU, scalars, 6 counters
+        st = (n + 8 * n + 2 * n * n + 4) * 8 + 4 + 4 + 4
+        return (st + n_params * 8 + 16 + 4) + (st + 6 * 16 + 4)
+    st = (2 * n + 4) * 8
+    return (st + n_params * 8 + 8 + 16 + 4) + (st + 8 + 64 + 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +78,8 @@ def main():
     ap.add_argument("--batch", type=int, default=100_000, help="trajectories per GPU (BASELINE C2: 100000)")
     ap.add_argument("--fp", choices=["strict", "fast"], default="strict")
     ap.add_argument("--chunk", type=int, default=0, help="step attempts per launch (0 = library default)")
+    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
+                    help="c2 = BASELINE headline (default); c3 = 1M Van der Pol DOP853 rtol 1e-8; c5 = 10k stiff Van der Pol BDF")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary fast-FP-mode measurement")
     args = ap.parse_args()
@@ -79,16 +109,21 @@ def main():
     from ivp_amd import workloads as W
 
     B = args.batch
-    # parameter sweep: rank r integrates its own B perturbed orbits (seed offset => distinct shards)
-    y0, p, t0, t1 = W.cr3bp_batch(B, seed=20260102 + rank)
+    fp = ivp_amd.FpMode.FAST if args.fp == "fast" else ivp_amd.FpMode.STRICT
+    wl = WORKLOADS[args.workload]
+    if args.workload != "c2" and args.batch == 100_000:
+        B = wl["B"]
+    # parameter sweep: rank r integrates its own B trajectories (seed offset => distinct shards)
+    y0, p, t0, t1 = getattr(W, wl["gen"])(B, seed=wl["seed"] + rank)
     y0d = torch.as_tensor(y0, device=dev)
     pd = torch.as_tensor(p, device=dev)
-    fp = ivp_amd.FpMode.FAST if args.fp == "fast" else ivp_amd.FpMode.STRICT
-    opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=fp, chunk_attempts=args.chunk, profile=1)
-    prob = ivp_amd.CR3BP()
+    t1 = torch.as_tensor(t1, device=dev) if np.ndim(t1) else t1
+    opts = ivp_amd.Options(method=wl["method"], rtol=wl["rtol"], atol=wl["atol"], fp_mode=fp, chunk_attempts=args.chunk, profile=1)
+    prob = getattr(ivp_amd, wl["problem"])()
+    n_state = prob.n
     ctx = ivp_amd.Context(local_rank)
     out = None
-    gathered = torch.empty((world, 6, B), dtype=torch.float64, device=dev) if dist is not None else None
+    gathered = torch.empty((world, n_state, B), dtype=torch.float64, device=dev) if dist is not None else None
 
     def step():
         nonlocal out
@@ -117,7 +152,7 @@ def main():
     elapsed = time.perf_counter() - t_begin
 
     acc = int(out.naccpt.sum().item())
-    attempts = float(out.nstep.sum().item()) * args.steps  # DOPRI5: nstep counts every attempt (dopri5.rs:285)
+    attempts = float(out.nstep.sum().item()) * args.steps  # DOPRI5/DOP853/BDF: nstep counts every attempt (dopri5.rs:285)
     ok = bool((out.status == 0).all().item())
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     t_acc = torch.tensor([float(acc)], dtype=torch.float64, device=dev)
@@ -133,18 +168,19 @@ def main():
         avg_launch_ms = kern_ms / max(launches, 1)
         attempts_per_launch = attempts / max(launches, 1)
         lanes_per_launch = lane_launches / max(launches, 1)  # trajectories that load + store their state
-        bytes_per_launch = lanes_per_launch * BYTES_PER_LANE_LAUNCH
+        flop_per_attempt = wl["flop_per_attempt"]
+        bytes_per_launch = lanes_per_launch * bytes_per_lane_launch(n_state, prob.n_params, args.workload)
         gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        tflops = attempts_per_launch * FLOP_PER_ATTEMPT / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        tflops = (attempts_per_launch * flop_per_attempt / (avg_launch_ms * 1e-3) / 1e12) if (avg_launch_ms > 0 and flop_per_attempt) else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes_per_launch.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.workload == "c2":
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         res = {
-            "metric": "accepted RK steps/sec (aggregate), batched CR3BP DOPRI5 @ rtol=1e-6",
+            "metric": wl["metric"],
             "value": value,
             "unit": "steps/s",
             "n_gpus": world,
@@ -157,8 +193,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C2: 100k independent 6-state CR3BP trajectories (perturbed Arenstorf orbits, one period), "
-                            "DOPRI5 rtol=1e-6 atol=1e-9; one step = whole batch integrated to t_end",
+                "workload": wl["desc"],
                 "trajectories_per_gpu": B,
                 "fp_mode": args.fp,
                 "chunk_attempts": opts.chunk_attempts or 64,
@@ -171,22 +206,22 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "chunk_kernel_t<DOPRI5, RhsCr3bp, lean>", "avg_launch_ms": avg_launch_ms,
+                "kernel": wl["kernel"], "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": launches / args.steps,
                 "note": "state is device-resident: HBM traffic is per trajectory per launch, not per step; "
                         "this fraction is informational, the binding resource is FP64 VALU issue (roofline_fp64)",
             },
             "roofline_fp64": {
                 "bound": "valu_fp64", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / FP64_PEAK_TFLOPS, "flop_per_attempt": FLOP_PER_ATTEMPT,
+                "frac": (tflops / FP64_PEAK_TFLOPS) if tflops is not None else None, "flop_per_attempt": flop_per_attempt,
                 "attempts_per_launch": attempts_per_launch,
             },
         }
-        if args.fp == "strict" and not args.no_fast and dist is None:   # single process only (it synchronises)
+        if args.fp == "strict" and not args.no_fast and dist is None and args.workload == "c2":   # single process only (it synchronises)
             res["fast_fp_mode"] = fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all)
-        if not args.no_fast and dist is None:
+        if not args.no_fast and dist is None and args.workload == "c2":
             res["pipelined"] = pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, opts.fp_mode, args)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

@@ -258,6 +258,11 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
         a.x[j] = L.x0; a.h[j] = 0.0; a.flags[j] = 0; a.status[j] = 0;
         return 0;
     }
+    if (L.x0 != L.x0 || L.xend != L.xend) {   // NaN interval: see init_body in rk_core.h
+        store_so();
+        a.x[j] = L.x0; a.h[j] = 0.0; a.flags[j] = 0; a.status[j] = 3;
+        return 3;
+    }
     const double direction = rs_signum(L.xend - L.x0);
     const double hmax = fabs(a.has_max_step ? a.max_step : fabs(L.xend - L.x0));
     R::ode(L.x0, y, f0, L.p);

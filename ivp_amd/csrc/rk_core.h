@@ -798,6 +798,17 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         return 0;
     }
 
+    if (L.x0 != L.x0 || L.xend != L.xend) {
+        // A NaN interval end makes every comparison of the reference's step loop false: it never terminates
+        // (with the default max_steps = None).  A GPU lane must retire: StepSizeTooSmall, nothing integrated.
+#pragma unroll
+        for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = 0.0; }
+        a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
+        a.status[j] = 3;
+        a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+        if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
+        return 3;
+    }
     L.posneg = rs_signum(L.xend - L.x0);
     // h_max: dopri5.rs:180 keeps the sign of max_step, dop853.rs:172-175 / rk23.rs:135 take |.|
     if (a.has_max_step) L.hmax = (M == M_DOPRI5) ? a.max_step : fabs(a.max_step);

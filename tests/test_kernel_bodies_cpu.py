@@ -142,3 +142,17 @@ def test_event_detection_matches_oracle(case):
     """Device event detection (Brent on the step interpolant, direction filter, chronological processing, terminal
     counts, the appended terminal sample in both output modes) record for record, all five methods."""
     check_events_against_oracle(lambda rhs, y0, p, t0, t1, **kw: emul_batch(rhs, y0, p, t0, t1, chunk=7, **kw), case)
+
+
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853", "RK4", "BDF"])
+def test_nan_interval_retires_the_lane(method):
+    """Documented deviation: with a NaN t0/t1 the reference's step loop never terminates; the kernels retire the
+    lane with StepSizeTooSmall and leave every other trajectory untouched."""
+    B = 5
+    y0 = np.tile(np.array([[1.0], [0.0]]), (1, B))
+    t1 = np.full(B, 2.0); t1[2] = np.nan
+    t0 = np.zeros(B); t0[4] = np.nan
+    g = emul_batch("sho", y0, None, t0, t1, method=method, rtol=1e-6, atol=1e-9)
+    assert list(g["status"]) == [0, 0, 3, 0, 3] and g["nfev"][2] == 0
+    r = oracle_batch("sho", y0[:, :2], None, 0.0, 2.0, method=method, rtol=1e-6, atol=1e-9)
+    assert np.array_equal(g["y_end"][:, :2], r["y_end"])
