@@ -122,16 +122,31 @@ def main():
     prob = getattr(ivp_amd, wl["problem"])()
     n_state = prob.n
     ctx = ivp_amd.Context(local_rank)
+    # Two result buffers: with N > 1 the RCCL all-gather of step i (C4: gather of sol.y over xGMI) is asynchronous and
+    # overlaps the integration of step i+1, which writes into the other buffer.
+    outs = [None, None]
+    works = [None, None]
+    gathered = [torch.empty((world, n_state, B), dtype=torch.float64, device=dev) for _ in range(2)] if dist is not None else None
+    step_no = [0]
     out = None
-    gathered = torch.empty((world, n_state, B), dtype=torch.float64, device=dev) if dist is not None else None
 
     def step():
         nonlocal out
-        out = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, ctx, out)
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if works[k] is not None:      # the gather that last read outs[k].y_end must have completed
+            works[k].wait()
+            works[k] = None
+        outs[k] = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, ctx, outs[k])
+        out = outs[k]
         if dist is not None:
-            dist.all_gather_into_tensor(gathered, out.y_end)  # C4: RCCL gather of sol.y over xGMI
+            works[k] = dist.all_gather_into_tensor(gathered[k], out.y_end, async_op=True)
 
     def sync_all():
+        for k in range(2):
+            if works[k] is not None:
+                works[k].wait()
+                works[k] = None
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
