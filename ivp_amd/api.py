@@ -253,7 +253,23 @@ class RationalEvents(_EventProblem):  # tests/test_ivp.py:345-353
     _ne = 3
 
 
-BUILTIN = {"sho_ev": SHOZeroEvent, "ball": BouncingBall, "cannon": Cannon, "rational_ev": RationalEvents,
+@dataclass
+class LinearDecay100(IVP):  # benches/benchmark.py:40-42,139-148 "Large Linear System (N=100)"
+    """y' = -y with 100 components: a large-n problem (one wavefront per trajectory, DOPRI5, end state only)."""
+    rhs_id = 100; n = 100; n_params = 0
+
+
+@dataclass
+class Heat1D256(IVP):
+    """Method-of-lines heat equation y_i' = kappa (y_{i-1} - 2 y_i + y_{i+1}), 256 interior nodes, zero ends."""
+    kappa: float = 1.0
+    rhs_id = 101; n = 256; n_params = 1
+    def params(self): return (self.kappa,)
+
+
+MAX_LANE_N = 8   # largest n of the thread-per-trajectory kernels; above it one wavefront owns a trajectory
+
+BUILTIN = {"linear_decay100": LinearDecay100, "heat1d256": Heat1D256, "sho_ev": SHOZeroEvent, "ball": BouncingBall, "cannon": Cannon, "rational_ev": RationalEvents,
            "linear": LinearSystem, "robertson": Robertson, "vdp_eps": StiffVanDerPol, "decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
            "zero": ZeroRhs, "rational": Rational, "exp2": Exp2}
 
@@ -264,6 +280,9 @@ class DeviceIVP(IVP):
     ``source`` is HIP device code defining
     ``__device__ void ode(double x, const double* y, double* dydx, const double* p)``;
     ``params`` are the values of the struct's fields (``p[...]`` inside ``ode``).
+    For ``8 < n <= 512`` the snippet defines the component form
+    ``__device__ double ode_comp(int i, double x, const double* y, const double* p)`` instead (one wavefront per
+    trajectory; DOPRI5, scalar tolerances, end state only).
     """
     rhs_id = 1000
 
@@ -741,6 +760,14 @@ def solve_ivp(f: IVP, x0: float, xend: float, y0: Sequence[float], options: Opti
                         nfev=0, njev=0, nlu=0, nstep=0, naccpt=0, nrejct=0, status=Status.Success, continuous_sol=cs)
     if n != f.n:
         raise ValueError(f"y0 has {n} components, problem has {f.n}")
+    if n > MAX_LANE_N:
+        # large-n problems: the kernels return the end state only, so Solution.t/y hold the two end points
+        pr = np.asarray(f.params(), dtype=np.float64).reshape(f.n_params, 1) if f.n_params else None
+        r = solve_ivp_batch(f, x0, xend, y0.reshape(n, 1), pr, options, ctx)
+        return Solution(t=np.array([x0, float(r.t_end[0])]), y=np.stack([y0, r.y_end[:, 0]]), t_events=[], y_events=[],
+                        nfev=int(r.nfev[0]), njev=0, nlu=0, nstep=int(r.nstep[0]), naccpt=int(r.naccpt[0]),
+                        nrejct=int(r.nrejct[0]), status=Status(int(r.status[0])), continuous_sol=None,
+                        h_next=float(r.h_next[0]))
 
     need_log = options.t_eval is None or options.dense_output
     cap = options.max_log or (4096 if need_log else 0)

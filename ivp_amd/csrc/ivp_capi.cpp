@@ -27,6 +27,17 @@ const RhsDim kRhsDims[IVP_RHS_BUILTIN_COUNT] = {{1, 1}, {2, 0}, {2, 1}, {6, 1}, 
                                                 {2, 0}, {2, 2}, {2, 0}, {2, 0}};
 const int kRhsEvents[IVP_RHS_BUILTIN_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 3};
 
+// wave-per-trajectory problems (rk_group.h): ids 100.., n > IVP_MAX_N
+#define IVP_MAX_GROUP_N 512
+bool group_builtin(int rhs_id, int *n, int *p)
+{
+    switch (rhs_id) {
+    case IVP_RHS_LINEAR_DECAY_100: *n = 100; *p = 0; return true;
+    case IVP_RHS_HEAT1D_256: *n = 256; *p = 1; return true;
+    }
+    return false;
+}
+
 int ncoef_of(int method) { return method == IVP_DOPRI5 ? 5 : method == IVP_DOP853 ? 8 : method == IVP_BDF ? 7 : 4; }
 
 // grow-only device buffer
@@ -103,12 +114,20 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     } else if (prob->rhs_id >= 0 && prob->rhs_id < IVP_RHS_BUILTIN_COUNT) {
         n = kRhsDims[prob->rhs_id].n;
         p = kRhsDims[prob->rhs_id].p;
+    } else if (group_builtin(prob->rhs_id, &n, &p)) {
     } else {
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown rhs_id %d", prob->rhs_id);
     }
     if (prob->n != n || prob->n_params != p)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "problem dims (n=%d,p=%d) do not match rhs (n=%d,p=%d)", prob->n, prob->n_params, n, p);
-    if (n < 1 || n > IVP_MAX_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
+    if (n < 1 || n > IVP_MAX_GROUP_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
+    if (n > IVP_MAX_N) {   // wave-per-trajectory kernels: DOPRI5, scalar tolerances, end state only
+        if (opt->method != IVP_DOPRI5 && opt->method != IVP_RADAU && opt->method >= IVP_RK23 && opt->method <= IVP_BDF)
+            return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "n = %d > %d: only DOPRI5 is available for large-n problems", n, IVP_MAX_N);
+        if (opt->rtol_vec || opt->atol_vec) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "large-n problems take scalar tolerances");
+        if (opt->t_eval || opt->dense_output || opt->max_log > 0)
+            return fail(ctx, IVP_ERR_BAD_ARGUMENT, "large-n problems return the end state only (no t_eval / log / dense output)");
+    }
     if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
     if (opt->method == IVP_RADAU)
         return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "method %d (RADAU) is not on the accelerated path", opt->method);
@@ -199,6 +218,12 @@ void ivp_options_default(ivp_options_t *o)
 
 int ivp_rhs_dims(int32_t rhs_id, int32_t *n, int32_t *np)
 {
+    int gn = 0, gp = 0;
+    if (group_builtin(rhs_id, &gn, &gp)) {
+        if (n) *n = gn;
+        if (np) *np = gp;
+        return IVP_OK;
+    }
     if (rhs_id < 0 || rhs_id >= IVP_RHS_BUILTIN_COUNT) return IVP_ERR_BAD_ARGUMENT;
     if (n) *n = kRhsDims[rhs_id].n;
     if (np) *np = kRhsDims[rhs_id].p;
@@ -229,7 +254,8 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     const bool want_eval = opt->t_eval != nullptr;
     const bool want_log = !want_eval && opt->max_log > 0 && out->t_log && out->y_log;
     const bool want_dense = opt->dense_output && opt->max_log > 0 && out->seg_cont && out->seg_xold && out->seg_h;
-    const int n_events = prob->rhs_id == IVP_RHS_JIT ? ivp_jit_n_events(prob->jit) : kRhsEvents[prob->rhs_id];
+    const bool group = n > IVP_MAX_N;
+    const int n_events = prob->rhs_id == IVP_RHS_JIT ? ivp_jit_n_events(prob->jit) : group ? 0 : kRhsEvents[prob->rhs_id];
     if (n_events > 4) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "at most 4 event functions");
     const bool full = want_eval || want_log || want_dense || n_events > 0;
     if (want_eval && opt->n_eval > 0 && !out->y_eval) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t_eval given but out.y_eval is NULL");
@@ -359,6 +385,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     const bool jit = prob->rhs_id == IVP_RHS_JIT;
     auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
         if (jit) return ivp_jit_launch(prob->jit, what, opt->method, opt->fp_mode, full, ka, lanes, s);
+        if (group) return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_group_fast : ivp_launch_group_strict)(what, prob->rhs_id, ka, lanes, s);
         return (use_hoist ? launch_hoist : launch_lean)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
     };
 
@@ -399,7 +426,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     uint64_t c = 0;  // chunk number
     bool err_checked = false;
     for (;;) {
-        const bool tail = adaptive && lanes <= kOneWavePerSimd;
+        const bool tail = adaptive && (size_t)lanes * (group ? IVP_WAVE : 1u) <= kOneWavePerSimd;
         // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
         // registers; auto = resident once at most two waves per SIMD are left to run
         // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;
@@ -510,7 +537,8 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
     struct Slot { void *host; size_t bytes; void **dev; };
     ivp_batch_result_t d;
     std::memset(&d, 0, sizeof d);
-    const size_t nev = prob->rhs_id == IVP_RHS_JIT ? (size_t)ivp_jit_n_events(prob->jit) : (size_t)kRhsEvents[prob->rhs_id];
+    const size_t nev = prob->rhs_id == IVP_RHS_JIT ? (size_t)ivp_jit_n_events(prob->jit)
+                     : n > IVP_MAX_N ? 0 : (size_t)kRhsEvents[prob->rhs_id];
     const size_t mev = opt->max_events;
     const size_t ne_rows = opt->t_eval ? ne + (nev > 0 ? 1 : 0) : 0;   // a terminal event appends one more sample
     Slot slots[24] = {
@@ -562,8 +590,9 @@ int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n
 int ivp_rhs_compile_events(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, int32_t n_events, void **handle)
 {
     if (!ctx || !ode_source || !handle) return IVP_ERR_BAD_ARGUMENT;
-    if (n < 1 || n > IVP_MAX_N || n_params < 0 || n_params > IVP_MAX_P || n_events < 0 || n_events > 4)
+    if (n < 1 || n > IVP_MAX_GROUP_N || n_params < 0 || n_params > IVP_MAX_P || n_events < 0 || n_events > 4)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
+    if (n > IVP_MAX_N && n_events > 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "large-n problems cannot carry events");
     std::string log;
     int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, n_events, handle, &log);
     if (rc != IVP_OK) ctx->err = log;

@@ -52,14 +52,28 @@ std::string build_source(const JitRhs &r, int method, bool full)
     s += "#define IVP_HD __device__ __forceinline__\n";
     s += "#define IVP_NS ivp_jit\n";
     s += "#define IVP_USER_NE " + std::to_string(r.ne) + "\n";
+    const bool group = r.n > IVP_MAX_N;   // wave-per-trajectory kernels (rk_group.h): user code defines ode_comp()
+    if (group) s += "#define IVP_HOIST 1\n";
     s += join(k_src_ivp_kargs_h);
     s += "\n// ---- user right-hand side ----\n";
     s += r.ode_source;
     s += "\n// ---- integrator ----\n";
     s += join(k_src_rk_core_h);
+    char buf[4096];
+    if (group) {
+        s += join(k_src_rk_group_h);
+        std::snprintf(buf, sizeof buf,
+                      "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d };\n"
+                      "  static __device__ __forceinline__ double ode_comp(int i, double x, const double* y, const double* p) { return ::ode_comp(i, x, y, p); }\n"
+                      "}; }\n"
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<ivp_jit::RhsUser>(a); }\n"
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<ivp_jit::RhsUser>(a); }\n",
+                      r.n, r.np);
+        s += buf;
+        return s;
+    }
     s += join(k_src_bdf_core_h);
     s += join(k_src_rk_global_h);
-    char buf[4096];
     std::snprintf(buf, sizeof buf,
                   "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d, NE = IVP_USER_NE };\n"
                   "  static IVP_HD void ode(double x, const double* y, double* d, const double* p) { ::ode(x, y, d, p); }\n"
@@ -179,7 +193,7 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool 
         }
         m = it->second;
     }
-    const unsigned grid = (lanes + IVP_WAVE - 1) / IVP_WAVE;
+    const unsigned grid = r->n > IVP_MAX_N ? lanes : (lanes + IVP_WAVE - 1) / IVP_WAVE;   // large n: one wave per trajectory
     if (grid == 0) return hipSuccess;
     IvpKArgs ka = a;
     void *args[] = {&ka};

@@ -10,3 +10,7 @@ hipError_t ivp_launch_strict(int what, int method, int rhs_id, bool full, const 
 hipError_t ivp_launch_strict_hoist(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 hipError_t ivp_launch_fast_hoist(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 hipError_t ivp_launch_fast(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+
+// wave-per-trajectory kernels (rk_group.hip): grid = `trajectories` one-wave blocks; DOPRI5, end state only
+hipError_t ivp_launch_group_strict(int what, int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+hipError_t ivp_launch_group_fast(int what, int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);

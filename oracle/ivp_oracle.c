@@ -211,6 +211,20 @@ static void rhs_cannon(double t, const double *y, double *d, const double *p)
     d[0] = y[1];
     d[1] = -9.80665;
 }
+static void rhs_linear_decay100(double t, const double *y, double *d, const double *p)
+{   /* benches/benchmark.py:40-42,139-148: y' = -y, N = 100 */
+    (void)t; (void)p;
+    for (int i = 0; i < 100; i++) d[i] = -y[i];
+}
+static void rhs_heat1d256(double t, const double *y, double *d, const double *p)
+{   /* method-of-lines heat equation, Dirichlet ends (no reference counterpart: a coupled large-n case) */
+    (void)t;
+    for (int i = 0; i < 256; i++) {
+        double left = i > 0 ? y[i - 1] : 0.0;
+        double right = i < 255 ? y[i + 1] : 0.0;
+        d[i] = p[0] * (left - 2.0 * y[i] + right);
+    }
+}
 /* event functions: trait IVP::events (src/ivp.rs:31-40) */
 static void ev_y0(double x, const double *y, double *g, const double *p)
 {   /* tests/ivp.rs:157-159, examples/bouncing_ball.rs:17-19, tests/test_ivp.py:156-157 */
@@ -241,6 +255,8 @@ orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *np_out)
         {rhs_linear, 2, 0}, {rhs_robertson, 3, 0}, {rhs_vdp_eps, 2, 1},
         {rhs_sho, 2, 0}, {rhs_ball, 2, 2}, {rhs_cannon, 2, 0}, {rhs_rational, 2, 0},
     };
+    if (rhs_id == ORC_RHS_LINEAR_DECAY_100) { if (n_out) *n_out = 100; if (np_out) *np_out = 0; return rhs_linear_decay100; }
+    if (rhs_id == ORC_RHS_HEAT1D_256) { if (n_out) *n_out = 256; if (np_out) *np_out = 1; return rhs_heat1d256; }
     if (rhs_id < 0 || rhs_id >= ORC_RHS_COUNT) return NULL;
     if (n_out) *n_out = tab[rhs_id].n;
     if (np_out) *np_out = tab[rhs_id].np;
@@ -355,7 +371,7 @@ typedef struct {
     double prev_event[ORC_MAX_EVENTS];
     uint64_t event_hits[ORC_MAX_EVENTS];
     int has_yold;
-    double yold[64];
+    double yold[ORC_MAX_N];
     size_t ev_len[ORC_MAX_EVENTS], ev_cap[ORC_MAX_EVENTS];
     double *t_events[ORC_MAX_EVENTS];
     double *y_events[ORC_MAX_EVENTS];
@@ -410,7 +426,7 @@ static int so_call2(solout_t *s, double xold, double x, const double *y,
         if (!s->has_yold) {
             memcpy(s->prev_event, g_curr, sizeof(double) * (size_t)s->n_events);
         } else {
-            double det_t[ORC_MAX_EVENTS], det_y[ORC_MAX_EVENTS][64];
+            double det_t[ORC_MAX_EVENTS], det_y[ORC_MAX_EVENTS][ORC_MAX_N];
             int det_i[ORC_MAX_EVENTS], ndet = 0;
             for (int i = 0; i < s->n_events; i++) {
                 double g_prev = s->prev_event[i], g_cur = g_curr[i];
@@ -421,7 +437,7 @@ static int so_call2(solout_t *s, double xold, double x, const double *y,
                 if (!crossed) continue;
                 const double XTOL = 2e-12, RTOL = 2.220446049250313e-16;
                 double a = xold, b = x, fa = g_prev, fb = g_cur;
-                double ymid[64], gmid[ORC_MAX_EVENTS];
+                double ymid[ORC_MAX_N], gmid[ORC_MAX_EVENTS];
                 if (fabs(fa) <= XTOL) { det_t[ndet] = a; memcpy(det_y[ndet], s->yold, sizeof(double) * (size_t)n); }
                 else if (fabs(fb) <= XTOL) { det_t[ndet] = b; memcpy(det_y[ndet], y, sizeof(double) * (size_t)n); }
                 else {   /* Brent's method (matches SciPy's brentq), solout.rs:204-291 */
@@ -470,7 +486,7 @@ static int so_call2(solout_t *s, double xold, double x, const double *y,
                     if (!swap) break;
                     double tt = det_t[v]; det_t[v] = det_t[v - 1]; det_t[v - 1] = tt;
                     int ti = det_i[v]; det_i[v] = det_i[v - 1]; det_i[v - 1] = ti;
-                    double ty[64]; memcpy(ty, det_y[v], sizeof ty); memcpy(det_y[v], det_y[v - 1], sizeof ty); memcpy(det_y[v - 1], ty, sizeof ty);
+                    double ty[ORC_MAX_N]; memcpy(ty, det_y[v], sizeof ty); memcpy(det_y[v], det_y[v - 1], sizeof ty); memcpy(det_y[v - 1], ty, sizeof ty);
                 }
             for (int u = 0; u < ndet; u++) {
                 int i = det_i[u];
@@ -495,7 +511,7 @@ static int so_call2(solout_t *s, double xold, double x, const double *y,
     memcpy(s->yold, y, sizeof(double) * (size_t)n);
     s->has_yold = 1;
 
-    double yi[64];
+    double yi[ORC_MAX_N];
     if (s->n_eval >= 0) {
         /* Mode 1, solout.rs:344-386 */
         size_t i = s->next_idx;
@@ -1242,7 +1258,7 @@ static void lin_solve(const double *a, double *b, const int *ip, int n)
 /* Default finite-difference Jacobian, trait IVP::jac (src/ivp.rs:67-107). */
 static void fd_jac(orc_ode_fn f, const double *p, int n, double x, const double *y, double *jac)
 {
-    double yp[64], fp[64], fo[64];
+    double yp[ORC_MAX_N], fp[ORC_MAX_N], fo[ORC_MAX_N];
     memcpy(yp, y, (size_t)n * sizeof(double));
     f(x, y, fo, p);
     const double eps = sqrt(2.220446049250313e-16);
@@ -1298,7 +1314,7 @@ static void change_d(double *d /* [8][n] */, int n, int order, double factor)
             if (coeff == 0.0) continue;
             for (int j = 0; j < size; j++) ru[i][j] += coeff * u[k][j];
         }
-    double scratch[6][64];
+    double scratch[6][ORC_MAX_N];
     for (int row = 0; row <= order; row++) {
         for (int i = 0; i < n; i++) scratch[row][i] = 0.0;
         for (int k = 0; k <= order; k++) {
@@ -1332,7 +1348,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
     double *y = w, *f0 = w + n, *psi = w + 2 * n, *scale = w + 3 * n, *y_predict = w + 4 * n, *y_new = w + 5 * n,
            *delta = w + 6 * n, *rhs = w + 7 * n, *d = w + 8 * n, *cont = w + 16 * n, *jac = w + 23 * n,
            *lu = w + 23 * n + (size_t)n * n;
-    int pivot[64];
+    int pivot[ORC_MAX_N];
     memcpy(y, y0, (size_t)n * sizeof(double));
     f(x, y, f0, p);
     nfev += 1;
@@ -1359,7 +1375,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
         if (opt->first_step == 0.0) { free(w); return ORC_ERR_INVALID_STEP_SIZE; }
         h_abs = fabs(opt->first_step);
     } else {
-        double f1[64], y1[64];
+        double f1[ORC_MAX_N], y1[ORC_MAX_N];
         double guess = hinit(f, p, n, x, y, direction, f0, f1, y1, 1, hmax, atol, rtol);
         double max_h = fabs(xend - x);
         if (fabs(guess) > max_h) guess = max_h * direction;
@@ -1573,7 +1589,7 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     memset(sol, 0, sizeof(*sol));
     sol->n = n;
     sol->ncoef = ncoef_of(opt->method);
-    if (n > 64) return ORC_ERR_BAD_ARGUMENT;
+    if (n > ORC_MAX_N) return ORC_ERR_BAD_ARGUMENT;
     if (opt->method < ORC_RK23 || opt->method > ORC_BDF || opt->method == ORC_RADAU) return ORC_ERR_BAD_ARGUMENT;
 
     if (fabs(xend - x0) < 1e-15) { /* solve_ivp.rs:110-145 */
@@ -1634,7 +1650,7 @@ static int solve_core(orc_ode_fn f, const double *params, int n, double x0, doub
     for (int i = 0; i < ORC_MAX_EVENTS; i++) { so.ev_direction[i] = opt->ev_direction[i]; so.ev_terminal[i] = opt->ev_terminal[i]; }
 
     int_result r;
-    double yf[64], xf = x0;
+    double yf[ORC_MAX_N], xf = x0;
     int rc;
     if (opt->method == ORC_DOPRI5) rc = dopri5_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
     else if (opt->method == ORC_DOP853) rc = dop853_solve(f, params, n, x0, y0, xend, &rtol, &atol, opt, &so, &r, yf, &xf);
@@ -1746,7 +1762,7 @@ int64_t orc_batch_solve(int rhs_id, size_t B, const double *y0, const double *pa
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : total)
 #endif
     for (long long b = 0; b < (long long)B; b++) {
-        double y0b[8], pb[4], yf[8], xf;
+        double y0b[ORC_MAX_N], pb[4], yf[ORC_MAX_N], xf;
         for (int i = 0; i < n; i++) y0b[i] = y0[(size_t)i * B + (size_t)b];
         for (int i = 0; i < np; i++) pb[i] = params[(size_t)i * B + (size_t)b];
         double a = t0_len == 1 ? t0[0] : t0[b];

@@ -70,12 +70,16 @@ enum {
     ORC_RHS_BALL = 12,    /* examples/bouncing_ball.rs            p={g,drag}     n=2, event g = y0 */
     ORC_RHS_CANNON = 13,  /* tests/test_ivp.py:152-170                           n=2, event g = y0 */
     ORC_RHS_RATIONAL_EV = 14, /* tests/test_ivp.py:345-353: rational + 3 events  n=2 */
-    ORC_RHS_COUNT = 15
+    ORC_RHS_COUNT = 15,
+    /* large-n problems (wave-per-trajectory kernels on the GPU side) */
+    ORC_RHS_LINEAR_DECAY_100 = 100, /* benches/benchmark.py:40-42,139-148             n=100 */
+    ORC_RHS_HEAT1D_256 = 101        /* y_i' = kappa (y_{i-1} - 2 y_i + y_{i+1}), p={kappa}  n=256 */
 };
 
 typedef void (*orc_ode_fn)(double x, const double *y, double *dydx, const double *p);
 typedef void (*orc_event_fn)(double x, const double *y, double *g, const double *p);   /* IVP::events, src/ivp.rs:31-40 */
 #define ORC_MAX_EVENTS 4
+#define ORC_MAX_N 512   /* largest state dimension the fixed-size work arrays accept */
 
 typedef struct {
     int method;           /* ORC_RK23 / ORC_DOPRI5 / ORC_DOP853 */

@@ -1,0 +1,130 @@
+"""Wave-per-trajectory kernels (rk_group.h: 8 < n <= 512, one wavefront per trajectory) against the oracle.
+
+STRICT: the per-component arithmetic is the reference's and the error-norm sum runs in index order, so results are
+bit-exact with the oracle's detpow build.  FAST uses a __shfl_xor butterfly for the norm: compared by tolerance."""
+import numpy as np
+import pytest
+
+from tests.common import assert_bitexact, gpu_batch, oracle_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _decay_batch(B, seed=3):
+    rng = np.random.default_rng(seed)
+    y0 = rng.uniform(-2.0, 2.0, (100, B))
+    t1 = rng.uniform(0.5, 12.0, B)
+    return y0, None, 0.0, t1
+
+
+def _heat_batch(B, seed=5):
+    rng = np.random.default_rng(seed)
+    x = np.arange(1, 257) / 257.0
+    modes = rng.integers(1, 6, B)
+    y0 = np.sin(np.pi * x[:, None] * modes[None, :]) + 0.1 * rng.standard_normal((256, B))
+    kappa = rng.uniform(20.0, 400.0, (1, B))
+    t1 = rng.uniform(0.05, 0.5, B)
+    return y0, kappa, 0.0, t1
+
+
+@pytest.mark.parametrize("tol", [(1e-3, 1e-6), (1e-6, 1e-9), (1e-10, 1e-12)])
+def test_linear_decay100_bitexact(tol):
+    """benches/benchmark.py:139-148 (N = 100, RK45) generalised to a batch with ragged horizons."""
+    y0, p, t0, t1 = _decay_batch(300)
+    ref = oracle_batch("linear_decay100", y0, p, t0, t1, method="DOPRI5", rtol=tol[0], atol=tol[1])
+    got = gpu_batch("linear_decay100", y0, p, t0, t1, method="DOPRI5", rtol=tol[0], atol=tol[1])
+    assert_bitexact(got, ref, "decay100 ")
+    assert (got["status"] == 0).all()
+    np.testing.assert_allclose(got["y_end"], y0 * np.exp(-t1)[None, :], rtol=0, atol=50 * tol[0])
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64, 0])
+def test_heat1d256_bitexact_any_chunk(chunk):
+    y0, p, t0, t1 = _heat_batch(200)
+    ref = oracle_batch("heat1d256", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9)
+    got = gpu_batch("heat1d256", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, chunk=chunk)
+    assert_bitexact(got, ref, f"heat chunk={chunk} ")
+    assert ref["nrejct"].sum() > 0          # the case exercises the reject branch
+
+
+def test_heat1d256_stiffness_detection_matches():
+    """kappa large enough that DOPRI5's stiffness test fires (dopri5.rs:364-391): status ProbablyStiff at the same
+    step, same state."""
+    y0, p, t0, _ = _heat_batch(64)
+    p[:] = 4000.0
+    ref = oracle_batch("heat1d256", y0, p, t0, 20.0, method="DOPRI5", rtol=1e-4, atol=1e-7)
+    got = gpu_batch("heat1d256", y0, p, t0, 20.0, method="DOPRI5", rtol=1e-4, atol=1e-7)
+    assert_bitexact(got, ref, "heat stiff ")
+    assert (ref["status"] == 4).any()
+
+
+def test_large_n_options_first_step_max_step_max_steps_backward():
+    y0, p, t0, t1 = _decay_batch(64, seed=9)
+    for kw in (dict(first_step=1e-3), dict(max_step=0.05), dict(max_steps=20), dict(first_step=0.2, max_step=0.3)):
+        ref = oracle_batch("linear_decay100", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, **kw)
+        got = gpu_batch("linear_decay100", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, **kw)
+        assert_bitexact(got, ref, f"{kw} ")
+    # backward in time and a zero-length interval
+    t1b = -np.abs(t1) * 0.3
+    t1b[::7] = 0.0
+    ref = oracle_batch("linear_decay100", y0, p, 0.0, t1b, method="DOPRI5", rtol=1e-6, atol=1e-9)
+    got = gpu_batch("linear_decay100", y0, p, 0.0, t1b, method="DOPRI5", rtol=1e-6, atol=1e-9)
+    assert_bitexact(got, ref, "backward ")
+
+
+def test_large_n_device_arrays_and_fast_mode():
+    y0, p, t0, t1 = _heat_batch(500, seed=11)
+    ref = oracle_batch("heat1d256", y0, p, t0, t1, method="DOPRI5", rtol=1e-8, atol=1e-10)
+    got = gpu_batch("heat1d256", y0, p, t0, t1, method="DOPRI5", rtol=1e-8, atol=1e-10, device_arrays=True)
+    assert_bitexact(got, ref, "heat device ")
+    fast = gpu_batch("heat1d256", y0, p, t0, t1, method="DOPRI5", rtol=1e-8, atol=1e-10, device_arrays=True, fast=True)
+    assert (fast["status"] == 0).all()
+    # FMA contraction + tree-order norm: the step sequence of this stability-limited problem shifts slightly, the
+    # answers agree at the level of the requested tolerance (rtol 1e-8 on O(1) states)
+    np.testing.assert_allclose(fast["y_end"], ref["y_end"], rtol=0, atol=1e-7)
+    assert abs(int(fast["naccpt"].sum()) - int(ref["naccpt"].sum())) <= 0.02 * ref["naccpt"].sum()
+
+
+def test_large_n_unsupported_requests_fail_loudly():
+    import ivp_amd
+    y0 = np.ones((100, 4))
+    f = ivp_amd.LinearDecay100()
+    with pytest.raises(ivp_amd.ConfigError) as e:
+        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOP853"))
+    assert e.value.code == -101
+    for bad in (dict(t_eval=[0.5]), dict(max_log=16), dict(rtol=[1e-6] * 100)):
+        with pytest.raises(ivp_amd.ConfigError):
+            ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOPRI5", **bad))
+
+
+def test_large_n_single_solve_ivp_and_jit_component_form():
+    """`impl IVP` for n = 40 as a device snippet in component form: a ring of coupled oscillators."""
+    import ivp_amd
+    s = ivp_amd.solve_ivp(ivp_amd.LinearDecay100(), 0.0, 5.0, np.linspace(0, 1, 100), ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
+    from oracle import oracle as O
+    o = O.solve_ivp("linear_decay100", 0.0, 5.0, list(np.linspace(0, 1, 100)), method="DOPRI5", rtol=1e-6, atol=1e-9, detpow=True)
+    assert (s.naccpt, s.nrejct, s.nfev, int(s.status)) == (o.naccpt, o.nrejct, o.nfev, o.status)
+    assert np.array_equal(s.y[-1], o.y[-1]) and s.t[-1] == 5.0
+
+    src = r'''
+    __device__ double ode_comp(int i, double t, const double* y, const double* p)
+    {   // 20 masses on a ring: y[0..20) positions, y[20..40) velocities
+        if (i < 20) return y[20 + i];
+        const int k = i - 20, l = (k + 19) % 20, r = (k + 1) % 20;
+        return p[0] * (y[l] - 2.0 * y[k] + y[r]);
+    }'''
+    f = ivp_amd.DeviceIVP(src, n=40, params=(3.0,))
+
+    def ring(t, y, p):
+        d = np.empty(40)
+        d[:20] = y[20:]
+        q = y[:20]
+        d[20:] = p[0] * (np.roll(q, 1) - 2.0 * q + np.roll(q, -1))
+        return d
+    rng = np.random.default_rng(2)
+    y0 = rng.standard_normal(40)
+    s = ivp_amd.solve_ivp(f, 0.0, 4.0, y0, ivp_amd.Options(method="DOPRI5", rtol=1e-7, atol=1e-9))
+    o = O.solve_ivp(ring, 0.0, 4.0, list(y0), params=[3.0], method="DOPRI5", rtol=1e-7, atol=1e-9, detpow=True)
+    assert int(s.status) == 0 and (s.naccpt, s.nrejct, s.nfev) == (o.naccpt, o.nrejct, o.nfev)
+    # numpy's roll-based RHS adds in the same order as the snippet: bit-exact end state
+    assert np.array_equal(s.y[-1], o.y[-1])

@@ -338,3 +338,26 @@ def test_bouncing_ball_example():  # examples/bouncing_ball.rs
                     event_direction=[-1], event_terminal=[1])
     assert s.status == 1 and len(s.t_events[0]) == 1 and abs(s.y_events[0][0][0]) < 1e-9
     assert s.t[-1] == s.t_events[0][0]      # terminal event point is appended to the output (solout.rs:317-319)
+
+
+# ---- large-n problems (wave-per-trajectory kernels on the GPU side) -------------------------------------------------
+def test_benchmark_problem4_large_linear_system():
+    """benches/benchmark.py:139-148: y' = -y, N = 100, y0 = ones, t in [0, 10], RK45, rtol 1e-6 / atol 1e-8."""
+    s = O.solve_ivp("linear_decay100", 0.0, 10.0, [1.0] * 100, method="DOPRI5", rtol=1e-6, atol=1e-8)
+    assert s.status == 0 and s.t[-1] == 10.0
+    assert np.abs(s.y[-1] - np.exp(-10.0)).max() < 1e-6
+    # all components are identical, so the RMS norm equals the scalar problem's: same step sequence as n = 1
+    s1 = O.solve_ivp("decay", 0.0, 10.0, [1.0], params=[1.0], method="DOPRI5", rtol=1e-6, atol=1e-8)
+    assert (s.naccpt, s.nrejct) == (s1.naccpt, s1.nrejct)
+    np.testing.assert_allclose(s.y[-1], s1.y[-1, 0], rtol=1e-13)
+
+
+def test_heat1d256_oracle_against_closed_form():
+    """Eigenmode of the discrete Laplacian decays as exp(-kappa (2 - 2 cos(pi m / 257)) t)."""
+    x = np.arange(1, 257) / 257.0
+    for m, kappa in ((1, 100.0), (3, 40.0)):
+        y0 = np.sin(np.pi * m * x)
+        s = O.solve_ivp("heat1d256", 0.0, 0.5, list(y0), params=[kappa], method="DOPRI5", rtol=1e-8, atol=1e-11)
+        lam = kappa * (2.0 - 2.0 * np.cos(np.pi * m / 257.0))
+        assert s.status == 0
+        assert np.abs(s.y[-1] - y0 * np.exp(-lam * 0.5)).max() < 1e-7
