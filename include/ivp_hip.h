@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IVP_HIP_ABI_VERSION 1
+#define IVP_HIP_ABI_VERSION 2
 
 /* Method: same order as `enum Method`, src/solve/options.rs:14-27. The explicit RK methods (RK23, DOPRI5,
  * DOP853, the fixed-step RK4) and the variable-order implicit BDF are on the accelerated path; RADAU returns
@@ -149,6 +149,20 @@ typedef struct {
     int32_t variant;        /* stepping-kernel variant: 0 = auto, 1 = lean registers, 2 = coefficients resident */
     int32_t profile;        /* 1: time every kernel launch with HIP events (see ivp_run_stats_t);
                                2: additionally sum naccpt / attempts over the batch on the host */
+    /* ---- direct per-method call: `DOPRI5 {..}.solve()`, `DOP853 {..}.solve()`, `RK23 {..}.solve()` ----
+     * (src/methods/dopri5.rs:34-72,122-198, dop853.rs:34-63,114-193, rk23.rs:17-37,81-129).
+     * has_settings == 0 (default): the struct defaults, i.e. exactly what solve_ivp() runs.
+     * has_settings != 0: the fields below replace the struct's controller fields and are validated like
+     * XXX::solve() validates them (OutOfRange / MustBePositive / InvalidScaleFactors); max_steps is then the struct's
+     * `usize` field taken literally (0 => IVP_ERR_MUST_BE_POSITIVE).  Fill with ivp_options_method_defaults() first.
+     * RK23 reads safety_factor / scale_min / scale_max only; RK4 / BDF reject has_settings. */
+    int32_t has_settings;
+    double uround;          /* default 2.3e-16                                   */
+    double safety_factor;   /* default 0.9                                       */
+    double scale_min;       /* default 0.2 (DOPRI5, RK23), 0.333 (DOP853)        */
+    double scale_max;       /* default 10  (DOPRI5, RK23), 6 (DOP853)            */
+    double beta;            /* default 0.04 (DOPRI5), 0 (DOP853)                 */
+    uint64_t stiff_test;    /* default 1000                                      */
 } ivp_options_t;
 
 /* Per-trajectory results: `struct Solution` (src/solve/solution.rs:7-20) + IntegrationResult.h
@@ -215,6 +229,9 @@ int ivp_ctx_get_stats(const ivp_ctx_t *ctx, ivp_run_stats_t *stats);
 
 /* Options::builder().build() defaults (src/solve/options.rs:75-123). */
 void ivp_options_default(ivp_options_t *opt);
+
+/* Sets method and fills uround .. stiff_test with that method's struct defaults (has_settings stays as it is). */
+int ivp_options_method_defaults(ivp_options_t *opt, int32_t method);
 
 /* Dimension lookup for built-in right-hand sides; ivp_rhs_n_events = IVP::n_events() (src/ivp.rs:42-46). */
 int ivp_rhs_dims(int32_t rhs_id, int32_t *n, int32_t *n_params);

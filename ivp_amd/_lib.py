@@ -35,6 +35,8 @@ class OptionsT(C.Structure):
         ("ev_direction", C.c_int32 * 4), ("ev_terminal", C.c_uint32 * 4), ("max_events", C.c_uint32),
         ("has_min_step", C.c_int32), ("min_step", C.c_double),
         ("fp_mode", C.c_int32), ("chunk_attempts", C.c_int32), ("max_log", C.c_uint32), ("variant", C.c_int32), ("profile", C.c_int32),
+        ("has_settings", C.c_int32), ("uround", C.c_double), ("safety_factor", C.c_double), ("scale_min", C.c_double),
+        ("scale_max", C.c_double), ("beta", C.c_double), ("stiff_test", C.c_uint64),
     ]
 
 
@@ -57,7 +59,7 @@ class RunStatsT(C.Structure):
 # every symbol include/ivp_hip.h declares
 EXPORTS = (
     "ivp_abi_version", "ivp_device_count", "ivp_ctx_create", "ivp_ctx_destroy", "ivp_last_error_string",
-    "ivp_ctx_get_stats", "ivp_options_default", "ivp_rhs_dims", "ivp_rhs_n_events", "ivp_batch_solve",
+    "ivp_ctx_get_stats", "ivp_options_default", "ivp_options_method_defaults", "ivp_rhs_dims", "ivp_rhs_n_events", "ivp_batch_solve",
     "ivp_batch_solve_device", "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_free",
 )
 
@@ -109,6 +111,8 @@ def load():
     L.ivp_ctx_get_stats.argtypes = [C.c_void_p, C.POINTER(RunStatsT)]
     L.ivp_options_default.restype = None
     L.ivp_options_default.argtypes = [C.POINTER(OptionsT)]
+    L.ivp_options_method_defaults.restype = C.c_int
+    L.ivp_options_method_defaults.argtypes = [C.POINTER(OptionsT), C.c_int32]
     L.ivp_rhs_dims.restype = C.c_int
     L.ivp_rhs_dims.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     solve_args = [C.c_void_p, C.POINTER(ProblemT), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -337,6 +337,11 @@ class Options:
     max_step: Optional[float] = None
     min_step: Optional[float] = None      # read by BDF only (src/solve/solve_ivp.rs:271)
     dense_output: bool = False
+    # A direct per-method call -- ``DOPRI5::builder().safety_factor(0.8).build().solve(..)`` (dopri5.rs:34-72,
+    # dop853.rs:34-63, rk23.rs:17-37): a dict with any of uround / safety_factor / scale_min / scale_max / beta /
+    # stiff_test; missing keys take the struct's defaults, and max_steps then defaults to the struct's 100_000
+    # (RK23: 10_000) instead of solve_ivp's unlimited.  None = what solve_ivp() runs.
+    settings: Optional[dict] = None
     # GPU-only
     fp_mode: FpMode = FpMode.STRICT
     chunk_attempts: int = 0
@@ -376,6 +381,19 @@ class Options:
         o.dense_output = int(bool(self.dense_output))
         if self.min_step is not None:
             o.has_min_step, o.min_step = 1, float(self.min_step)
+        if self.settings is not None:
+            if m not in (Method.RK23, Method.DOPRI5, Method.DOP853):
+                raise ConfigError(-100, "settings apply to RK23 / DOPRI5 / DOP853")
+            rc = _lib.load().ivp_options_method_defaults(C.byref(o), int(m))
+            if rc != 0:
+                raise ConfigError(rc, "ivp_options_method_defaults failed")
+            for key, val in self.settings.items():
+                if key not in ("uround", "safety_factor", "scale_min", "scale_max", "beta", "stiff_test"):
+                    raise ValueError(f"unknown method setting {key!r}")
+                setattr(o, key, int(val) if key == "stiff_test" else float(val))
+            o.has_settings = 1
+            if self.max_steps is None:
+                o.max_steps = 10_000 if m == Method.RK23 else 100_000
         o.fp_mode = int(self.fp_mode)
         o.chunk_attempts = int(self.chunk_attempts)
         o.max_log = int(self.max_log)

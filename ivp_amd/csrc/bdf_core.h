@@ -658,11 +658,11 @@ IVP_HD int32_t any_init_body(const IvpKArgs &a, uint32_t j)
     if constexpr (M == M_BDF) return bdf_init_body<R, FULL>(a, j);
     else return init_body<M, R, FULL>(a, j);
 }
-template <int M, class R, bool FULL>
+template <int M, class R, bool FULL, bool CTL = false>
 IVP_HD uint32_t any_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     if constexpr (M == M_BDF) return bdf_chunk_body<R, FULL>(a, j, status_out);
-    else return chunk_body<M, R, FULL>(a, j, status_out);
+    else return chunk_body<M, R, FULL, CTL>(a, j, status_out);
 }
 
 }  // namespace IVP_NS

@@ -38,6 +38,20 @@ bool group_builtin(int rhs_id, int *n, int *p)
     return false;
 }
 
+// controller fields of the method structs (dopri5.rs:34-72, dop853.rs:34-63, rk23.rs:17-37)
+struct MethodSettings { double uround, safety, scale_min, scale_max, beta; uint64_t nstiff; };
+MethodSettings method_defaults(int method)
+{
+    if (method == IVP_DOP853) return {2.3e-16, 0.9, 0.333, 6.0, 0.0, 1000};
+    if (method == IVP_DOPRI5) return {2.3e-16, 0.9, 0.2, 10.0, 0.04, 1000};
+    return {2.3e-16, 0.9, 0.2, 10.0, 0.0, 1000};   // RK23 (reads safety / scale_min / scale_max only)
+}
+MethodSettings settings_of(const ivp_options_t *opt)
+{
+    if (!opt->has_settings) return method_defaults(opt->method);
+    return {opt->uround, opt->safety_factor, opt->scale_min, opt->scale_max, opt->beta, opt->stiff_test};
+}
+
 int ncoef_of(int method) { return method == IVP_DOPRI5 ? 5 : method == IVP_DOP853 ? 8 : method == IVP_BDF ? 7 : 4; }
 
 // grow-only device buffer
@@ -139,6 +153,23 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
             if (rt < 0.0 || at < 0.0) return fail(ctx, IVP_ERR_NEGATIVE_TOLERANCE, "negative tolerance at component %d", i);
         }
     }
+    if (opt->has_settings) {   // XXX::solve() input validation, in the reference's order
+        const MethodSettings m = settings_of(opt);
+        if (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853) {   // dopri5.rs:143-198, dop853.rs:135-193
+            if (m.uround <= 1e-35 || m.uround >= 1.0) return fail(ctx, IVP_ERR_OUT_OF_RANGE, "uround = %g outside (1e-35, 1)", m.uround);
+            if (m.safety >= 1.0 || m.safety <= 1e-4) return fail(ctx, IVP_ERR_OUT_OF_RANGE, "safety_factor = %g outside (1e-4, 1)", m.safety);
+            if (m.beta > 0.2) return fail(ctx, IVP_ERR_OUT_OF_RANGE, "beta = %g outside [0, 0.2]", m.beta);
+            if (opt->max_steps == 0) return fail(ctx, IVP_ERR_MUST_BE_POSITIVE, "max_steps must be positive");
+            if (m.nstiff == 0) return fail(ctx, IVP_ERR_MUST_BE_POSITIVE, "stiff_test must be positive");
+        } else if (opt->method == IVP_RK23) {                           // rk23.rs:102-129
+            if (opt->max_steps == 0) return fail(ctx, IVP_ERR_MUST_BE_POSITIVE, "max_steps must be positive");
+            if (m.safety >= 1.0 || m.safety <= 1e-4) return fail(ctx, IVP_ERR_OUT_OF_RANGE, "safety_factor = %g outside (1e-4, 1)", m.safety);
+            if (m.scale_min <= 0.0 || m.scale_max <= m.scale_min)
+                return fail(ctx, IVP_ERR_INVALID_SCALE_FACTORS, "scale factors min = %g, max = %g", m.scale_min, m.scale_max);
+        } else {
+            return fail(ctx, IVP_ERR_BAD_ARGUMENT, "has_settings applies to RK23 / DOPRI5 / DOP853");
+        }
+    }
     if (opt->rtol_vec && opt->rtol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "rtol: expected %d, got %d", n, opt->rtol_vec_len);
     if (opt->atol_vec && opt->atol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "atol: expected %d, got %d", n, opt->atol_vec_len);
     if (opt->t_eval && opt->n_eval < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative n_eval");
@@ -216,6 +247,20 @@ void ivp_options_default(ivp_options_t *o)
     o->fp_mode = IVP_FP_STRICT;
 }
 
+int ivp_options_method_defaults(ivp_options_t *o, int32_t method)
+{
+    if (!o || (method != IVP_RK23 && method != IVP_DOPRI5 && method != IVP_DOP853)) return IVP_ERR_BAD_ARGUMENT;
+    const MethodSettings m = method_defaults(method);
+    o->method = method;
+    o->uround = m.uround;
+    o->safety_factor = m.safety;
+    o->scale_min = m.scale_min;
+    o->scale_max = m.scale_max;
+    o->beta = m.beta;
+    o->stiff_test = m.nstiff;
+    return IVP_OK;
+}
+
 int ivp_rhs_dims(int32_t rhs_id, int32_t *n, int32_t *np)
 {
     int gn = 0, gp = 0;
@@ -281,6 +326,20 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     a.nmax = opt->max_steps ? opt->max_steps : UINT64_MAX;  // None => usize::MAX, solve_ivp.rs:218
     a.min_step = opt->min_step;
     a.has_min_step = opt->has_min_step ? 1 : 0;
+    {   // controller settings: IEEE operations exactly as XXX::solve() derives them (no contraction on the host)
+        const MethodSettings m = settings_of(opt);
+        volatile double prod = m.beta * (opt->method == IVP_DOP853 ? 0.2 : 0.75);
+        a.ctl_uround = m.uround;
+        a.ctl_safety = m.safety;
+        a.ctl_facc1 = 1.0 / m.scale_min;
+        a.ctl_facc2 = 1.0 / m.scale_max;
+        a.ctl_beta = m.beta;
+        a.ctl_expo1 = (opt->method == IVP_DOP853 ? 1.0 / 8.0 : 0.2) - prod;   // dop853.rs:229, dopri5.rs:226
+        a.ctl_scale_min = m.scale_min;
+        a.ctl_scale_max = m.scale_max;
+        a.ctl_nstiff = m.nstiff;
+        a.has_ctl = opt->has_settings ? 1 : 0;
+    }
 
     // ---- state / result arrays: the caller's buffers where given, context scratch otherwise ----
 #define BIND(field, userptr, scratch, bytes)                                   \
@@ -432,8 +491,9 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
         // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;
         //  fast-mode FMA fusion differs between them, so there it is fixed by the batch size to keep every
         //  trajectory's result independent of what else is in the batch at launch time)
-        use_hoist = opt->variant == 2 ||
-                    (opt->variant == 0 && (opt->fp_mode == IVP_FP_FAST ? B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd);
+        use_hoist = !opt->has_settings &&   // run-time controller fields exist in the lean builds only
+                    (opt->variant == 2 ||
+                     (opt->variant == 0 && (opt->fp_mode == IVP_FP_FAST ? B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
         const int launches_per_sync = tail ? 1 : 4;
         const uint32_t this_chunk = tail ? 1024u : chunk;
         for (int r = 0; r < launches_per_sync; ++r, ++c) {

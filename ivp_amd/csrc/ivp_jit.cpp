@@ -34,7 +34,7 @@ struct JitRhs {
     std::string ode_source;
     std::string arch;
     std::mutex mu;
-    std::map<std::tuple<int, int, bool>, JitModule> modules;  // (method, fp_mode, full)
+    std::map<std::tuple<int, int, bool, bool>, JitModule> modules;  // (method, fp_mode, full, ctl)
     std::string log;
 };
 
@@ -45,7 +45,7 @@ std::string join(const char *const *parts)
     return s;
 }
 
-std::string build_source(const JitRhs &r, int method, bool full)
+std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
 {
     std::string s;
     s += "typedef unsigned int uint32_t;\ntypedef int int32_t;\ntypedef unsigned long long uint64_t;\ntypedef long long int64_t;\n";
@@ -84,15 +84,16 @@ std::string build_source(const JitRhs &r, int method, bool full)
                   "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a)\n"
                   "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::any_init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
                   "extern \"C\" __global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void ivp_jit_chunk(const IvpKArgs a)\n"
-                  "{ ivp_jit::chunk_kernel_body<%d, ivp_jit::RhsUser, %s>(a); }\n",
-                  r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false");
+                  "{ ivp_jit::chunk_kernel_body<%d, ivp_jit::RhsUser, %s, %s>(a); }\n",
+                  r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false",
+                  (ctl && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? "true" : "false");
     s += buf;
     return s;
 }
 
-int compile_module(JitRhs &r, int method, int fp_mode, bool full, JitModule *out)
+int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitModule *out)
 {
-    const std::string src = build_source(r, method, full);
+    const std::string src = build_source(r, method, full, ctl);
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "ivp_user_rhs.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         r.log = "hiprtcCreateProgram failed";
@@ -148,7 +149,7 @@ int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, int
         r->arch = "gfx950";
     }
     // compile the default configuration now so that syntax errors surface at ivp_rhs_compile() time
-    const int rc = compile_module(*r, IVP_DOPRI5, IVP_FP_STRICT, n_events > 0, nullptr);
+    const int rc = compile_module(*r, IVP_DOPRI5, IVP_FP_STRICT, n_events > 0, false, nullptr);
     if (rc != IVP_OK) {
         if (log) *log = r->log;
         delete r;
@@ -181,11 +182,12 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool 
     JitModule m;
     {
         std::lock_guard<std::mutex> lk(r->mu);
-        auto key = std::make_tuple(method, fp_mode, full);
+        const bool ctl = a.has_ctl != 0;
+        auto key = std::make_tuple(method, fp_mode, full, ctl);
         auto it = r->modules.find(key);
         if (it == r->modules.end()) {
             JitModule nm;
-            if (compile_module(*r, method, fp_mode, full, &nm) != IVP_OK) {
+            if (compile_module(*r, method, fp_mode, full, ctl, &nm) != IVP_OK) {
                 std::fprintf(stderr, "ivp_hip: JIT build failed: %s\n", r->log.c_str());
                 return hipErrorInvalidValue;
             }

@@ -15,7 +15,7 @@
 #define IVP_F_FIRSTOUT  0x4u          // DefaultSolOut.first_output_done (solout.rs:53)
 #define IVP_F_IASTI_SHIFT 4           // iasti   0..15  (dopri5.rs:215)
 #define IVP_F_NONSTIFF_SHIFT 8        // nonstiff 0..6  (dopri5.rs:213)
-#define IVP_F_STIFFCTR_SHIFT 12       // naccpt mod nstiff (0..999), replaces the 64-bit modulo
+#define IVP_F_STIFFCTR_SHIFT 12       // bits 12..31: naccpt mod nstiff for nstiff < 2^20, replaces the 64-bit modulo
 
 struct IvpKArgs {
     // ---- batch geometry ----
@@ -35,6 +35,19 @@ struct IvpKArgs {
     uint64_t nmax;            // Options.max_steps or UINT64_MAX
     int32_t has_first_step;
     int32_t has_max_step;
+    // step-size controller settings: the method struct's fields (dopri5.rs:34-72, dop853.rs:34-63, rk23.rs:17-37).
+    // Always filled (struct defaults unless ivp_options_t.has_settings); read by the CTL = true kernels and by the
+    // wave-per-trajectory kernels, the CTL = false kernels have the defaults compiled in.
+    double ctl_uround;
+    double ctl_safety;        // safety_factor
+    double ctl_facc1;         // 1 / scale_min   (DOPRI5, DOP853)
+    double ctl_facc2;         // 1 / scale_max
+    double ctl_beta;
+    double ctl_expo1;         // 0.2 - 0.75 beta (DOPRI5), 1/8 - 0.2 beta (DOP853)
+    double ctl_scale_min;     // RK23 uses the factors themselves
+    double ctl_scale_max;
+    uint64_t ctl_nstiff;      // stiff_test
+    int32_t has_ctl;          // ivp_options_t.has_settings
     // ---- persistent per-trajectory state (doubles as the result arrays) ----
     double *y;                // [N][B]  current state; y_end on exit
     double *k1;               // [N][B]  FSAL derivative at (x, y)

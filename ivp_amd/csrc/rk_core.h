@@ -869,21 +869,32 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
                   ((iasti & 0xFu) << IVP_F_IASTI_SHIFT) | ((nonstiff & 0xFu) << IVP_F_NONSTIFF_SHIFT); \
     }
 
-// stiffness-test cadence: `steps.accepted % nstiff == 0` with nstiff = 1000 kept as a 10-bit counter
-IVP_HD bool stiff_tick(uint32_t &flags)
+// stiffness-test cadence: `steps.accepted % nstiff == 0` (dopri5.rs:364) kept as a counter in flags bits 12..31.
+// CTL = false: the struct default nstiff = 1000.  CTL = true: a.ctl_nstiff; a stiff_test >= 2^20 falls back to the
+// 64-bit modulo on the stored accepted count.
+template <bool CTL>
+IVP_HD bool stiff_tick(const IvpKArgs &a, uint32_t j, uint32_t &flags, uint32_t d_naccpt)
 {
-    uint32_t sc = (flags >> IVP_F_STIFFCTR_SHIFT) & 0x3FFu;
-    sc += 1;
-    const bool hit = sc == 1000u;
-    if (hit) sc = 0;
-    flags = (flags & ~(0x3FFu << IVP_F_STIFFCTR_SHIFT)) | (sc << IVP_F_STIFFCTR_SHIFT);
+    bool hit;
+    if (!CTL || a.ctl_nstiff < (1ull << 20)) {
+        uint32_t sc = flags >> IVP_F_STIFFCTR_SHIFT;
+        sc += 1;
+        hit = sc == (CTL ? (uint32_t)a.ctl_nstiff : 1000u);
+        if (hit) sc = 0;
+        flags = (flags & ((1u << IVP_F_STIFFCTR_SHIFT) - 1u)) | (sc << IVP_F_STIFFCTR_SHIFT);
+    } else {
+        hit = ((a.naccpt[j] + d_naccpt) % a.ctl_nstiff) == 0;
+    }
     return hit || ((flags >> IVP_F_IASTI_SHIFT) & 0xFu) > 0;
 }
+// controller field: the compile-time struct default (CTL = false: solve_ivp()'s path) or the run-time value of a
+// direct method call (CTL = true)
+#define IVP_CTL(field, dflt) (CTL ? a.field : KC(dflt))
 
 // ------------------------------------------------------------------------------------------------
 // DOPRI5 attempt (dopri5.rs:266-461).  Returns false when the trajectory retired.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool FULL>
+template <class R, bool FULL, bool CTL = false>
 IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE
@@ -899,14 +910,14 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     constexpr double D1 = -12715105075.0 / 11282082432.0, D3 = 87487479700.0 / 32700410799.0, D4 = -10690763975.0 / 1880347072.0,
                      D5 = 701980252875.0 / 199316789632.0, D6 = -1453857185.0 / 822651844.0, D7 = 69997945.0 / 29380423.0;
     // struct defaults (dopri5.rs:34-72); solve_ivp overrides only max_step/first_step/max_steps
-    constexpr double uround = 2.3e-16, safety = 0.9, beta = 0.04;
-    constexpr double facc1 = 1.0 / 0.2, facc2 = 1.0 / 10.0;
-    constexpr double expo1 = 0.2 - beta * 0.75;
+    constexpr double d_uround = 2.3e-16, d_safety = 0.9, d_beta = 0.04;
+    constexpr double d_facc1 = 1.0 / 0.2, d_facc2 = 1.0 / 10.0;
+    constexpr double d_expo1 = 0.2 - d_beta * 0.75;
 
     if (L.over || L.d_nstep > L.budget) { L.status = 2; return false; }               // NeedLargerNMax
     double h = L.h;
     const double x = L.x;
-    if (KC(0.1) * fabs(h) <= fabs(x) * KC(uround)) { L.status = 3; return false; }             // StepSizeTooSmall
+    if (KC(0.1) * fabs(h) <= fabs(x) * IVP_CTL(ctl_uround, d_uround)) { L.status = 3; return false; }             // StepSizeTooSmall
     bool last = (L.flags & IVP_F_LAST) != 0;
     if ((x + KC(1.01) * h - L.xend) * L.posneg > 0.0) { h = L.xend - x; last = true; }
     L.d_nstep += 1;
@@ -967,16 +978,16 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     }
     err = sqrt(err / (double)N);
 
-    const double fac11 = ivp_pow(err, KC(expo1));
-    double fac = fac11 / ivp_pow(L.facold, beta);
-    fac = fmax(KC(facc2), fmin(KC(facc1), fac / KC(safety)));
+    const double fac11 = ivp_pow(err, IVP_CTL(ctl_expo1, d_expo1));
+    double fac = fac11 / ivp_pow(L.facold, CTL ? a.ctl_beta : d_beta);
+    fac = fmax(IVP_CTL(ctl_facc2, d_facc2), fmin(IVP_CTL(ctl_facc1, d_facc1), fac / IVP_CTL(ctl_safety, d_safety)));
     double hnew = h / fac;
 
     if (err <= 1.0) {
         L.facold = fmax(err, KC(1.0e-4));
         L.d_naccpt += 1;
         if (L.acc_small < 2) L.acc_small += 1;
-        if (stiff_tick(L.flags)) {  // dopri5.rs:364-391 (rare: every 1000 accepted steps)
+        if (stiff_tick<CTL>(a, j, L.flags, L.d_naccpt)) {  // dopri5.rs:364-391 (rare: every 1000 accepted steps)
             double stnum = 0.0, stden = 0.0;
             bool stiff_break = false;
 { const double cA61 = KC(A61), cA62 = KC(A62), cA63 = KC(A63), cA64 = KC(A64), cA65 = KC(A65);
@@ -1013,7 +1024,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
         if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
     } else {
-        hnew = h / fmin(KC(facc1), fac11 / KC(safety));
+        hnew = h / fmin(IVP_CTL(ctl_facc1, d_facc1), fac11 / IVP_CTL(ctl_safety, d_safety));
         L.flags |= IVP_F_REJECT;
         if (L.acc_small > 1) L.d_nrejct += 1;
         last = false;
@@ -1026,7 +1037,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 // ------------------------------------------------------------------------------------------------
 // DOP853 attempt (dop853.rs:272-653)
 // ------------------------------------------------------------------------------------------------
-template <class R, bool FULL>
+template <class R, bool FULL, bool CTL = false>
 IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE
@@ -1089,14 +1100,14 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
                      D711 = 0.10409964950896230045147246184e+03, D712 = 0.29840293426660503123344363579e+02, D713 = -0.43533456590011143754432175058e+02,
                      D714 = 0.96324553959188282948394950600e+02, D715 = -0.39177261675615439165231486172e+02, D716 = -0.14972683625798562581422125276e+03;
     // struct defaults (dop853.rs:34-63)
-    constexpr double uround = 2.3e-16, safety = 0.9, beta = 0.0;
-    constexpr double facc1 = 1.0 / 0.333, facc2 = 1.0 / 6.0;
-    constexpr double expo1 = 1.0 / 8.0 - beta * 0.2;
+    constexpr double d_uround = 2.3e-16, d_safety = 0.9, d_beta = 0.0;   // dop853.rs:34-63
+    constexpr double d_facc1 = 1.0 / 0.333, d_facc2 = 1.0 / 6.0;
+    constexpr double d_expo1 = 1.0 / 8.0 - d_beta * 0.2;
 
     if (L.over || L.d_nstep > L.budget) { L.status = 2; return false; }
     double h = L.h;
     const double x = L.x;
-    if (KC(0.1) * fabs(h) <= fabs(x) * KC(uround)) { L.status = 3; return false; }
+    if (KC(0.1) * fabs(h) <= fabs(x) * IVP_CTL(ctl_uround, d_uround)) { L.status = 3; return false; }
     bool last = (L.flags & IVP_F_LAST) != 0;
     if ((x + KC(1.01) * h - L.xend) * L.posneg > 0.0) { h = L.xend - x; last = true; }
     L.d_nstep += 1;
@@ -1190,9 +1201,9 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     if (deno <= 0.0) deno = 1.0;
     err = fabs(h) * err * sqrt(1.0 / ((double)N * deno));
 
-    const double fac11 = ivp_pow(err, KC(expo1));
-    double fac = fac11 / ivp_pow(L.facold, beta);
-    fac = fmax(KC(facc2), fmin(KC(facc1), fac / KC(safety)));
+    const double fac11 = ivp_pow(err, IVP_CTL(ctl_expo1, d_expo1));
+    double fac = fac11 / ivp_pow(L.facold, CTL ? a.ctl_beta : d_beta);
+    fac = fmax(IVP_CTL(ctl_facc2, d_facc2), fmin(IVP_CTL(ctl_facc1, d_facc1), fac / IVP_CTL(ctl_safety, d_safety)));
     double hnew = h / fac;
 
     if (err <= 1.0) {
@@ -1201,7 +1212,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         if (L.acc_small < 2) L.acc_small += 1;
         R::ode(xph, k5, k4, p);
         L.d_nfev += 1;
-        if (stiff_tick(L.flags)) {  // dop853.rs:447-472
+        if (stiff_tick<CTL>(a, j, L.flags, L.d_naccpt)) {  // dop853.rs:447-472
             double stnum = 0.0, stden = 0.0;
             bool stiff_break = false;
 #pragma unroll
@@ -1275,7 +1286,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
         if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
     } else {
-        hnew = h / fmin(KC(facc1), fac11 / KC(safety));
+        hnew = h / fmin(IVP_CTL(ctl_facc1, d_facc1), fac11 / IVP_CTL(ctl_safety, d_safety));
         L.flags |= IVP_F_REJECT;
         if (L.acc_small > 1) L.d_nrejct += 1;
         last = false;
@@ -1288,7 +1299,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 // ------------------------------------------------------------------------------------------------
 // RK23 attempt (rk23.rs:189-307)
 // ------------------------------------------------------------------------------------------------
-template <class R, bool FULL>
+template <class R, bool FULL, bool CTL = false>
 IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE
@@ -1299,7 +1310,7 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     constexpr double E1 = 5.0 / 72.0, E2 = -1.0 / 12.0, E3 = -1.0 / 9.0, E4 = 1.0 / 8.0;
     constexpr double D21 = -4.0 / 3.0, D22 = 1.0, D23 = 4.0 / 3.0, D24 = -1.0;
     constexpr double D31 = 5.0 / 9.0, D32 = -2.0 / 3.0, D33 = -8.0 / 9.0, D34 = 1.0;
-    constexpr double safety = 0.9, scale_min = 0.2, scale_max = 10.0;  // rk23.rs:16-36
+    constexpr double d_safety = 0.9, d_scale_min = 0.2, d_scale_max = 10.0;  // rk23.rs:16-36
     constexpr double error_exponent = -1.0 / 3.0;
 
     if (L.over || L.d_nstep >= L.budget) { L.status = 2; return false; }   // `steps.total >= nmax`
@@ -1364,13 +1375,13 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) L.k1[i] = k4[i];
-        h *= fmax(fmin(KC(safety) * ivp_pow(err, KC(error_exponent)), KC(scale_max)), KC(scale_min));
+        h *= fmax(fmin(IVP_CTL(ctl_safety, d_safety) * ivp_pow(err, KC(error_exponent)), IVP_CTL(ctl_scale_max, d_scale_max)), IVP_CTL(ctl_scale_min, d_scale_min));
         if (fabs(h) > L.hmax) h = L.hmax * L.posneg;
         L.h = h;
         if (xnew == L.xend) { L.status = 0; return false; }
     } else {
         L.d_nrejct += 1;
-        h *= fmax(fmin(KC(safety) * ivp_pow(err, KC(error_exponent)), 1.0), KC(scale_min));
+        h *= fmax(fmin(IVP_CTL(ctl_safety, d_safety) * ivp_pow(err, KC(error_exponent)), 1.0), IVP_CTL(ctl_scale_min, d_scale_min));
         L.h = h;
         // The reference never terminates from here when err is NaN (h *= 1.0 forever) or once h has
         // collapsed to 0 (rk23.rs:300-306 has no underflow test).  A GPU lane must retire: report
@@ -1438,7 +1449,7 @@ IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 }
 
 // One chunk of step attempts for one lane. Every lane leaves after at most `chunk` attempts.
-template <int M, class R, bool FULL>
+template <int M, class R, bool FULL, bool CTL = false>
 IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     Lane<R::N, R::P> L;
@@ -1448,10 +1459,10 @@ IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
     uint32_t it = 0;
     bool run = true;
     while (run && it < a.chunk) {
-        if constexpr (M == M_DOPRI5) run = dopri5_attempt<R, FULL>(a, j, L);
-        else if constexpr (M == M_DOP853) run = dop853_attempt<R, FULL>(a, j, L);
+        if constexpr (M == M_DOPRI5) run = dopri5_attempt<R, FULL, CTL>(a, j, L);
+        else if constexpr (M == M_DOP853) run = dop853_attempt<R, FULL, CTL>(a, j, L);
         else if constexpr (M == M_RK4) run = rk4_attempt<R, FULL>(a, j, L);
-        else run = rk23_attempt<R, FULL>(a, j, L);
+        else run = rk23_attempt<R, FULL, CTL>(a, j, L);
         ++it;
     }
     // Re-derive the store addresses from an opaque copy of j: otherwise the ~2 VGPRs per state array

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(IVP_WAVE) void init_kernel_t(const IvpKArgs a)
     if (a.perm_out) compact_append(a, i, valid && st == IVP_RUNNING);
 }
 
-template <int M, class R, bool FULL>
+template <int M, class R, bool FULL, bool CTL = false>
 __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 {
     const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x;
@@ -50,7 +50,7 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
     }
     uint32_t it = 0;
     int32_t st = 0;
-    if (active) it = any_chunk_body<M, R, FULL>(a, j, st);
+    if (active) it = any_chunk_body<M, R, FULL, CTL>(a, j, st);
     const bool still = active && st == IVP_RUNNING;
     compact_append(a, j, still);
     if (a.slot_counter) {
@@ -66,10 +66,12 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
     }
 }
 
-template <int M, class R, bool FULL>
+// CTL = true: controller fields from IvpKArgs.ctl_* (a direct method call with non-default struct fields);
+// CTL = false keeps them compile-time constants, which is the path solve_ivp() takes.
+template <int M, class R, bool FULL, bool CTL = false>
 __global__ __launch_bounds__(IVP_WAVE, (M == M_BDF) ? 1 : IVP_MIN_WAVES) void chunk_kernel_t(const IvpKArgs a)
 {
-    chunk_kernel_body<M, R, FULL>(a);
+    chunk_kernel_body<M, R, FULL, CTL>(a);
 }
 
 }  // namespace IVP_NS

@@ -172,8 +172,8 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
     constexpr double A61 = 9017.0 / 3168.0, A62 = -355.0 / 33.0, A63 = 46732.0 / 5247.0, A64 = 49.0 / 176.0, A65 = -5103.0 / 18656.0;
     constexpr double A71 = 35.0 / 384.0, A73 = 500.0 / 1113.0, A74 = 125.0 / 192.0, A75 = -2187.0 / 6784.0, A76 = 11.0 / 84.0;
     constexpr double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, E5 = -17253.0 / 339200.0, E6 = 22.0 / 525.0, E7 = -1.0 / 40.0;
-    constexpr double uround = 2.3e-16, safety = 0.9, beta = 0.04, facc1 = 1.0 / 0.2, facc2 = 1.0 / 10.0;
-    constexpr double expo1 = 0.2 - beta * 0.75;
+    const double uround = a.ctl_uround, safety = a.ctl_safety, beta = a.ctl_beta;   // dopri5.rs:34-72 struct fields
+    const double facc1 = a.ctl_facc1, facc2 = a.ctl_facc2, expo1 = a.ctl_expo1;
 
     const uint32_t lane = threadIdx.x;
     const uint32_t count = a.perm_in ? *a.count_in : a.B;
@@ -205,7 +205,7 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
 
     for (uint32_t it = 0; it < a.chunk && status == IVP_RUNNING; ++it) {
         if (over || d_nstep > budget) { status = 2; break; }
-        if (KC(0.1) * fabs(h) <= fabs(x) * KC(uround)) { status = 3; break; }
+        if (KC(0.1) * fabs(h) <= fabs(x) * uround) { status = 3; break; }
         bool last = (flags & IVP_F_LAST) != 0;
         if ((x + KC(1.01) * h - xend) * posneg > 0.0) { h = xend - x; last = true; }
         d_nstep += 1;
@@ -245,15 +245,15 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
         } }
         double err = group_sum<N, C>(term, lds, lane);
         err = sqrt(err / (double)N);
-        const double fac11 = ivp_pow(err, KC(expo1));
+        const double fac11 = ivp_pow(err, expo1);
         double fac = fac11 / ivp_pow(facold, beta);
-        fac = fmax(KC(facc2), fmin(KC(facc1), fac / KC(safety)));
+        fac = fmax(facc2, fmin(facc1, fac / safety));
         double hnew = h / fac;
         if (err <= 1.0) {
             facold = fmax(err, KC(1.0e-4));
             d_naccpt += 1;
             if (acc_small < 2) acc_small += 1;
-            if (stiff_tick(flags)) {   // dopri5.rs:364-391
+            if (stiff_tick<true>(a, j, flags, d_naccpt)) {   // dopri5.rs:364-391
                 double t1[C], t2[C];
                 { const double c1 = KC(A61), c2 = KC(A62), c3 = KC(A63), c4 = KC(A64), c5 = KC(A65);
 #pragma unroll
@@ -281,7 +281,7 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
             if (fabs(hnew) > fabs(hmax)) hnew = posneg * fabs(hmax);
             if (flags & IVP_F_REJECT) { hnew = posneg * fmin(fabs(hnew), fabs(h)); flags &= ~IVP_F_REJECT; }
         } else {
-            hnew = h / fmin(KC(facc1), fac11 / KC(safety));
+            hnew = h / fmin(facc1, fac11 / safety);
             flags |= IVP_F_REJECT;
             if (acc_small > 1) d_nrejct += 1;
             last = false;

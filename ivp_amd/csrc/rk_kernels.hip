@@ -46,8 +46,22 @@ hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s
 {
     const dim3 grid((lanes + IVP_WAVE - 1) / IVP_WAVE), block(IVP_WAVE);
     if (grid.x == 0) return hipSuccess;
-    if (what == IVP_LAUNCH_INIT) hipLaunchKernelGGL((init_kernel_t<M, R, FULL>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((chunk_kernel_t<M, R, FULL>), grid, block, 0, s, a);
+    if (what == IVP_LAUNCH_INIT) {
+        hipLaunchKernelGGL((init_kernel_t<M, R, FULL>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    // a direct method call with its own controller fields (IvpKArgs.has_ctl) runs the CTL = true instantiation;
+    // only the lean builds carry it (the host never selects the resident-coefficient variant for such a call)
+    constexpr bool kHasCtl = !IVP_HOIST && (M == M_RK23 || M == M_DOPRI5 || M == M_DOP853);
+    if constexpr (kHasCtl) {
+        if (a.has_ctl) {
+            hipLaunchKernelGGL((chunk_kernel_t<M, R, FULL, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+    } else if (a.has_ctl) {
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL((chunk_kernel_t<M, R, FULL>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

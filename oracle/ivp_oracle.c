@@ -633,10 +633,17 @@ static int dopri5_solve(orc_ode_fn f, const double *p, int n, double x0, const d
                  D6 = -1453857185.0 / 822651844.0, D7 = 69997945.0 / 29380423.0;
 
     /* struct defaults, dopri5.rs:34-72; solve_ivp only overrides max_step/first_step/max_steps */
-    const double uround = 2.3e-16, safety = 0.9, scale_min = 0.2, scale_max = 10.0, beta = 0.04;
-    const uint64_t nstiff = 1000;
+    const int hs = opt->has_settings;
+    const double uround = hs ? opt->uround : 2.3e-16, safety = hs ? opt->safety_factor : 0.9;
+    const double scale_min = hs ? opt->scale_min : 0.2, scale_max = hs ? opt->scale_max : 10.0, beta = hs ? opt->beta : 0.04;
+    const uint64_t nstiff = hs ? opt->stiff_test : 1000;
     const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    /* validation in the reference's order, dopri5.rs:143-198 */
+    if (uround <= 1e-35 || uround >= 1.0) return ORC_ERR_OUT_OF_RANGE;
+    if (safety >= 1.0 || safety <= 1e-4) return ORC_ERR_OUT_OF_RANGE;
+    if (beta > 0.2) return ORC_ERR_OUT_OF_RANGE;
     if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE; /* dopri5.rs:184-189 */
+    if (nstiff == 0) return ORC_ERR_MUST_BE_POSITIVE;
 
     double x = x0;
     double *w = (double *)malloc((size_t)n * (8 + 5) * sizeof(double));
@@ -859,10 +866,17 @@ static int dop853_solve(orc_ode_fn f, const double *p, int n, double x0, const d
                  D715 = -0.39177261675615439165231486172e+02, D716 = -0.14972683625798562581422125276e+03;
 
     /* struct defaults, dop853.rs:34-63 */
-    const double uround = 2.3e-16, safety = 0.9, scale_min = 0.333, scale_max = 6.0, beta = 0.0;
-    const uint64_t nstiff = 1000;
+    const int hs = opt->has_settings;
+    const double uround = hs ? opt->uround : 2.3e-16, safety = hs ? opt->safety_factor : 0.9;
+    const double scale_min = hs ? opt->scale_min : 0.333, scale_max = hs ? opt->scale_max : 6.0, beta = hs ? opt->beta : 0.0;
+    const uint64_t nstiff = hs ? opt->stiff_test : 1000;
     const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    /* validation in the reference's order, dop853.rs:135-193 */
+    if (uround <= 1e-35 || uround >= 1.0) return ORC_ERR_OUT_OF_RANGE;
+    if (safety >= 1.0 || safety <= 1e-4) return ORC_ERR_OUT_OF_RANGE;
+    if (beta > 0.2) return ORC_ERR_OUT_OF_RANGE;
     if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE;
+    if (nstiff == 0) return ORC_ERR_MUST_BE_POSITIVE;
 
     double x = x0;
     double *w = (double *)malloc((size_t)n * (12 + 8) * sizeof(double));
@@ -1062,9 +1076,13 @@ static int rk23_solve(orc_ode_fn f, const double *p, int n, double x0, const dou
     const double D31 = 5.0 / 9.0, D32 = -2.0 / 3.0, D33 = -8.0 / 9.0, D34 = 1.0;
 
     /* struct defaults, rk23.rs:16-36 */
-    const double safety = 0.9, scale_min = 0.2, scale_max = 10.0;
+    const int hs = opt->has_settings;
+    const double safety = hs ? opt->safety_factor : 0.9, scale_min = hs ? opt->scale_min : 0.2, scale_max = hs ? opt->scale_max : 10.0;
     const uint64_t nmax = opt->has_max_steps ? opt->max_steps : UINT64_MAX;
+    /* validation in the reference's order, rk23.rs:102-129 */
     if (nmax == 0) return ORC_ERR_MUST_BE_POSITIVE;
+    if (safety >= 1.0 || safety <= 1e-4) return ORC_ERR_OUT_OF_RANGE;
+    if (scale_min <= 0.0 || scale_max <= scale_min) return ORC_ERR_INVALID_SCALE_FACTORS;
     const double error_exponent = -1.0 / 3.0;
 
     double x = x0;

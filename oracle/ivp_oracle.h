@@ -107,6 +107,12 @@ typedef struct {
      * with ORC_NEED_LARGER_NMAX.  0 => no guard.  Needed because RK23 in the reference
      * never terminates when the error estimate is NaN (rk23.rs:300-306 leaves h unchanged). */
     uint64_t attempt_guard;
+    /* Per-method struct fields for a direct `DOPRI5{..}.solve()` / `DOP853{..}.solve()` / `RK23{..}.solve()` call
+     * (dopri5.rs:34-72, dop853.rs:34-63, rk23.rs:17-37).  has_settings == 0: the struct defaults, which is what
+     * solve_ivp() uses.  RK23 reads safety_factor / scale_min / scale_max only. */
+    int has_settings;
+    double uround, safety_factor, scale_min, scale_max, beta;
+    uint64_t stiff_test;
 } orc_options;
 
 /* Solution (src/solve/solution.rs:7-20) minus events. Owned by the library; free with orc_solution_free. */

@@ -38,7 +38,17 @@ class _Options(C.Structure):
         ("has_min_step", C.c_int), ("min_step", C.c_double),
         ("events", C.c_void_p), ("n_events", C.c_int), ("ev_direction", C.c_int * 4), ("ev_terminal", C.c_uint64 * 4),
         ("attempt_guard", C.c_uint64),
+        ("has_settings", C.c_int), ("uround", C.c_double), ("safety_factor", C.c_double), ("scale_min", C.c_double),
+        ("scale_max", C.c_double), ("beta", C.c_double), ("stiff_test", C.c_uint64),
     ]
+
+
+# per-method struct defaults (dopri5.rs:34-72, dop853.rs:34-63, rk23.rs:17-37); keys a direct method call may override
+SETTINGS_DEFAULTS = {
+    1: dict(uround=2.3e-16, safety_factor=0.9, scale_min=0.2, scale_max=10.0, beta=0.04, stiff_test=1000),
+    2: dict(uround=2.3e-16, safety_factor=0.9, scale_min=0.333, scale_max=6.0, beta=0.0, stiff_test=1000),
+    0: dict(uround=2.3e-16, safety_factor=0.9, scale_min=0.2, scale_max=10.0, beta=0.0, stiff_test=1000),
+}
 
 
 class _Solution(C.Structure):
@@ -113,7 +123,7 @@ class _OptHolder:
 
     def __init__(self, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
                  first_step=None, max_step=None, min_step=None, dense_output=False, attempt_guard=0,
-                 event_direction=None, event_terminal=None):
+                 event_direction=None, event_terminal=None, settings=None):
         m = METHODS[method.upper()] if isinstance(method, str) else int(method)
         self.rtol = np.atleast_1d(np.asarray(rtol, dtype=np.float64)).copy()
         self.atol = np.atleast_1d(np.asarray(atol, dtype=np.float64)).copy()
@@ -136,6 +146,19 @@ class _OptHolder:
         o.has_min_step = int(min_step is not None)
         o.min_step = float(min_step or 0.0)
         o.attempt_guard = int(attempt_guard)
+        if settings is not None:   # a direct `DOPRI5 {..}.solve()`-style call with struct fields overridden
+            if m not in SETTINGS_DEFAULTS:
+                raise ValueError("settings apply to RK23 / DOPRI5 / DOP853")
+            unknown = set(settings) - set(SETTINGS_DEFAULTS[m])
+            if unknown:
+                raise ValueError(f"unknown settings {sorted(unknown)}")
+            full = {**SETTINGS_DEFAULTS[m], **settings}
+            o.has_settings = 1
+            o.uround, o.safety_factor = float(full["uround"]), float(full["safety_factor"])
+            o.scale_min, o.scale_max, o.beta = float(full["scale_min"]), float(full["scale_max"]), float(full["beta"])
+            o.stiff_test = int(full["stiff_test"])
+            if max_steps is None:   # a direct method call has no `None`: the struct default applies
+                o.has_max_steps, o.max_steps = 1, (10_000 if m == 0 else 100_000)
         self.event_direction = list(event_direction or [])
         self.event_terminal = list(event_terminal or [])
         for i, d in enumerate(self.event_direction[:4]):

@@ -183,6 +183,22 @@ CASES.append(("bdf-mixed-intervals", "sho", mixed_intervals("BDF")))
 CASES.append(("bdf-cr3bp-short", "cr3bp", lambda: (*W.cr3bp_batch(16)[:3], 2.0, dict(method="BDF", rtol=1e-6, atol=1e-9))))
 CASES.append(("bdf-zero-rhs", "zero", lambda: (np.ones((3, 2)), None, 0.0, 10.0, dict(method="BDF", rtol=1e-6, atol=1e-9, max_steps=5000))))
 
+# direct per-method calls with non-default struct fields (dopri5.rs:34-72, dop853.rs:34-63, rk23.rs:17-37)
+CASES.append(("settings-dopri5-sho", "sho", sho("DOPRI5", 0.0, 20.0, rtol=1e-6, atol=1e-9,
+                                                 settings=dict(safety_factor=0.8, beta=0.0, scale_min=0.5, scale_max=4.0))))
+CASES.append(("settings-dopri5-beta-cr3bp", "cr3bp", lambda: (*W.cr3bp_batch(64), dict(method="DOPRI5", rtol=1e-6, atol=1e-9,
+                                                                                   settings=dict(beta=0.1, safety_factor=0.95)))))
+CASES.append(("settings-dop853-vdp", "vdp", lambda: (*W.vdp_batch(64), dict(method="DOP853", rtol=1e-8, atol=1e-10,
+                                                                         settings=dict(beta=0.08, safety_factor=0.7, scale_max=3.0)))))
+CASES.append(("settings-rk23-sho", "sho", sho("RK23", 0.0, 10.0, rtol=1e-5, atol=1e-8,
+                                               settings=dict(safety_factor=0.5, scale_min=0.3, scale_max=3.0))))
+for _m in ("DOPRI5", "DOP853"):
+    CASES.append((f"settings-stifftest7-{_m}", "sho", (lambda mm: lambda: (*long_sho(mm)()[:4], dict(method=mm, rtol=1e-10, atol=1e-10, settings=dict(stiff_test=7))))(_m)))
+    CASES.append((f"settings-stifftest1-stiff-vdp-{_m}", "vdp", (lambda mm: lambda: (*stiff_vdp(mm)()[:4], dict(method=mm, rtol=1e-4, atol=1e-6, settings=dict(stiff_test=1))))(_m)))
+    CASES.append((f"settings-stifftest-huge-{_m}", "sho", (lambda mm: lambda: (*long_sho(mm)()[:4], dict(method=mm, rtol=1e-10, atol=1e-10, settings=dict(stiff_test=2 ** 20 + 3))))(_m)))
+    CASES.append((f"settings-uround-{_m}", "sho", sho(_m, 50.0, 80.0, rtol=1e-12, atol=1e-14, settings=dict(uround=1e-4))))
+CASES.append(("settings-maxsteps-default-rk23", "sho", sho("RK23", 0.0, 2000.0, B=3, rtol=1e-7, atol=1e-9, settings={})))
+
 CASE_IDS = [c[0] for c in CASES]
 
 

@@ -23,8 +23,11 @@ static void run_all(IvpKArgs a, uint64_t *chunks_out)
     uint64_t chunks = 0;
     for (uint32_t j = 0; j < a.B; ++j) {
         int32_t st = any_init_body<M, R, FULL>(a, j);
+        constexpr bool kHasCtl = M == M_RK23 || M == M_DOPRI5 || M == M_DOP853;
         while (st == IVP_RUNNING) {
-            any_chunk_body<M, R, FULL>(a, j, st);
+            // same dispatch as launch_one() in rk_kernels.hip: run-time controller fields only for a direct method call
+            if (kHasCtl && a.has_ctl) any_chunk_body<M, R, FULL, kHasCtl>(a, j, st);
+            else any_chunk_body<M, R, FULL>(a, j, st);
             ++chunks;
         }
     }

@@ -19,6 +19,9 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("first_step", C.c_double), ("max_step", C.c_double),
         ("nmax", C.c_uint64),
         ("has_first_step", C.c_int32), ("has_max_step", C.c_int32),
+        ("ctl_uround", C.c_double), ("ctl_safety", C.c_double), ("ctl_facc1", C.c_double), ("ctl_facc2", C.c_double),
+        ("ctl_beta", C.c_double), ("ctl_expo1", C.c_double), ("ctl_scale_min", C.c_double), ("ctl_scale_max", C.c_double),
+        ("ctl_nstiff", C.c_uint64), ("has_ctl", C.c_int32),
         ("y", VP), ("k1", VP), ("x", VP), ("h", VP), ("facold", VP), ("hlamb", VP),
         ("flags", VP), ("status", VP), ("nfev", VP), ("nstep", VP), ("naccpt", VP), ("nrejct", VP),
         ("perm_in", VP), ("count_in", VP), ("perm_out", VP), ("count_out", VP),
@@ -68,7 +71,7 @@ def lib(fast=False):
 
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
                 first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False,
-                event_direction=None, event_terminal=None, max_events=16):
+                event_direction=None, event_terminal=None, max_events=16, settings=None):
     L = lib(fast)
     rid = RHS[rhs]
     n, npar = RHS_DIMS[rid]
@@ -95,6 +98,16 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     a.nmax = int(max_steps) if max_steps else 2 ** 64 - 1
     a.min_step = float(min_step or 0.0)
     a.has_min_step = int(min_step is not None)
+    # controller settings, derived like ivp_capi.cpp does (method struct defaults unless overridden)
+    from oracle.oracle import SETTINGS_DEFAULTS
+    st = {**SETTINGS_DEFAULTS.get(m, SETTINGS_DEFAULTS[0]), **(settings or {})}
+    a.ctl_uround, a.ctl_safety, a.ctl_beta = st["uround"], st["safety_factor"], st["beta"]
+    a.ctl_facc1, a.ctl_facc2 = 1.0 / st["scale_min"], 1.0 / st["scale_max"]
+    a.ctl_expo1 = (1.0 / 8.0 - st["beta"] * 0.2) if m == 2 else (0.2 - st["beta"] * 0.75)
+    a.ctl_scale_min, a.ctl_scale_max, a.ctl_nstiff = st["scale_min"], st["scale_max"], int(st["stiff_test"])
+    a.has_ctl = int(settings is not None)
+    if settings is not None and max_steps is None:
+        a.nmax = 10_000 if m == 0 else 100_000
     res = {
         "y_end": np.zeros((n, B)), "t_end": np.zeros(B), "h_next": np.zeros(B), "status": np.zeros(B, dtype=np.int32),
         "nfev": np.zeros(B, dtype=np.uint64), "nstep": np.zeros(B, dtype=np.uint64),

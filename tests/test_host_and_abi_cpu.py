@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ivp_abi_version() == 1
+    assert lib.ivp_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(lib):
@@ -146,3 +146,19 @@ def test_sharded_solve_and_gather_under_gloo_world_size_2(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_method_defaults_are_the_reference_struct_defaults():
+    """ivp_options_method_defaults(): dopri5.rs:34-72, dop853.rs:34-63, rk23.rs:17-37 (no GPU needed)."""
+    import ctypes as C
+    from ivp_amd import _lib
+    lib = _lib.load()
+    o = _lib.OptionsT()
+    lib.ivp_options_default(C.byref(o))
+    assert o.has_settings == 0
+    want = {1: (2.3e-16, 0.9, 0.2, 10.0, 0.04, 1000), 2: (2.3e-16, 0.9, 0.333, 6.0, 0.0, 1000), 0: (2.3e-16, 0.9, 0.2, 10.0, 0.0, 1000)}
+    for m, w in want.items():
+        assert lib.ivp_options_method_defaults(C.byref(o), m) == 0
+        assert (o.method, o.uround, o.safety_factor, o.scale_min, o.scale_max, o.beta, o.stiff_test) == (m, *w)
+    for m in (3, 4, 5, 17):
+        assert lib.ivp_options_method_defaults(C.byref(o), m) == -100
