@@ -44,18 +44,18 @@ BYTES_PER_LANE_LAUNCH = (16 * 8 + 8 + 8 + 16 + 4) + (16 * 8 + 8 + 64 + 4)
 
 WORKLOADS = {
     "c2": dict(gen="cr3bp_batch", seed=20260102, B=100_000, problem="CR3BP", method="DOPRI5", rtol=1e-6, atol=1e-9,
-               flop_per_attempt=FLOP_PER_ATTEMPT, kernel="chunk_kernel_t<DOPRI5, RhsCr3bp, lean>",
+               flop_per_attempt=FLOP_PER_ATTEMPT, kernel="chunk_kernel_t<DOPRI5, RhsCr3bp> (bulk launches) + coop_chunk_kernel<RhsCr3bp> (tail launch)",
                metric="accepted RK steps/sec (aggregate), batched CR3BP DOPRI5 @ rtol=1e-6",
                desc="C2: 100k independent 6-state CR3BP trajectories (perturbed Arenstorf orbits, one period), "
                     "DOPRI5 rtol=1e-6 atol=1e-9; one step = whole batch integrated to t_end"),
     # DOP853 on the 2-state Van der Pol system: ~0.4 kFLOP per attempt (dense stages elided)
     "c3": dict(gen="vdp_batch", seed=20260103, B=1_000_000, problem="VanDerPol", method="DOP853", rtol=1e-8, atol=1e-10,
-               flop_per_attempt=400, kernel="chunk_kernel_t<DOP853, RhsVdp, lean>",
+               flop_per_attempt=400, kernel="chunk_kernel_t<DOP853, RhsVdp>",
                metric="accepted RK steps/sec (aggregate), batched Van der Pol DOP853 @ rtol=1e-8",
                desc="C3: 1M independent 2-state Van der Pol (mu=1) trajectories, per-trajectory t_end in [50,100], "
                     "DOP853 rtol=1e-8 atol=1e-10"),
     "c5": dict(gen="vdp_stiff_batch", seed=20260105, B=10_000, problem="VanDerPol", method="BDF", rtol=1e-4, atol=1e-6,
-               flop_per_attempt=None, kernel="chunk_kernel_t<BDF, RhsVdp, lean>",
+               flop_per_attempt=None, kernel="chunk_kernel_t<BDF, RhsVdp>",
                metric="accepted BDF steps/sec (aggregate), batched stiff Van der Pol (mu~1000) @ rtol=1e-4",
                desc="C5: 10k stiff Van der Pol (mu ~ 1000) trajectories, t in [0,3000], BDF order 1-5, rtol=1e-4 atol=1e-6"),
 }

@@ -146,7 +146,9 @@ typedef struct {
     int32_t chunk_attempts; /* step attempts per kernel launch between compactions; 0 = auto */
     uint32_t max_log;       /* capacity (per trajectory) of the accepted-step log t_log/y_log and of the
                                dense-segment log; 0 = do not record (end state only) */
-    int32_t variant;        /* stepping-kernel variant: 0 = auto, 1 = lean registers, 2 = coefficients resident */
+    int32_t variant;        /* stepping-kernel variant: 0 = auto, 1 = lean registers, 2 = coefficients resident,
+                               3 = lane-cooperative (eight lanes per trajectory; DOPRI5 end-state runs of built-in
+                               problems, otherwise as 0).  Strict-mode results do not depend on the variant. */
     int32_t profile;        /* 1: time every kernel launch with HIP events (see ivp_run_stats_t);
                                2: additionally sum naccpt / attempts over the batch on the host */
     /* ---- direct per-method call: `DOPRI5 {..}.solve()`, `DOP853 {..}.solve()`, `RK23 {..}.solve()` ----

@@ -176,6 +176,7 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     if (opt->t_eval && opt->n_eval > 0x7FFFFFFFll) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "n_eval too large");
     if (opt->fp_mode != IVP_FP_STRICT && opt->fp_mode != IVP_FP_FAST) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown fp_mode");
     if (opt->chunk_attempts < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative chunk_attempts");
+    if (opt->variant < 0 || opt->variant > 3) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown kernel variant %d", opt->variant);
     *n_out = n;
     *p_out = p;
     return IVP_OK;
@@ -442,9 +443,17 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     auto launch_hoist = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast_hoist : ivp_launch_strict_hoist;
     bool use_hoist = false;
     const bool jit = prob->rhs_id == IVP_RHS_JIT;
+    // lane-cooperative DOPRI5 kernel (rk_coop.h: eight lanes per trajectory): available for built-in problems with
+    // n <= 8 on end-state runs.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict
+    // mode the loop switches to it for the latency-bound tail; fast mode only on request (variant 3).
+    const bool coop_ok = !jit && !group && !full && opt->method == IVP_DOPRI5;
+    bool use_coop = false;
+    const int variant = (opt->variant == 3 && !coop_ok) ? 0 : opt->variant;
     auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
         if (jit) return ivp_jit_launch(prob->jit, what, opt->method, opt->fp_mode, full, ka, lanes, s);
         if (group) return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_group_fast : ivp_launch_group_strict)(what, prob->rhs_id, ka, lanes, s);
+        if (use_coop && what == IVP_LAUNCH_CHUNK)
+            return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_coop_fast : ivp_launch_coop_strict)(prob->rhs_id, ka, lanes, s);
         return (use_hoist ? launch_hoist : launch_lean)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
     };
 
@@ -492,8 +501,11 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
         //  fast-mode FMA fusion differs between them, so there it is fixed by the batch size to keep every
         //  trajectory's result independent of what else is in the batch at launch time)
         use_hoist = !opt->has_settings &&   // run-time controller fields exist in the lean builds only
-                    (opt->variant == 2 ||
-                     (opt->variant == 0 && (opt->fp_mode == IVP_FP_FAST ? B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
+                    (variant == 2 ||
+                     (variant == 0 && (opt->fp_mode == IVP_FP_FAST ? B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
+        // eight lanes per trajectory pay off once the cooperative waves still fit one per SIMD
+        use_coop = coop_ok && (variant == 3 ||
+                               (variant == 0 && opt->fp_mode == IVP_FP_STRICT && adaptive && (size_t)lanes * 8u <= kOneWavePerSimd));
         const int launches_per_sync = tail ? 1 : 4;
         const uint32_t this_chunk = tail ? 1024u : chunk;
         for (int r = 0; r < launches_per_sync; ++r, ++c) {

@@ -199,6 +199,37 @@ struct RhsCr3bp {    // examples/cr3bp.rs:23-36
         d[5] = -(1.0 - mu) * z / r13 - mu * z / r23;
 #endif
     }
+#if defined(__HIPCC__) && !IVP_FAST
+    // Lane-cooperative form for rk_coop.h: lane c (0..7) of an 8-lane group holds component c of the stage state in
+    // `ys` and returns component c of f.  One uniform instruction stream for all lanes (per-lane operands are picked
+    // with selects, so there is no divergence): every lane computes r13 and r23, then a single
+    //     d = (lin + ((-(1-mu)) * q) / r13) - (mu * q2) / r23
+    // which is the reference expression of its component bit for bit: u - v == u + (-v), (-s) * t == -(s * t) and
+    // (-s) / t == -(s / t) hold exactly in IEEE arithmetic, and lin = -0.0 reproduces the leading unary minus of d[5]
+    // including the sign of a zero result.
+    static __device__ __forceinline__ double ode_coop(double, double ys, uint32_t base, uint32_t c, const double *p)
+    {
+        const double mu = p[0];
+        const double x = __shfl(ys, (int)base), y = __shfl(ys, (int)base + 1), z = __shfl(ys, (int)base + 2);
+        // lanes 0..2 return vx, vy, vz; lane 3 needs vy, lane 4 needs vx
+        const uint32_t src = c < 3u ? c + 3u : (c == 3u ? 4u : 3u);
+        const double w = __shfl(ys, (int)(base + src));
+        const double a = x + mu;
+        const double b = x - 1.0 + mu;
+        const double r1 = sqrt(a * a + y * y + z * z);
+        const double r2 = sqrt(b * b + y * y + z * z);
+        const double r13 = r1 * r1 * r1;
+        const double r23 = r2 * r2 * r2;
+        const double q = c == 3u ? a : (c == 4u ? y : z);
+        const double q2 = c == 3u ? b : (c == 4u ? y : z);
+        const double P = c == 3u ? x : y;
+        const double sgn2 = c == 3u ? 2.0 : -2.0;
+        double lin = P + sgn2 * w;
+        lin = c == 5u ? -0.0 : lin;
+        const double d = (lin + (-(1.0 - mu)) * q / r13) - mu * q2 / r23;
+        return c < 3u ? w : d;
+    }
+#endif
 };
 struct RhsLorenz {   // benches/benchmark.py:30-37
     enum { N = 3, P = 3, NE = 0 };

@@ -1,5 +1,6 @@
-// rk_group.hip -- wave-per-trajectory DOPRI5 kernels for large state dimensions (see rk_group.h) and their
-// launch table.  Compiled twice like rk_kernels.hip: strict (-ffp-contract=off, index-order error-norm sum) and
+// rk_group.hip -- the kernels in which several lanes share one trajectory, and their launch tables:
+//   * rk_group.h: wave-per-trajectory DOPRI5 for large state dimensions (8 < n <= 512);
+//   * rk_coop.h:  eight lanes per trajectory (n <= 8) for the latency-bound tail of a batch.  Compiled twice like rk_kernels.hip: strict (-ffp-contract=off, index-order error-norm sum) and
 // fast (-ffp-contract=fast, __shfl_xor butterfly).  Coefficients stay resident in registers (IVP_HOIST): a lone
 // wave per trajectory is latency-bound and has VGPRs to spare.
 #include <hip/hip_runtime.h>
@@ -9,12 +10,17 @@
 #if IVP_FAST
 #define IVP_NS ivp_group_fast
 #define IVP_LAUNCH_NAME ivp_launch_group_fast
+#define IVP_COOP_LAUNCH_NAME ivp_launch_coop_fast
 #else
+#define IVP_COOP_LAUNCH_NAME ivp_launch_coop_strict
 #define IVP_NS ivp_group_strict
 #define IVP_LAUNCH_NAME ivp_launch_group_strict
 #endif
 #include "rk_core.h"
+#include "bdf_core.h"
+#include "rk_global.h"
 #include "rk_group.h"
+#include "rk_coop.h"
 #include "rk_launch.h"
 
 namespace {
@@ -29,7 +35,38 @@ hipError_t launch_group(int what, const IvpKArgs &a, uint32_t trajectories, hipS
     return hipGetLastError();
 }
 
+template <class R>
+hipError_t launch_coop(const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+{
+    const dim3 grid((trajectories + 7) / 8), block(IVP_WAVE);   // eight lanes per trajectory
+    if (grid.x == 0) return hipSuccess;
+    hipLaunchKernelGGL((IVP_NS::coop_chunk_kernel<R>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+hipError_t IVP_COOP_LAUNCH_NAME(int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+{
+    switch (rhs_id) {
+    case 0: return launch_coop<IVP_NS::RhsDecay>(a, trajectories, s);
+    case 1: return launch_coop<IVP_NS::RhsSho>(a, trajectories, s);
+    case 2: return launch_coop<IVP_NS::RhsVdp>(a, trajectories, s);
+    case 3: return launch_coop<IVP_NS::RhsCr3bp>(a, trajectories, s);
+    case 4: return launch_coop<IVP_NS::RhsLorenz>(a, trajectories, s);
+    case 5: return launch_coop<IVP_NS::RhsZero>(a, trajectories, s);
+    case 6: return launch_coop<IVP_NS::RhsRational>(a, trajectories, s);
+    case 7: return launch_coop<IVP_NS::RhsExp2>(a, trajectories, s);
+    case 8: return launch_coop<IVP_NS::RhsLinear>(a, trajectories, s);
+    case 9: return launch_coop<IVP_NS::RhsRobertson>(a, trajectories, s);
+    case 10: return launch_coop<IVP_NS::RhsVdpEps>(a, trajectories, s);
+    case 11: return launch_coop<IVP_NS::RhsShoEv>(a, trajectories, s);
+    case 12: return launch_coop<IVP_NS::RhsBall>(a, trajectories, s);
+    case 13: return launch_coop<IVP_NS::RhsCannon>(a, trajectories, s);
+    case 14: return launch_coop<IVP_NS::RhsRationalEv>(a, trajectories, s);
+    }
+    return hipErrorInvalidValue;
+}
 
 hipError_t IVP_LAUNCH_NAME(int what, int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {

@@ -16,6 +16,7 @@ def oracle_batch(rhs, y0, params, t0, t1, detpow=True, **opts):
     opts.pop("max_log", None)
     opts.pop("max_events", None)
     opts.pop("chunk", None)
+    opts.pop("variant", None)
     return O.solve_batch(rhs, y0, params, t0, t1, detpow=detpow, **opts)
 
 

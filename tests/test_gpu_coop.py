@@ -1,0 +1,58 @@
+"""Lane-cooperative DOPRI5 kernel (rk_coop.h: eight lanes per trajectory, used for the latency-bound tail of a batch).
+
+In strict mode it must be bit-identical to the oracle -- and hence to the thread-per-trajectory kernels -- whether it
+runs the whole integration (variant = 3) or takes over at a launch boundary (variant = 0, the default policy)."""
+import numpy as np
+import pytest
+
+import ivp_amd
+from ivp_amd import workloads as W
+from tests.cases import CASES
+from tests.common import assert_bitexact, gpu_batch, oracle_batch
+
+pytestmark = pytest.mark.gpu
+
+DOPRI5_END_STATE = [c for c in CASES if "DOPRI5" in c[0].upper() or c[0] in ("C1-decay", "exp2-vector-rtol")]
+
+
+@pytest.mark.parametrize("case", DOPRI5_END_STATE, ids=[c[0] for c in DOPRI5_END_STATE])
+def test_coop_everywhere_bitexact_vs_oracle(case):
+    name, rhs, build = case
+    y0, p, t0, t1, o = build()
+    if "t_eval" in o:
+        pytest.skip("FULL runs do not use the cooperative kernel")
+    ref = oracle_batch(rhs, y0, p, t0, t1, **o)
+    for chunk in (0, 17):
+        got = gpu_batch(rhs, y0, p, t0, t1, variant=3, chunk=chunk, **o)
+        assert_bitexact(got, ref, f"{name} coop chunk={chunk}: ")
+
+
+def test_c2_tail_switch_is_invisible():
+    """20k of the C2 trajectories: the default policy starts on the thread-per-trajectory kernels and hands the
+    stragglers to the cooperative kernel; forcing either kind for the whole run gives the same bits."""
+    y0, p, t0, t1 = W.cr3bp_batch(100000)          # the BASELINE C2 batch (slowest trajectory: 702 attempts) ...
+    y0, p = np.ascontiguousarray(y0[:, 40000:60000]), np.ascontiguousarray(p[:, 40000:60000])   # ... a 20k slice of it
+    o = dict(method="DOPRI5", rtol=1e-6, atol=1e-9)
+    auto = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, **o)
+    lean = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, variant=1, **o)
+    coop = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, variant=3, **o)
+    assert_bitexact(auto, lean, "auto vs lean ")
+    assert_bitexact(coop, lean, "coop vs lean ")
+    ref = oracle_batch("cr3bp", y0[:, :2048], p[:, :2048], t0, t1, **o)
+    sub = {k: (v[..., :2048] if isinstance(v, np.ndarray) else v) for k, v in auto.items()}
+    assert_bitexact(sub, ref, "auto vs oracle ")
+
+
+def test_coop_handles_ragged_groups_and_all_rhs():
+    """Batch sizes that leave a partly filled 8-lane group / wave, for every built-in problem without events."""
+    rng = np.random.default_rng(4)
+    for rhs, n, npar, pv in (("decay", 1, 1, [0.7]), ("sho", 2, 0, None), ("vdp", 2, 1, [1.5]), ("lorenz", 3, 3, [10.0, 28.0, 8 / 3]),
+                             ("linear", 2, 0, None), ("robertson", 3, 0, None), ("exp2", 2, 0, None)):
+        for B in (1, 7, 9, 65):
+            y0 = 1.0 + 0.1 * rng.standard_normal((n, B))
+            p = None if not npar else np.repeat(np.asarray(pv)[:, None], B, axis=1)
+            t1 = rng.uniform(0.1, 1.0, B)
+            o = dict(method="DOPRI5", rtol=1e-7, atol=1e-9)
+            ref = oracle_batch(rhs, y0, p, 0.0, t1, **o)
+            got = gpu_batch(rhs, y0, p, 0.0, t1, variant=3, **o)
+            assert_bitexact(got, ref, f"{rhs} B={B}: ")
