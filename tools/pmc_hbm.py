@@ -29,14 +29,16 @@ res = {"calibration": {"known_bytes_each_way": known, "FETCH_SIZE_bytes_raw": f_
 bf_, bw_ = per_kernel(bf, "FETCH_SIZE"), per_kernel(bw, "WRITE_SIZE")
 kern = {}
 for k in bf_:
-    if "chunk_kernel" in k or "init_kernel" in k:
+    if "chunk_kernel" in k or "init_kernel" in k or "chunk_body" in k:
         f = sum(bf_[k]) / len(bf_[k]) * 1024.0 * corr_f
         w = sum(bw_.get(k, [0.0])) / max(len(bw_.get(k, [0.0])), 1) * 1024.0 * corr_w
         kern[k] = {"launches": len(bf_[k]), "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w}
 res["kernels"] = kern
-ck = [k for k in kern if "chunk_kernel" in k]
+ck = [k for k in kern if "chunk_kernel" in k]   # chunk_kernel_t<..> and coop_chunk_kernel<..>: every stepping launch
 if ck:
-    res["hbm_bytes_per_launch"] = kern[ck[0]]["hbm_bytes_per_launch"]
-    res["kernel"] = ck[0]
+    n = sum(kern[k]["launches"] for k in ck)
+    res["hbm_bytes_per_launch"] = sum(kern[k]["hbm_bytes_per_launch"] * kern[k]["launches"] for k in ck) / n
+    res["kernel"] = " + ".join(ck)
+    res["stepping_launches"] = n
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
