@@ -65,7 +65,7 @@ typedef enum {
     IVP_ERR_INVALID_STEP_SIZE = -5,       /* ConfigError::InvalidStepSize (RK4: first_step zero / wrong sign, rk4.rs:81-87) */
     IVP_ERR_INVALID_SCALE_FACTORS = -6,   /* ConfigError::InvalidScaleFactors  */
     IVP_ERR_BAD_ARGUMENT = -100,          /* NULL pointer, unknown rhs id, n mismatch ...            */
-    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU (any problem), or a method other than DOPRI5 for a large-n problem */
+    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU (any problem), or BDF for a large-n problem        */
     IVP_ERR_NO_DEVICE = -102,             /* no HIP device: there is deliberately no CPU fallback    */
     IVP_ERR_HIP = -103,                   /* a HIP runtime call failed; see ivp_last_error_string()  */
     IVP_ERR_JIT = -104                    /* hiprtc compilation of a user RHS failed                 */
@@ -93,8 +93,8 @@ typedef enum {
     IVP_RHS_RATIONAL_EV = 14, /* rational problem + 3 events            n=2  tests/test_ivp.py:345-353          */
     IVP_RHS_BUILTIN_COUNT = 15,
     /* Large state dimensions (8 < n <= 512): one 64-lane wavefront integrates one trajectory, the state is
-     * distributed over its lanes and the error norm is a wavefront reduction.  DOPRI5, scalar tolerances and
-     * end-state results only (no t_eval / step log / dense output / events) in this ABI version. */
+     * distributed over its lanes and the error norm is a wavefront reduction.  RK23 / DOPRI5 / DOP853 / RK4 with
+     * every output mode (t_eval, step log, dense output); scalar tolerances; no events, no BDF in this ABI version. */
     IVP_RHS_LINEAR_DECAY_100 = 100, /* y' = -y                            n=100 benches/benchmark.py:40-42,139-148 */
     IVP_RHS_HEAT1D_256 = 101,       /* y_i' = k (y_{i-1} - 2 y_i + y_{i+1}), p={k}  n=256 (method of lines)  */
     IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */

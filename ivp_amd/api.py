@@ -255,7 +255,7 @@ class RationalEvents(_EventProblem):  # tests/test_ivp.py:345-353
 
 @dataclass
 class LinearDecay100(IVP):  # benches/benchmark.py:40-42,139-148 "Large Linear System (N=100)"
-    """y' = -y with 100 components: a large-n problem (one wavefront per trajectory, DOPRI5, end state only)."""
+    """y' = -y with 100 components: a large-n problem (one wavefront per trajectory; explicit RK methods)."""
     rhs_id = 100; n = 100; n_params = 0
 
 
@@ -282,7 +282,7 @@ class DeviceIVP(IVP):
     ``params`` are the values of the struct's fields (``p[...]`` inside ``ode``).
     For ``8 < n <= 512`` the snippet defines the component form
     ``__device__ double ode_comp(int i, double x, const double* y, const double* p)`` instead (one wavefront per
-    trajectory; DOPRI5, scalar tolerances, end state only).
+    trajectory; RK23 / DOPRI5 / DOP853 / RK4, scalar tolerances, no events).
     """
     rhs_id = 1000
 
@@ -778,15 +778,6 @@ def solve_ivp(f: IVP, x0: float, xend: float, y0: Sequence[float], options: Opti
                         nfev=0, njev=0, nlu=0, nstep=0, naccpt=0, nrejct=0, status=Status.Success, continuous_sol=cs)
     if n != f.n:
         raise ValueError(f"y0 has {n} components, problem has {f.n}")
-    if n > MAX_LANE_N:
-        # large-n problems: the kernels return the end state only, so Solution.t/y hold the two end points
-        pr = np.asarray(f.params(), dtype=np.float64).reshape(f.n_params, 1) if f.n_params else None
-        r = solve_ivp_batch(f, x0, xend, y0.reshape(n, 1), pr, options, ctx)
-        return Solution(t=np.array([x0, float(r.t_end[0])]), y=np.stack([y0, r.y_end[:, 0]]), t_events=[], y_events=[],
-                        nfev=int(r.nfev[0]), njev=0, nlu=0, nstep=int(r.nstep[0]), naccpt=int(r.naccpt[0]),
-                        nrejct=int(r.nrejct[0]), status=Status(int(r.status[0])), continuous_sol=None,
-                        h_next=float(r.h_next[0]))
-
     need_log = options.t_eval is None or options.dense_output
     cap = options.max_log or (4096 if need_log else 0)
     while True:

@@ -135,12 +135,10 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     if (prob->n != n || prob->n_params != p)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "problem dims (n=%d,p=%d) do not match rhs (n=%d,p=%d)", prob->n, prob->n_params, n, p);
     if (n < 1 || n > IVP_MAX_GROUP_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
-    if (n > IVP_MAX_N) {   // wave-per-trajectory kernels: DOPRI5, scalar tolerances, end state only
-        if (opt->method != IVP_DOPRI5 && opt->method != IVP_RADAU && opt->method >= IVP_RK23 && opt->method <= IVP_BDF)
-            return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "n = %d > %d: only DOPRI5 is available for large-n problems", n, IVP_MAX_N);
+    if (n > IVP_MAX_N) {   // wave-per-trajectory kernels: explicit RK methods, scalar tolerances, no events
+        if (opt->method == IVP_BDF)
+            return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "n = %d > %d: BDF is not available for large-n problems", n, IVP_MAX_N);
         if (opt->rtol_vec || opt->atol_vec) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "large-n problems take scalar tolerances");
-        if (opt->t_eval || opt->dense_output || opt->max_log > 0)
-            return fail(ctx, IVP_ERR_BAD_ARGUMENT, "large-n problems return the end state only (no t_eval / log / dense output)");
     }
     if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
     if (opt->method == IVP_RADAU)
@@ -451,7 +449,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     const int variant = (opt->variant == 3 && !coop_ok) ? 0 : opt->variant;
     auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
         if (jit) return ivp_jit_launch(prob->jit, what, opt->method, opt->fp_mode, full, ka, lanes, s);
-        if (group) return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_group_fast : ivp_launch_group_strict)(what, prob->rhs_id, ka, lanes, s);
+        if (group) return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_group_fast : ivp_launch_group_strict)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
         if (use_coop && what == IVP_LAUNCH_CHUNK)
             return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_coop_fast : ivp_launch_coop_strict)(prob->rhs_id, ka, lanes, s);
         return (use_hoist ? launch_hoist : launch_lean)(what, opt->method, prob->rhs_id, full, ka, lanes, s);

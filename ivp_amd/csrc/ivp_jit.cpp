@@ -66,9 +66,9 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
                       "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d };\n"
                       "  static __device__ __forceinline__ double ode_comp(int i, double x, const double* y, const double* p) { return ::ode_comp(i, x, y, p); }\n"
                       "}; }\n"
-                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<ivp_jit::RhsUser>(a); }\n"
-                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<ivp_jit::RhsUser>(a); }\n",
-                      r.n, r.np);
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<%d, ivp_jit::RhsUser, %s>(a); }\n"
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<%d, ivp_jit::RhsUser, %s>(a); }\n",
+                      r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false");
         s += buf;
         return s;
     }

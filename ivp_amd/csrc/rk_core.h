@@ -321,6 +321,39 @@ struct RhsRationalEv {   // tests/test_ivp.py:345-353
 };
 
 // ------------------------------------------------------------------------------------------------
+// Customisation points for kernels in which a lane holds only SOME components of a trajectory (rk_group.h:
+// one wavefront per trajectory).  For the ordinary functors they are the identity / a plain loop, so the
+// thread-per-trajectory code below is unchanged by them.
+//   IdMap<N>      local component c -> global component gi(c) of NT; own(c) = this lane really holds it
+//   NormOps<R>    NT = number of components in the RMS norms, sum() = the reference's left-to-right sum
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct IdMap {
+    enum { NT = N };
+    static IVP_HD int gi(int c) { return c; }
+    static IVP_HD bool own(int) { return true; }
+};
+template <class R, class = void>
+struct OutMap { using type = IdMap<R::N>; };
+template <class R, class = void>
+struct NormOps {
+    enum { NT = R::N };
+    template <int N>
+    static IVP_HD double sum(const double (&t)[N])
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s += t[i];
+        return s;
+    }
+};
+// state-array access through the map (component-major SoA: a[gi(c) * B + j])
+template <class MAP>
+IVP_HD double map_ld(const double *arr, int c, size_t B, uint32_t j) { return MAP::own(c) ? arr[(size_t)MAP::gi(c) * B + j] : 0.0; }
+template <class MAP>
+IVP_HD void map_st(double *arr, int c, size_t B, uint32_t j, double v) { if (MAP::own(c)) arr[(size_t)MAP::gi(c) * B + j] = v; }
+
+// ------------------------------------------------------------------------------------------------
 // Per-lane state
 // ------------------------------------------------------------------------------------------------
 template <int N, int P>
@@ -343,9 +376,10 @@ template <class R>
 IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool rk23, bool full)
 {
     constexpr int N = R::N, P = R::P;
+    using MAP = typename OutMap<R>::type;
     const size_t B = a.B;
 #pragma unroll
-    for (int c = 0; c < N; ++c) { L.y[c] = a.y[c * B + j]; L.k1[c] = a.k1[c * B + j]; }
+    for (int c = 0; c < N; ++c) { L.y[c] = map_ld<MAP>(a.y, c, B, j); L.k1[c] = map_ld<MAP>(a.k1, c, B, j); }
 #pragma unroll
     for (int c = 0; c < P; ++c) L.p[c] = a.params[c * B + j];
     L.x = a.x[j];
@@ -385,9 +419,10 @@ template <class R>
 IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L, bool full)
 {
     constexpr int N = R::N;
+    using MAP = typename OutMap<R>::type;
     const size_t B = a.B;
 #pragma unroll
-    for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = L.k1[c]; }
+    for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, L.k1[c]); }
     a.x[j] = L.x;
     a.h[j] = L.h;
     a.facold[j] = L.facold;
@@ -487,17 +522,17 @@ IVP_HD void interpolate(double xi, double *yi, const double *cont, double xold, 
 // collection, t_eval sampling, accepted-step recording with first_step enforcement.
 // `cont == nullptr` is the initial callback (interpolant None).
 // ------------------------------------------------------------------------------------------------
-template <int M, int N, int P>
+template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t ti, const double *yv)
 {
     const size_t B = a.B;
     const size_t k = (size_t)L.n_filled;
 #pragma unroll
-    for (int c = 0; c < N; ++c) a.y_eval[(k * N + c) * B + j] = yv[c];
+    for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_eval[(k * MAP::NT + MAP::gi(c)) * B + j] = yv[c];
     if (a.eval_idx) a.eval_idx[k * B + j] = ti;
     L.n_filled += 1;
 }
-template <int M, int N, int P>
+template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, const double *yv)
 {
     const size_t B = a.B;
@@ -505,24 +540,26 @@ IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, 
         const size_t k = L.n_log;
         a.t_log[k * B + j] = t;
 #pragma unroll
-        for (int c = 0; c < N; ++c) a.y_log[(k * N + c) * B + j] = yv[c];
+        for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_log[(k * MAP::NT + MAP::gi(c)) * B + j] = yv[c];
     }
     L.n_log += 1;
     L.t_last = t;
 }
 
-template <int M, int N, int P>
+template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_collect_dense(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
                              const double *cont, double h, double ixold)
 {
     constexpr int NC = NCoef<M>::v * N;
+    constexpr int NCT = NCoef<M>::v * MAP::NT;   // coefficient blocks are [coef][component] (cont.rs:16-28)
     const size_t B = a.B;
     // dense collection, solout.rs:141-146
     if (a.collect_dense && x != xold && cont != nullptr && h != 0.0) {
         if (L.n_seg < a.max_log) {
             const size_t k = L.n_seg;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) a.seg_cont[(k * NC + c) * B + j] = cont[c];
+            for (int c = 0; c < NC; ++c)
+                if (MAP::own(c % N)) a.seg_cont[(k * NCT + (size_t)(c / N) * MAP::NT + MAP::gi(c % N)) * B + j] = cont[c];
             a.seg_xold[k * B + j] = ixold;
             a.seg_h[k * B + j] = h;
         }
@@ -533,7 +570,7 @@ IVP_HD void so_collect_dense(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, doubl
 // t_eval sampling / accepted-step recording (solout.rs:344-428). `xold` is the callback's first argument,
 // `ixold`/`h` the interpolant's own anchor (StepInterpolant.xold/.h): identical for the RK methods, different for
 // BDF (bdf.rs:518-519).
-template <int M, int N, int P>
+template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
                       const double *y, const double *cont, double h, double ixold)
 {
@@ -544,17 +581,17 @@ IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold,
         int32_t i = L.next_idx;
         const int32_t ne = a.n_eval;
         if (fabs(xold - x) <= tol) {
-            while (i < ne && fabs(a.t_eval[i] - x) <= tol) { so_emit_eval<M, N, P>(a, j, L, i, y); ++i; }
+            while (i < ne && fabs(a.t_eval[i] - x) <= tol) { so_emit_eval<M, N, P, MAP>(a, j, L, i, y); ++i; }
         } else if (x > xold) {
             while (i < ne && a.t_eval[i] <= x + tol) {
                 const double te = a.t_eval[i];
-                if (te >= xold - tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
+                if (te >= xold - tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P, MAP>(a, j, L, i, yi); }
                 ++i;
             }
         } else {
             while (i < ne && a.t_eval[i] >= x - tol) {
                 const double te = a.t_eval[i];
-                if (te <= xold + tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P>(a, j, L, i, yi); }
+                if (te <= xold + tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P, MAP>(a, j, L, i, yi); }
                 ++i;
             }
         }
@@ -567,15 +604,15 @@ IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold,
                 if (direction * (x - target) >= -tol) {
                     if (cont != nullptr) {
                         interpolate<M, N>(target, yi, cont, ixold, h);
-                        so_push_log<M, N, P>(a, j, L, target, yi);
+                        so_push_log<M, N, P, MAP>(a, j, L, target, yi);
                         L.flags |= IVP_F_FIRSTOUT;
                     }
-                    if (fabs(x - target) > tol) so_push_log<M, N, P>(a, j, L, x, y);
+                    if (fabs(x - target) > tol) so_push_log<M, N, P, MAP>(a, j, L, x, y);
                 }
                 return;
             }
         }
-        if (L.n_log == 0 || fabs(L.t_last - x) > tol) so_push_log<M, N, P>(a, j, L, x, y);
+        if (L.n_log == 0 || fabs(L.t_last - x) > tol) so_push_log<M, N, P, MAP>(a, j, L, x, y);
     }
 }
 
@@ -716,11 +753,12 @@ template <int M, class R>
 IVP_HD bool solout_full(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
                         const double *y, const double *yold, const double *cont, double h, double ixold)
 {
-    so_collect_dense<M, R::N, R::P>(a, j, L, xold, x, cont, h, ixold);
+    using MAP = typename OutMap<R>::type;
+    so_collect_dense<M, R::N, R::P, MAP>(a, j, L, xold, x, cont, h, ixold);
     if constexpr (R::NE > 0) {
         if (so_events<M, R>(a, j, L, xold, x, y, yold, cont, h, ixold)) return true;
     }
-    so_sample<M, R::N, R::P>(a, j, L, xold, x, y, cont, h, ixold);
+    so_sample<M, R::N, R::P, MAP>(a, j, L, xold, x, y, cont, h, ixold);
     return false;
 }
 
@@ -746,13 +784,14 @@ IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg,
                     const double *p, int iord, double hmax)
 {
     constexpr int N = R::N;
-    double dnf = 0.0, dny = 0.0;
+    double t_dnf[N], t_dny[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double sk = a.atol[i] + a.rtol[i] * fabs(y[i]);
-        dnf += (f0[i] / sk) * (f0[i] / sk);
-        dny += (y[i] / sk) * (y[i] / sk);
+        t_dnf[i] = (f0[i] / sk) * (f0[i] / sk);
+        t_dny[i] = (y[i] / sk) * (y[i] / sk);
     }
+    const double dnf = NormOps<R>::sum(t_dnf), dny = NormOps<R>::sum(t_dny);
     double h;
     if (dnf <= 1e-10 || dny <= 1e-10) h = 1.0e-6;
     else h = sqrt(dny / dnf) * 0.01;
@@ -762,13 +801,14 @@ IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg,
 #pragma unroll
     for (int i = 0; i < N; ++i) y1[i] = y[i] + h * f0[i];
     R::ode(x + h, y1, f1, p);
-    double der2 = 0.0;
+    double t_der2[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double sk = a.atol[i] + a.rtol[i] * fabs(y[i]);
         const double df = (f1[i] - f0[i]) / sk;
-        der2 += df * df;
+        t_der2[i] = df * df;
     }
+    double der2 = NormOps<R>::sum(t_der2);
     der2 = sqrt(der2) / fabs(h);
     const double der12 = fmax(fabs(der2), sqrt(dnf));
     double h1;
@@ -787,10 +827,11 @@ template <int M, class R, bool FULL>
 IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
 {
     constexpr int N = R::N, P = R::P;
+    using MAP = typename OutMap<R>::type;
     const size_t B = a.B;
     Lane<N, P> L;
 #pragma unroll
-    for (int c = 0; c < N; ++c) L.y[c] = a.y0[c * B + j];
+    for (int c = 0; c < N; ++c) L.y[c] = map_ld<MAP>(a.y0, c, B, j);
 #pragma unroll
     for (int c = 0; c < P; ++c) L.p[c] = a.params[c * B + j];
     L.x0 = a.t0[(size_t)j * a.t0_stride];
@@ -804,18 +845,19 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
 
     if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
 #pragma unroll
-        for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = 0.0; }
+        for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, 0.0); }
         if (FULL) {
             if (a.n_eval >= 0) {
                 for (int32_t i = 0; i < a.n_eval; ++i)
-                    if (fabs(a.t_eval[i] - L.x0) < 1e-12) so_emit_eval<M, N, P>(a, j, L, i, L.y);
+                    if (fabs(a.t_eval[i] - L.x0) < 1e-12) so_emit_eval<M, N, P, MAP>(a, j, L, i, L.y);
             } else if (a.t_log != nullptr) {
-                so_push_log<M, N, P>(a, j, L, L.x0, L.y);
+                so_push_log<M, N, P, MAP>(a, j, L, L.x0, L.y);
             }
             if (a.collect_dense && a.max_log > 0) {  // ContinuousOutput::constant, cont.rs:32-64
                 constexpr int NC = NCoef<M>::v * N;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) a.seg_cont[(size_t)c * B + j] = c < N ? L.y[c] : 0.0;
+                for (int c = 0; c < NC; ++c)
+                    if (MAP::own(c % N)) a.seg_cont[((size_t)(c / N) * MAP::NT + MAP::gi(c % N)) * B + j] = c < N ? L.y[c] : 0.0;
                 a.seg_xold[j] = L.x0;
                 a.seg_h[j] = 1e-15;
                 L.n_seg = 1;
@@ -833,7 +875,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         // A NaN interval end makes every comparison of the reference's step loop false: it never terminates
         // (with the default max_steps = None).  A GPU lane must retire: StepSizeTooSmall, nothing integrated.
 #pragma unroll
-        for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = 0.0; }
+        for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, 0.0); }
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 3;
         a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
@@ -854,7 +896,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         if (L.h == 0.0 || rs_signum(L.h) != L.posneg) {
             ivp_flag_error(a, IVP_ERRFLAG_INVALID_STEP);
 #pragma unroll
-            for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = 0.0; }
+            for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, 0.0); }
             a.x[j] = L.x0; a.h[j] = L.h; a.facold[j] = 0.0; a.hlamb[j] = 0.0; a.flags[j] = 0;
             a.status[j] = 0;
             a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
@@ -871,7 +913,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     if (FULL) (void)solout_full<M, R>(a, j, L, L.x, L.x, L.y, L.y, nullptr, 0.0, L.x);
 
 #pragma unroll
-    for (int c = 0; c < N; ++c) { a.y[c * B + j] = L.y[c]; a.k1[c * B + j] = L.k1[c]; }
+    for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, L.k1[c]); }
     a.x[j] = L.x; a.h[j] = L.h; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = L.flags;
     a.status[j] = IVP_RUNNING;
     a.nfev[j] = nfev; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
@@ -929,7 +971,7 @@ template <class R, bool FULL, bool CTL = false>
 IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE
-    constexpr int N = R::N, P = R::P;
+    constexpr int N = R::N;
     // tableau, dopri5.rs:482-520
     constexpr double C2 = 0.2, C3 = 0.3, C4 = 0.8, C5 = 8.0 / 9.0;
     constexpr double A21 = 0.2, A31 = 3.0 / 40.0, A32 = 9.0 / 40.0;
@@ -1001,13 +1043,14 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     for (int i = 0; i < N; ++i)
         k4[i] = (cE1 * k1[i] + cE3 * k3[i] + cE4 * k4[i] + cE5 * k5[i] + cE6 * k6[i] + cE7 * k2[i]) * h;
 }
-    double err = 0.0;
+    double t_err[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double sk = a.atol[i] + a.rtol[i] * fmax(fabs(y[i]), fabs(y1[i]));
-        err += (k4[i] / sk) * (k4[i] / sk);
+        t_err[i] = (k4[i] / sk) * (k4[i] / sk);
     }
-    err = sqrt(err / (double)N);
+    double err = NormOps<R>::sum(t_err);
+    err = sqrt(err / (double)NormOps<R>::NT);
 
     const double fac11 = ivp_pow(err, IVP_CTL(ctl_expo1, d_expo1));
     double fac = fac11 / ivp_pow(L.facold, CTL ? a.ctl_beta : d_beta);
@@ -1019,7 +1062,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         L.d_naccpt += 1;
         if (L.acc_small < 2) L.acc_small += 1;
         if (stiff_tick<CTL>(a, j, L.flags, L.d_naccpt)) {  // dopri5.rs:364-391 (rare: every 1000 accepted steps)
-            double stnum = 0.0, stden = 0.0;
+            double t_num[N], t_den[N];
             bool stiff_break = false;
 { const double cA61 = KC(A61), cA62 = KC(A62), cA63 = KC(A63), cA64 = KC(A64), cA65 = KC(A65);
 #pragma unroll
@@ -1027,10 +1070,11 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
                 const double d1 = k2[i] - k6[i];
                 const double ysti = y[i] + h * (cA61 * k1[i] + cA62 * k2[i] + cA63 * k3[i] + cA64 * k4[i] + cA65 * k5[i]);
                 const double d2 = y1[i] - ysti;
-                stnum += d1 * d1;
-                stden += d2 * d2;
+                t_num[i] = d1 * d1;
+                t_den[i] = d2 * d2;
             }
 }
+            const double stnum = NormOps<R>::sum(t_num), stden = NormOps<R>::sum(t_den);
             IVP_STIFF_BOOKKEEPING(3.25)
             if (stiff_break) { L.h = h; L.status = 4; return false; }                  // ProbablyStiff
         }
@@ -1215,22 +1259,24 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         k5[i] = y[i] + h * k4[i];
     }
 }
-    double err = 0.0, err2 = 0.0;
+    double t_err[N], t_err2[N];
 { const double cBH1 = KC(BH1), cBH2 = KC(BH2), cBH3 = KC(BH3), cER1 = KC(ER1), cER6 = KC(ER6), cER7 = KC(ER7), cER8 = KC(ER8), cER9 = KC(ER9), cER10 = KC(ER10), cER11 = KC(ER11), cER12 = KC(ER12);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double sk = a.atol[i] + a.rtol[i] * fmax(fabs(y[i]), fabs(k5[i]));
         double erri = k4[i] - cBH1 * k1[i] - cBH2 * k9[i] - cBH3 * k3[i];
         double q = erri / sk;
-        err2 += q * q;
+        t_err2[i] = q * q;
         erri = cER1 * k1[i] + cER6 * k6[i] + cER7 * k7[i] + cER8 * k8[i] + cER9 * k9[i] + cER10 * k10[i] + cER11 * k2[i] + cER12 * k3[i];
         q = erri / sk;
-        err += q * q;
+        t_err[i] = q * q;
     }
 }
+    double err = NormOps<R>::sum(t_err);
+    const double err2 = NormOps<R>::sum(t_err2);
     double deno = err + 0.01 * err2;
     if (deno <= 0.0) deno = 1.0;
-    err = fabs(h) * err * sqrt(1.0 / ((double)N * deno));
+    err = fabs(h) * err * sqrt(1.0 / ((double)NormOps<R>::NT * deno));
 
     const double fac11 = ivp_pow(err, IVP_CTL(ctl_expo1, d_expo1));
     double fac = fac11 / ivp_pow(L.facold, CTL ? a.ctl_beta : d_beta);
@@ -1244,15 +1290,16 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         R::ode(xph, k5, k4, p);
         L.d_nfev += 1;
         if (stiff_tick<CTL>(a, j, L.flags, L.d_naccpt)) {  // dop853.rs:447-472
-            double stnum = 0.0, stden = 0.0;
+            double t_num[N], t_den[N];
             bool stiff_break = false;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const double d1 = k4[i] - k3[i];
                 const double d2 = k5[i] - y1[i];
-                stnum += d1 * d1;
-                stden += d2 * d2;
+                t_num[i] = d1 * d1;
+                t_den[i] = d2 * d2;
             }
+            const double stnum = NormOps<R>::sum(t_num), stden = NormOps<R>::sum(t_den);
             IVP_STIFF_BOOKKEEPING(6.1)
             if (stiff_break) { L.h = h; L.status = 4; return false; }
         }
@@ -1334,7 +1381,7 @@ template <class R, bool FULL, bool CTL = false>
 IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE
-    constexpr int N = R::N, P = R::P;
+    constexpr int N = R::N;
     // tableau, rk23.rs:325-347
     constexpr double C2 = 0.5, C3 = 0.75, A21 = 0.5, A32 = 0.75;
     constexpr double B1 = 2.0 / 9.0, B2 = 1.0 / 3.0, B3 = 4.0 / 9.0;
@@ -1371,14 +1418,15 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
     for (int i = 0; i < N; ++i) ye[i] = h * (cE1 * k1[i] + cE2 * k2[i] + cE3 * k3[i] + cE4 * k4[i]);
 }
-    double err = 0.0;
+    double t_err[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double tl = a.atol[i] + a.rtol[i] * fmax(fabs(yt[i]), fabs(y[i]));
         const double q = ye[i] / tl;
-        err += q * q;
+        t_err[i] = q * q;
     }
-    err = sqrt(err / (double)N);
+    double err = NormOps<R>::sum(t_err);
+    err = sqrt(err / (double)NormOps<R>::NT);
 
     if (err <= 1.0) {
         L.d_nstep += 1;
@@ -1431,7 +1479,7 @@ template <class R, bool FULL>
 IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE
-    constexpr int N = R::N, P = R::P;
+    constexpr int N = R::N;
     constexpr double C2 = 0.5, C3 = 0.5, A21 = 0.5, A32 = 0.5;   // rk4.rs:247-257 (C4 = A43 = 1)
     constexpr double B1 = 1.0 / 6.0, B2 = 1.0 / 3.0, B3 = 1.0 / 3.0, B4 = 1.0 / 6.0;
 

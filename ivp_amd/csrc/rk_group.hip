@@ -1,5 +1,5 @@
 // rk_group.hip -- the kernels in which several lanes share one trajectory, and their launch tables:
-//   * rk_group.h: wave-per-trajectory DOPRI5 for large state dimensions (8 < n <= 512);
+//   * rk_group.h: wave-per-trajectory RK23 / DOPRI5 / DOP853 / RK4 for large state dimensions (8 < n <= 512);
 //   * rk_coop.h:  eight lanes per trajectory (n <= 8) for the latency-bound tail of a batch.  Compiled twice like rk_kernels.hip: strict (-ffp-contract=off, index-order error-norm sum) and
 // fast (-ffp-contract=fast, __shfl_xor butterfly).  Coefficients stay resident in registers (IVP_HOIST): a lone
 // wave per trajectory is latency-bound and has VGPRs to spare.
@@ -25,14 +25,27 @@
 
 namespace {
 
-template <class R>
-hipError_t launch_group(int what, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+template <int M, class R, bool FULL>
+hipError_t launch_group_one(int what, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     const dim3 grid(trajectories), block(IVP_WAVE);   // one wavefront per trajectory
     if (grid.x == 0) return hipSuccess;
-    if (what == IVP_LAUNCH_INIT) hipLaunchKernelGGL((IVP_NS::group_init_kernel<R>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((IVP_NS::group_chunk_kernel<R>), grid, block, 0, s, a);
+    if (what == IVP_LAUNCH_INIT) hipLaunchKernelGGL((IVP_NS::group_init_kernel<M, R, FULL>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((IVP_NS::group_chunk_kernel<M, R, FULL>), grid, block, 0, s, a);
     return hipGetLastError();
+}
+
+template <class R>
+hipError_t launch_group(int what, int method, bool full, const IvpKArgs &a, uint32_t n, hipStream_t s)
+{
+    using namespace IVP_NS;
+    switch (method) {
+    case M_RK23: return full ? launch_group_one<M_RK23, R, true>(what, a, n, s) : launch_group_one<M_RK23, R, false>(what, a, n, s);
+    case M_DOPRI5: return full ? launch_group_one<M_DOPRI5, R, true>(what, a, n, s) : launch_group_one<M_DOPRI5, R, false>(what, a, n, s);
+    case M_DOP853: return full ? launch_group_one<M_DOP853, R, true>(what, a, n, s) : launch_group_one<M_DOP853, R, false>(what, a, n, s);
+    case M_RK4: return full ? launch_group_one<M_RK4, R, true>(what, a, n, s) : launch_group_one<M_RK4, R, false>(what, a, n, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <class R>
@@ -68,11 +81,11 @@ hipError_t IVP_COOP_LAUNCH_NAME(int rhs_id, const IvpKArgs &a, uint32_t trajecto
     return hipErrorInvalidValue;
 }
 
-hipError_t IVP_LAUNCH_NAME(int what, int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     switch (rhs_id) {
-    case 100: return launch_group<IVP_NS::RhsLinearDecay100>(what, a, trajectories, s);
-    case 101: return launch_group<IVP_NS::RhsHeat1D256>(what, a, trajectories, s);
+    case 100: return launch_group<IVP_NS::RhsLinearDecay100>(what, method, full, a, trajectories, s);
+    case 101: return launch_group<IVP_NS::RhsHeat1D256>(what, method, full, a, trajectories, s);
     }
     return hipErrorInvalidValue;
 }

@@ -11,9 +11,9 @@ hipError_t ivp_launch_strict_hoist(int what, int method, int rhs_id, bool full, 
 hipError_t ivp_launch_fast_hoist(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 hipError_t ivp_launch_fast(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 
-// wave-per-trajectory kernels (rk_group.hip): grid = `trajectories` one-wave blocks; DOPRI5, end state only
-hipError_t ivp_launch_group_strict(int what, int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
-hipError_t ivp_launch_group_fast(int what, int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+// wave-per-trajectory kernels (rk_group.hip): grid = `trajectories` one-wave blocks; RK23 / DOPRI5 / DOP853 / RK4
+hipError_t ivp_launch_group_strict(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+hipError_t ivp_launch_group_fast(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
 
 // lane-cooperative DOPRI5 chunk kernel (rk_coop.h): eight lanes per trajectory, grid = ceil(trajectories / 8) waves;
 // built-in right-hand sides, end-state runs

@@ -90,11 +90,59 @@ def test_large_n_unsupported_requests_fail_loudly():
     y0 = np.ones((100, 4))
     f = ivp_amd.LinearDecay100()
     with pytest.raises(ivp_amd.ConfigError) as e:
-        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOP853"))
+        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="BDF"))
     assert e.value.code == -101
-    for bad in (dict(t_eval=[0.5]), dict(max_log=16), dict(rtol=[1e-6] * 100)):
-        with pytest.raises(ivp_amd.ConfigError):
-            ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOPRI5", **bad))
+    with pytest.raises(ivp_amd.ConfigError):
+        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOPRI5", rtol=[1e-6] * 100))
+
+
+@pytest.mark.parametrize("method,tol", [("RK23", (1e-4, 1e-7)), ("DOP853", (1e-9, 1e-11)), ("DOP853", (1e-4, 1e-6)), ("RK4", None)])
+def test_large_n_other_methods_bitexact(method, tol):
+    """The same attempt bodies as the thread-per-trajectory kernels, instantiated per lane-slice: RK23, DOP853, RK4."""
+    kw = dict(method=method) if tol is None else dict(method=method, rtol=tol[0], atol=tol[1])
+    y0, p, t0, t1 = _heat_batch(96, seed=21)
+    ref = oracle_batch("heat1d256", y0, p, t0, t1, **kw)
+    got = gpu_batch("heat1d256", y0, p, t0, t1, **kw)
+    assert_bitexact(got, ref, f"heat {method} ")
+    y0, p, t0, t1 = _decay_batch(64, seed=22)
+    ref = oracle_batch("linear_decay100", y0, p, t0, t1, **kw)
+    got = gpu_batch("linear_decay100", y0, p, t0, t1, chunk=9, **kw)
+    assert_bitexact(got, ref, f"decay {method} ")
+
+
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+def test_large_n_t_eval_log_and_dense_match_oracle(method):
+    """DefaultSolOut on the wave-per-trajectory path: t_eval samples, accepted-step log and dense segments record for
+    record (solout.rs:344-428), including points outside the span and a backward run."""
+    from oracle import oracle as O
+    import ivp_amd
+    rng = np.random.default_rng(31)
+    x = np.arange(1, 257) / 257.0
+    B = 12
+    y0 = np.sin(np.pi * x[:, None] * rng.integers(1, 4, B)[None, :]) + 0.05 * rng.standard_normal((256, B))
+    kappa = rng.uniform(30.0, 120.0, (1, B))
+    tol = dict(RK23=(1e-4, 1e-7), DOPRI5=(1e-6, 1e-9), DOP853=(1e-8, 1e-10))[method]
+    te = np.concatenate([[-0.1], np.linspace(0.0, 0.3, 17), [0.31]])
+    got = gpu_batch("heat1d256", y0, kappa, 0.0, 0.3, method=method, rtol=tol[0], atol=tol[1], t_eval=te)
+    ref = oracle_batch("heat1d256", y0, kappa, 0.0, 0.3, method=method, rtol=tol[0], atol=tol[1], t_eval=te)
+    assert_bitexact(got, ref, f"t_eval {method} ")
+    assert np.array_equal(got["n_filled"], ref["n_filled"]) and (got["n_filled"] == 17).all()
+    for b in range(B):
+        assert np.array_equal(got["y_eval"][:17, :, b], ref["y_eval"][:17, :, b])
+        assert np.array_equal(got["eval_idx"][:17, b], np.arange(1, 18))
+    # step log + dense segments for one trajectory through the single-solve front end, against the oracle's Solution
+    f = ivp_amd.Heat1D256(float(kappa[0, 0]))
+    s = ivp_amd.solve_ivp(f, 0.0, 0.3, y0[:, 0], ivp_amd.Options(method=method, rtol=tol[0], atol=tol[1], dense_output=True))
+    o = O.solve_ivp("heat1d256", 0.0, 0.3, list(y0[:, 0]), params=[float(kappa[0, 0])], method=method, rtol=tol[0], atol=tol[1],
+                    dense_output=True, detpow=True)
+    assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
+    assert (s.nfev, s.naccpt, s.nrejct) == (o.nfev, o.naccpt, o.nrejct)
+    for tq in (0.0, 0.0123, 0.15, 0.2999, 0.3):
+        assert np.array_equal(s.sol(tq), o.sol(tq))
+    # backward in time with first_step (step-record mode enforces the first output, solout.rs:390-417)
+    s = ivp_amd.solve_ivp(ivp_amd.LinearDecay100(), 1.0, 0.2, np.linspace(0.5, 1.5, 100), ivp_amd.Options(method=method, rtol=tol[0], atol=tol[1], first_step=0.05))
+    o = O.solve_ivp("linear_decay100", 1.0, 0.2, list(np.linspace(0.5, 1.5, 100)), method=method, rtol=tol[0], atol=tol[1], first_step=0.05, detpow=True)
+    assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
 
 
 def test_large_n_single_solve_ivp_and_jit_component_form():
@@ -104,7 +152,7 @@ def test_large_n_single_solve_ivp_and_jit_component_form():
     from oracle import oracle as O
     o = O.solve_ivp("linear_decay100", 0.0, 5.0, list(np.linspace(0, 1, 100)), method="DOPRI5", rtol=1e-6, atol=1e-9, detpow=True)
     assert (s.naccpt, s.nrejct, s.nfev, int(s.status)) == (o.naccpt, o.nrejct, o.nfev, o.status)
-    assert np.array_equal(s.y[-1], o.y[-1]) and s.t[-1] == 5.0
+    assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y) and s.t[-1] == 5.0
 
     src = r'''
     __device__ double ode_comp(int i, double t, const double* y, const double* p)
@@ -123,8 +171,9 @@ def test_large_n_single_solve_ivp_and_jit_component_form():
         return d
     rng = np.random.default_rng(2)
     y0 = rng.standard_normal(40)
-    s = ivp_amd.solve_ivp(f, 0.0, 4.0, y0, ivp_amd.Options(method="DOPRI5", rtol=1e-7, atol=1e-9))
-    o = O.solve_ivp(ring, 0.0, 4.0, list(y0), params=[3.0], method="DOPRI5", rtol=1e-7, atol=1e-9, detpow=True)
-    assert int(s.status) == 0 and (s.naccpt, s.nrejct, s.nfev) == (o.naccpt, o.nrejct, o.nfev)
-    # numpy's roll-based RHS adds in the same order as the snippet: bit-exact end state
-    assert np.array_equal(s.y[-1], o.y[-1])
+    for method in ("DOPRI5", "DOP853"):
+        s = ivp_amd.solve_ivp(f, 0.0, 4.0, y0, ivp_amd.Options(method=method, rtol=1e-7, atol=1e-9, t_eval=[1.0, 2.5, 4.0]))
+        o = O.solve_ivp(ring, 0.0, 4.0, list(y0), params=[3.0], method=method, rtol=1e-7, atol=1e-9, t_eval=[1.0, 2.5, 4.0], detpow=True)
+        assert int(s.status) == 0 and (s.naccpt, s.nrejct, s.nfev) == (o.naccpt, o.nrejct, o.nfev)
+        # numpy's roll-based RHS adds in the same order as the snippet: bit-exact samples
+        assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
