@@ -154,7 +154,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    kern_ms = launches = attempts = slots = lane_launches = 0.0
+    kern_ms = launches = attempts = slots = lane_launches = coop_ms = coop_launches = 0.0
     t_begin = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -163,6 +163,8 @@ def main():
         launches += st["launches"]
         slots += st["lane_attempt_slots"]
         lane_launches += st["lane_launches"]
+        coop_ms += st["coop_kernel_ms"]
+        coop_launches += st["coop_launches"]
     sync_all()
     elapsed = time.perf_counter() - t_begin
 
@@ -223,6 +225,13 @@ def main():
                 "traffic": traffic,
                 "kernel": wl["kernel"], "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": launches / args.steps,
+                # per kernel name, for a one-to-one check against the rocprofv3 --kernel-trace --stats rows
+                "per_kernel": {
+                    "chunk_kernel_t": {"launches_per_step": (launches - coop_launches) / args.steps,
+                                       "avg_launch_ms": (kern_ms - coop_ms) / max(launches - coop_launches, 1)},
+                    "coop_chunk_kernel": {"launches_per_step": coop_launches / args.steps,
+                                          "avg_launch_ms": (coop_ms / coop_launches) if coop_launches else None},
+                },
                 "note": "state is device-resident: HBM traffic is per trajectory per launch, not per step; "
                         "this fraction is informational, the binding resource is FP64 VALU issue (roofline_fp64)",
             },

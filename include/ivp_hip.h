@@ -213,6 +213,8 @@ typedef struct {
     uint64_t total_attempts;    /* sum over the batch of step attempts                   */
     uint64_t lane_attempt_slots;/* sum over launches of (lanes launched x attempts the wave ran): divergence accounting */
     uint64_t lane_launches;     /* sum over launches of trajectories that loaded + stored their state */
+    uint32_t coop_launches;     /* of `launches`: lane-cooperative tail launches (variant 3 / auto policy) */
+    double coop_kernel_ms;      /* of `step_kernel_ms`: time in those launches                            */
 } ivp_run_stats_t;
 
 typedef struct ivp_ctx ivp_ctx_t;

@@ -441,17 +441,17 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     auto launch_hoist = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast_hoist : ivp_launch_strict_hoist;
     bool use_hoist = false;
     const bool jit = prob->rhs_id == IVP_RHS_JIT;
-    // lane-cooperative DOPRI5 kernel (rk_coop.h: eight lanes per trajectory): available for built-in problems with
-    // n <= 8 on end-state runs.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict
+    // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for built-in
+    // problems with n <= 8 and no events.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict
     // mode the loop switches to it for the latency-bound tail; fast mode only on request (variant 3).
-    const bool coop_ok = !jit && !group && !full && opt->method == IVP_DOPRI5;
+    const bool coop_ok = !jit && !group && n_events == 0 && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
     bool use_coop = false;
     const int variant = (opt->variant == 3 && !coop_ok) ? 0 : opt->variant;
     auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
         if (jit) return ivp_jit_launch(prob->jit, what, opt->method, opt->fp_mode, full, ka, lanes, s);
         if (group) return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_group_fast : ivp_launch_group_strict)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
         if (use_coop && what == IVP_LAUNCH_CHUNK)
-            return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_coop_fast : ivp_launch_coop_strict)(prob->rhs_id, ka, lanes, s);
+            return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_coop_fast : ivp_launch_coop_strict)(opt->method, prob->rhs_id, full, ka, lanes, s);
         return (use_hoist ? launch_hoist : launch_lean)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
     };
 
@@ -465,6 +465,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
         return ctx->events[ev_used++];
     };
     std::vector<std::pair<hipEvent_t, hipEvent_t>> step_ev;
+    std::vector<char> step_is_coop;
     hipEvent_t ev_t0 = nullptr, ev_init1 = nullptr, ev_end = nullptr;
 
     // ---- init: f0, hinit / first_step, initial SolOut call ----
@@ -501,9 +502,11 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
         use_hoist = !opt->has_settings &&   // run-time controller fields exist in the lean builds only
                     (variant == 2 ||
                      (variant == 0 && (opt->fp_mode == IVP_FP_FAST ? B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
-        // eight lanes per trajectory pay off once the cooperative waves still fit one per SIMD
+        // eight lanes per trajectory pay off once the cooperative waves still fit one per SIMD, and only for systems
+        // with enough components to share out (measured: 1.3-1.45x at n = 6, break-even at n = 3, a loss at n = 2)
         use_coop = coop_ok && (variant == 3 ||
-                               (variant == 0 && opt->fp_mode == IVP_FP_STRICT && adaptive && (size_t)lanes * 8u <= kOneWavePerSimd));
+                               (variant == 0 && opt->fp_mode == IVP_FP_STRICT && adaptive && n >= 4 &&
+                                (size_t)lanes * 8u <= kOneWavePerSimd));
         const int launches_per_sync = tail ? 1 : 4;
         const uint32_t this_chunk = tail ? 1024u : chunk;
         for (int r = 0; r < launches_per_sync; ++r, ++c) {
@@ -524,8 +527,9 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (profile) { e0 = ev(); HIP_TRY(ctx, hipEventRecord(e0, s)); }
             HIP_TRY(ctx, do_launch(IVP_LAUNCH_CHUNK, ka, lanes));
-            if (profile) { e1 = ev(); HIP_TRY(ctx, hipEventRecord(e1, s)); step_ev.emplace_back(e0, e1); }
+            if (profile) { e1 = ev(); HIP_TRY(ctx, hipEventRecord(e1, s)); step_ev.emplace_back(e0, e1); step_is_coop.push_back(use_coop ? 1 : 0); }
             ctx->stats.launches += 1;
+            if (use_coop) ctx->stats.coop_launches += 1;
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         if (!err_checked) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -546,9 +550,10 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_t0, ev_init1));
         ctx->stats.init_kernel_ms = ms;
-        for (auto &pr : step_ev) {
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        for (size_t q = 0; q < step_ev.size(); ++q) {
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, step_ev[q].first, step_ev[q].second));
             ctx->stats.step_kernel_ms += ms;
+            if (step_is_coop[q]) ctx->stats.coop_kernel_ms += ms;
         }
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_t0, ev_end));
         ctx->stats.total_ms = ms;

@@ -65,6 +65,7 @@ struct OutMap<GroupRhs<R>, void> {
 template <class R>
 struct NormOps<GroupRhs<R>, void> {
     enum { NT = R::N };
+    static __device__ __forceinline__ double tol(const double *arr, int) { return arr[0]; }   // scalar tolerances
     template <int C>
     static __device__ __forceinline__ double sum(const double (&term)[C])
     {

@@ -48,35 +48,47 @@ hipError_t launch_group(int what, int method, bool full, const IvpKArgs &a, uint
     return hipErrorInvalidValue;
 }
 
-template <class R>
-hipError_t launch_coop(const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+template <int M, class R, bool FULL>
+hipError_t launch_coop_one(const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     const dim3 grid((trajectories + 7) / 8), block(IVP_WAVE);   // eight lanes per trajectory
     if (grid.x == 0) return hipSuccess;
-    hipLaunchKernelGGL((IVP_NS::coop_chunk_kernel<R>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((IVP_NS::coop_chunk_kernel<M, R, FULL>), grid, block, 0, s, a);
     return hipGetLastError();
+}
+template <class R>
+hipError_t launch_coop(int method, bool full, const IvpKArgs &a, uint32_t n, hipStream_t s)
+{
+    using namespace IVP_NS;
+    if constexpr (R::NE > 0) {
+        return hipErrorInvalidValue;   // event problems always run FULL kernels with events: not cooperative
+    } else {
+        if (method == M_DOPRI5) return full ? launch_coop_one<M_DOPRI5, R, true>(a, n, s) : launch_coop_one<M_DOPRI5, R, false>(a, n, s);
+        if (method == M_DOP853) return full ? launch_coop_one<M_DOP853, R, true>(a, n, s) : launch_coop_one<M_DOP853, R, false>(a, n, s);
+        return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
 
-hipError_t IVP_COOP_LAUNCH_NAME(int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+hipError_t IVP_COOP_LAUNCH_NAME(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     switch (rhs_id) {
-    case 0: return launch_coop<IVP_NS::RhsDecay>(a, trajectories, s);
-    case 1: return launch_coop<IVP_NS::RhsSho>(a, trajectories, s);
-    case 2: return launch_coop<IVP_NS::RhsVdp>(a, trajectories, s);
-    case 3: return launch_coop<IVP_NS::RhsCr3bp>(a, trajectories, s);
-    case 4: return launch_coop<IVP_NS::RhsLorenz>(a, trajectories, s);
-    case 5: return launch_coop<IVP_NS::RhsZero>(a, trajectories, s);
-    case 6: return launch_coop<IVP_NS::RhsRational>(a, trajectories, s);
-    case 7: return launch_coop<IVP_NS::RhsExp2>(a, trajectories, s);
-    case 8: return launch_coop<IVP_NS::RhsLinear>(a, trajectories, s);
-    case 9: return launch_coop<IVP_NS::RhsRobertson>(a, trajectories, s);
-    case 10: return launch_coop<IVP_NS::RhsVdpEps>(a, trajectories, s);
-    case 11: return launch_coop<IVP_NS::RhsShoEv>(a, trajectories, s);
-    case 12: return launch_coop<IVP_NS::RhsBall>(a, trajectories, s);
-    case 13: return launch_coop<IVP_NS::RhsCannon>(a, trajectories, s);
-    case 14: return launch_coop<IVP_NS::RhsRationalEv>(a, trajectories, s);
+    case 0: return launch_coop<IVP_NS::RhsDecay>(method, full, a, trajectories, s);
+    case 1: return launch_coop<IVP_NS::RhsSho>(method, full, a, trajectories, s);
+    case 2: return launch_coop<IVP_NS::RhsVdp>(method, full, a, trajectories, s);
+    case 3: return launch_coop<IVP_NS::RhsCr3bp>(method, full, a, trajectories, s);
+    case 4: return launch_coop<IVP_NS::RhsLorenz>(method, full, a, trajectories, s);
+    case 5: return launch_coop<IVP_NS::RhsZero>(method, full, a, trajectories, s);
+    case 6: return launch_coop<IVP_NS::RhsRational>(method, full, a, trajectories, s);
+    case 7: return launch_coop<IVP_NS::RhsExp2>(method, full, a, trajectories, s);
+    case 8: return launch_coop<IVP_NS::RhsLinear>(method, full, a, trajectories, s);
+    case 9: return launch_coop<IVP_NS::RhsRobertson>(method, full, a, trajectories, s);
+    case 10: return launch_coop<IVP_NS::RhsVdpEps>(method, full, a, trajectories, s);
+    case 11: return launch_coop<IVP_NS::RhsShoEv>(method, full, a, trajectories, s);
+    case 12: return launch_coop<IVP_NS::RhsBall>(method, full, a, trajectories, s);
+    case 13: return launch_coop<IVP_NS::RhsCannon>(method, full, a, trajectories, s);
+    case 14: return launch_coop<IVP_NS::RhsRationalEv>(method, full, a, trajectories, s);
     }
     return hipErrorInvalidValue;
 }

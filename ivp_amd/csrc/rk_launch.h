@@ -15,7 +15,7 @@ hipError_t ivp_launch_fast(int what, int method, int rhs_id, bool full, const Iv
 hipError_t ivp_launch_group_strict(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
 hipError_t ivp_launch_group_fast(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
 
-// lane-cooperative DOPRI5 chunk kernel (rk_coop.h): eight lanes per trajectory, grid = ceil(trajectories / 8) waves;
-// built-in right-hand sides, end-state runs
-hipError_t ivp_launch_coop_strict(int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
-hipError_t ivp_launch_coop_fast(int rhs_id, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+// lane-cooperative chunk kernels (rk_coop.h): eight lanes per trajectory, grid = ceil(trajectories / 8) waves;
+// DOPRI5 / DOP853, built-in right-hand sides without events
+hipError_t ivp_launch_coop_strict(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+hipError_t ivp_launch_coop_fast(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);

@@ -12,19 +12,40 @@ from tests.common import assert_bitexact, gpu_batch, oracle_batch
 
 pytestmark = pytest.mark.gpu
 
-DOPRI5_END_STATE = [c for c in CASES if "DOPRI5" in c[0].upper() or c[0] in ("C1-decay", "exp2-vector-rtol")]
+COOP_CASES = [c for c in CASES if "DOPRI5" in c[0].upper() or "DOP853" in c[0].upper() or c[0] in ("C1-decay", "exp2-vector-rtol")]
 
 
-@pytest.mark.parametrize("case", DOPRI5_END_STATE, ids=[c[0] for c in DOPRI5_END_STATE])
+@pytest.mark.parametrize("case", COOP_CASES, ids=[c[0] for c in COOP_CASES])
 def test_coop_everywhere_bitexact_vs_oracle(case):
     name, rhs, build = case
     y0, p, t0, t1, o = build()
-    if "t_eval" in o:
-        pytest.skip("FULL runs do not use the cooperative kernel")
     ref = oracle_batch(rhs, y0, p, t0, t1, **o)
     for chunk in (0, 17):
         got = gpu_batch(rhs, y0, p, t0, t1, variant=3, chunk=chunk, **o)
         assert_bitexact(got, ref, f"{name} coop chunk={chunk}: ")
+        if "t_eval" in o:
+            assert np.array_equal(got["n_filled"], ref["n_filled"])
+            for b in range(y0.shape[1]):
+                m = int(ref["n_filled"][b])
+                assert np.array_equal(got["y_eval"][:m, :, b], ref["y_eval"][:m, :, b])
+
+
+@pytest.mark.parametrize("method", ["DOPRI5", "DOP853"])
+def test_coop_full_outputs_match_thread_per_trajectory_kernels(method):
+    """t_eval samples, step log and dense segments written by the cooperative kernels (variant 3) are the records the
+    thread-per-trajectory kernels (variant 1) write, bit for bit."""
+    y0, p, t0, t1 = W.vdp_batch(300)
+    tol = dict(DOPRI5=(1e-6, 1e-9), DOP853=(1e-8, 1e-10))[method]
+    te = np.linspace(0.0, 50.0, 41)
+    a = gpu_batch("vdp", y0, p, t0, t1, method=method, rtol=tol[0], atol=tol[1], t_eval=te, variant=1)
+    b = gpu_batch("vdp", y0, p, t0, t1, method=method, rtol=tol[0], atol=tol[1], t_eval=te, variant=3)
+    assert_bitexact(b, a, "t_eval ")
+    assert np.array_equal(a["n_filled"], b["n_filled"]) and np.array_equal(a["y_eval"], b["y_eval"]) and np.array_equal(a["eval_idx"], b["eval_idx"])
+    a = gpu_batch("vdp", y0[:, :40], p[:, :40], t0, t1[:40], method=method, rtol=tol[0], atol=tol[1], max_log=900, dense_output=True, variant=1)
+    b = gpu_batch("vdp", y0[:, :40], p[:, :40], t0, t1[:40], method=method, rtol=tol[0], atol=tol[1], max_log=900, dense_output=True, variant=3)
+    assert_bitexact(b, a, "log ")
+    for k in ("n_log", "t_log", "y_log", "n_seg", "seg_xold", "seg_h", "seg_cont"):
+        assert np.array_equal(a[k], b[k]), k
 
 
 def test_c2_tail_switch_is_invisible():
