@@ -444,11 +444,11 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for built-in
     // problems with n <= 8 and no events.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict
     // mode the loop switches to it for the latency-bound tail; fast mode only on request (variant 3).
-    const bool coop_ok = !jit && !group && n_events == 0 && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
+    const bool coop_ok = !group && n_events == 0 && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
     bool use_coop = false;
     const int variant = (opt->variant == 3 && !coop_ok) ? 0 : opt->variant;
     auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
-        if (jit) return ivp_jit_launch(prob->jit, what, opt->method, opt->fp_mode, full, ka, lanes, s);
+        if (jit) return ivp_jit_launch(prob->jit, (use_coop && what == IVP_LAUNCH_CHUNK) ? IVP_LAUNCH_COOP : what, opt->method, opt->fp_mode, full, ka, lanes, s);
         if (group) return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_group_fast : ivp_launch_group_strict)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
         if (use_coop && what == IVP_LAUNCH_CHUNK)
             return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_coop_fast : ivp_launch_coop_strict)(opt->method, prob->rhs_id, full, ka, lanes, s);

@@ -26,7 +26,7 @@ namespace {
 
 struct JitModule {
     hipModule_t mod = nullptr;
-    hipFunction_t init = nullptr, chunk = nullptr;
+    hipFunction_t init = nullptr, chunk = nullptr, coop = nullptr;   // coop: lane-cooperative chunk kernel (rk_coop.h), optional
 };
 
 struct JitRhs {
@@ -88,6 +88,13 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
                   r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false",
                   (ctl && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? "true" : "false");
     s += buf;
+    if (r.ne == 0 && (method == IVP_DOPRI5 || method == IVP_DOP853)) {   // eight lanes per trajectory for the tail of a batch
+        s += join(k_src_rk_coop_h);
+        std::snprintf(buf, sizeof buf,
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_coop(const IvpKArgs a)\n"
+                      "{ ivp_jit::coop_chunk_body<%d, ivp_jit::RhsUser, %s>(a); }\n", method, full ? "true" : "false");
+        s += buf;
+    }
     return s;
 }
 
@@ -125,6 +132,7 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitM
         r.log = "kernel lookup failed";
         return IVP_ERR_HIP;
     }
+    if (hipModuleGetFunction(&out->coop, out->mod, "ivp_jit_coop") != hipSuccess) out->coop = nullptr;   // not every module has one
     return IVP_OK;
 }
 
@@ -195,9 +203,15 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool 
         }
         m = it->second;
     }
-    const unsigned grid = r->n > IVP_MAX_N ? lanes : (lanes + IVP_WAVE - 1) / IVP_WAVE;   // large n: one wave per trajectory
+    unsigned grid = r->n > IVP_MAX_N ? lanes : (lanes + IVP_WAVE - 1) / IVP_WAVE;   // large n: one wave per trajectory
+    hipFunction_t fn = what == IVP_LAUNCH_INIT ? m.init : m.chunk;
+    if (what == IVP_LAUNCH_COOP) {
+        if (!m.coop) return hipErrorInvalidValue;
+        fn = m.coop;
+        grid = (lanes + 7) / 8;
+    }
     if (grid == 0) return hipSuccess;
     IvpKArgs ka = a;
     void *args[] = {&ka};
-    return hipModuleLaunchKernel(what == IVP_LAUNCH_INIT ? m.init : m.chunk, grid, 1, 1, IVP_WAVE, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(fn, grid, 1, 1, IVP_WAVE, 1, 1, 0, s, args, nullptr);
 }

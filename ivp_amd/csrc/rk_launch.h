@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "ivp_kargs.h"
 
-enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1 };
+enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1, IVP_LAUNCH_COOP = 2 /* hiprtc modules only */ };
 
 // `lanes` = upper bound of trajectories the launch has to cover (grid = ceil(lanes / 64) one-wave blocks).
 hipError_t ivp_launch_strict(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);

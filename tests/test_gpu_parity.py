@@ -251,6 +251,11 @@ def test_user_rhs_compiled_with_hiprtc_matches_builtin_and_oracle():
         ref = oracle_batch("cr3bp", y0, p, t0, t1, threads=8, method=method, rtol=rt, atol=at)
         got = {k: getattr(r, k) for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct")}
         assert_bitexact(got, ref, f"jit {method}: ")
+        if method != "RK23":   # the hiprtc module's lane-cooperative kernel (generic shuffle-gather form), whole run
+            r = ivp_amd.solve_ivp_batch(f, t0, t1, y0, p, ivp_amd.Options(method=method, rtol=rt, atol=at, variant=3, profile=1))
+            got = {k: getattr(r, k) for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct")}
+            assert_bitexact(got, ref, f"jit coop {method}: ")
+            assert r.stats["coop_launches"] == r.stats["launches"] > 0
 
 
 def test_user_rhs_python_callable_cross_check():
