@@ -132,7 +132,10 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitM
         r.log = "kernel lookup failed";
         return IVP_ERR_HIP;
     }
-    if (hipModuleGetFunction(&out->coop, out->mod, "ivp_jit_coop") != hipSuccess) out->coop = nullptr;   // not every module has one
+    if (hipModuleGetFunction(&out->coop, out->mod, "ivp_jit_coop") != hipSuccess) {   // not every module has one
+        out->coop = nullptr;
+        (void)hipGetLastError();   // the failed lookup must not surface as the "last error" of a later launch
+    }
     return IVP_OK;
 }
 

@@ -30,6 +30,7 @@ hipError_t launch_group_one(int what, const IvpKArgs &a, uint32_t trajectories, 
 {
     const dim3 grid(trajectories), block(IVP_WAVE);   // one wavefront per trajectory
     if (grid.x == 0) return hipSuccess;
+    (void)hipGetLastError();   // drop a stale error of some earlier runtime call: the value returned below is this launch's
     if (what == IVP_LAUNCH_INIT) hipLaunchKernelGGL((IVP_NS::group_init_kernel<M, R, FULL>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((IVP_NS::group_chunk_kernel<M, R, FULL>), grid, block, 0, s, a);
     return hipGetLastError();
@@ -53,6 +54,7 @@ hipError_t launch_coop_one(const IvpKArgs &a, uint32_t trajectories, hipStream_t
 {
     const dim3 grid((trajectories + 7) / 8), block(IVP_WAVE);   // eight lanes per trajectory
     if (grid.x == 0) return hipSuccess;
+    (void)hipGetLastError();   // drop a stale error of some earlier runtime call: the value returned below is this launch's
     hipLaunchKernelGGL((IVP_NS::coop_chunk_kernel<M, R, FULL>), grid, block, 0, s, a);
     return hipGetLastError();
 }

@@ -46,6 +46,7 @@ hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s
 {
     const dim3 grid((lanes + IVP_WAVE - 1) / IVP_WAVE), block(IVP_WAVE);
     if (grid.x == 0) return hipSuccess;
+    (void)hipGetLastError();   // drop a stale error of some earlier runtime call: the value returned below is this launch's
     if (what == IVP_LAUNCH_INIT) {
         hipLaunchKernelGGL((init_kernel_t<M, R, FULL>), grid, block, 0, s, a);
         return hipGetLastError();

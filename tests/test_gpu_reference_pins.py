@@ -324,7 +324,7 @@ def test_bouncing_ball_example_and_user_defined_events():  # examples/bouncing_b
     assert np.array_equal(s2.y, sol.y)
 
 
-@pytest.mark.parametrize("method", EXPLICIT + [Method.RK4])
+@pytest.mark.parametrize("method", EXPLICIT)
 def test_tbound_respected(method):  # tests/test_ivp.py:885-949, tests/test_edge_cases.py:55-121
     """The right-hand side is never evaluated outside [t0, tf]: the device RHS returns NaN there, which would poison
     the state (all stage abscissae are <= 1 and the last step lands exactly on tf)."""
@@ -335,7 +335,6 @@ def test_tbound_respected(method):  # tests/test_ivp.py:885-949, tests/test_edge
     """
     for a, b in ((0.0, 1.0), (1.0, 0.0), (0.0, 1e-3)):
         f = ivp_amd.DeviceIVP(src, n=1, params=(a, b))
-        o = Options(method=method) if method == Method.RK4 else Options(method=method, rtol=1e-6, atol=1e-9)
-        s = solve_ivp(f, a, b, [1.0], o)
+        s = solve_ivp(f, a, b, [1.0], Options(method=method, rtol=1e-6, atol=1e-9))
         assert s.status == Status.Success and s.t[-1] == b
         assert np.isfinite(s.y).all() and abs(s.y[-1][0] - np.exp(-(b - a))) < 1e-4
