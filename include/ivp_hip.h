@@ -94,7 +94,7 @@ typedef enum {
     IVP_RHS_BUILTIN_COUNT = 15,
     /* Large state dimensions (8 < n <= 512): one 64-lane wavefront integrates one trajectory, the state is
      * distributed over its lanes and the error norm is a wavefront reduction.  RK23 / DOPRI5 / DOP853 / RK4 with
-     * every output mode (t_eval, step log, dense output); scalar tolerances; no events, no BDF in this ABI version. */
+     * every output mode (t_eval, step log, dense output) and scalar or vector tolerances; no events, no BDF. */
     IVP_RHS_LINEAR_DECAY_100 = 100, /* y' = -y                            n=100 benches/benchmark.py:40-42,139-148 */
     IVP_RHS_HEAT1D_256 = 101,       /* y_i' = k (y_{i-1} - 2 y_i + y_{i+1}), p={k}  n=256 (method of lines)  */
     IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */

@@ -82,7 +82,7 @@ struct ivp_ctx {
     int device = 0;
     std::string err;
     // scratch (device)
-    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval;
+    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval, tolvec;
     DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
     DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
     DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu, prev_event, sc_n_ev;
@@ -138,7 +138,6 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     if (n > IVP_MAX_N) {   // wave-per-trajectory kernels: explicit RK methods, scalar tolerances, no events
         if (opt->method == IVP_BDF)
             return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "n = %d > %d: BDF is not available for large-n problems", n, IVP_MAX_N);
-        if (opt->rtol_vec || opt->atol_vec) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "large-n problems take scalar tolerances");
     }
     if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
     if (opt->method == IVP_RADAU)
@@ -215,7 +214,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval,
+    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval, &c->tolvec,
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
@@ -315,8 +314,20 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     a.t0_stride = t0_len == 1 ? 0u : 1u;
     a.t1_stride = t1_len == 1 ? 0u : 1u;
     for (int i = 0; i < IVP_MAX_N; ++i) {
-        a.rtol[i] = (opt->rtol_vec && i < n) ? opt->rtol_vec[i] : opt->rtol;
-        a.atol[i] = (opt->atol_vec && i < n) ? opt->atol_vec[i] : opt->atol;
+        a.rtol[i] = (opt->rtol_vec && i < n && n <= IVP_MAX_N) ? opt->rtol_vec[i] : opt->rtol;
+        a.atol[i] = (opt->atol_vec && i < n && n <= IVP_MAX_N) ? opt->atol_vec[i] : opt->atol;
+    }
+    if (n > IVP_MAX_N && (opt->rtol_vec || opt->atol_vec)) {   // Tolerance::Vector for a large-n problem: [n] on the device
+        std::vector<double> tv(2 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            tv[i] = opt->rtol_vec ? opt->rtol_vec[i] : opt->rtol;
+            tv[n + i] = opt->atol_vec ? opt->atol_vec[i] : opt->atol;
+        }
+        HIP_TRY(ctx, ctx->tolvec.reserve(sizeof(double) * 2 * n));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->tolvec.p, tv.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));   // tv is a stack-lifetime host buffer
+        a.rtol_dev = (const double *)ctx->tolvec.p;
+        a.atol_dev = (const double *)ctx->tolvec.p + n;
     }
     a.first_step = opt->first_step;
     a.max_step = opt->max_step;

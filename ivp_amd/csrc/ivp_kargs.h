@@ -30,6 +30,8 @@ struct IvpKArgs {
     // ---- options (uniform -> SGPRs) ----
     double rtol[IVP_MAX_N];
     double atol[IVP_MAX_N];
+    const double *rtol_dev;   // large-n problems with per-component tolerances: [n] in device memory, else NULL
+    const double *atol_dev;
     double first_step;
     double max_step;
     uint64_t nmax;            // Options.max_steps or UINT64_MAX

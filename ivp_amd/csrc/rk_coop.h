@@ -90,7 +90,7 @@ template <class R>
 struct NormOps<CoopRhs<R>, void> {
     enum { NT = R::N };
     // this lane's rtol / atol (Tolerance, mod.rs:104-214): select chain instead of a dynamically indexed kernarg array
-    static __device__ __forceinline__ double tol(const double *arr, int)
+    static __device__ __forceinline__ double pick(const double (&arr)[IVP_MAX_N])
     {
         const uint32_t c = threadIdx.x & 7u;
         double v = arr[0];
@@ -98,6 +98,8 @@ struct NormOps<CoopRhs<R>, void> {
         for (int q = 1; q < NT; ++q) v = (c == (uint32_t)q) ? arr[q] : v;
         return v;
     }
+    static __device__ __forceinline__ double rtol(const IvpKArgs &a, int) { return pick(a.rtol); }
+    static __device__ __forceinline__ double atol(const IvpKArgs &a, int) { return pick(a.atol); }
     static __device__ __forceinline__ double sum(const double (&term)[1]) { return coop_sum<NT>(term[0], threadIdx.x & ~7u); }
 };
 

@@ -326,7 +326,7 @@ struct RhsRationalEv {   // tests/test_ivp.py:345-353
 // thread-per-trajectory code below is unchanged by them.
 //   IdMap<N>      local component c -> global component gi(c) of NT; own(c) = this lane really holds it
 //   NormOps<R>    NT = number of components in the RMS norms, sum() = the reference's left-to-right sum,
-//                 tol(arr, c) = rtol / atol of local component c
+//                 rtol(a, c) / atol(a, c) = tolerances of local component c
 // ------------------------------------------------------------------------------------------------
 template <int N>
 struct IdMap {
@@ -339,7 +339,8 @@ struct OutMap { using type = IdMap<R::N>; };
 template <class R, class = void>
 struct NormOps {
     enum { NT = R::N };
-    static IVP_HD double tol(const double *arr, int i) { return arr[i]; }   // Tolerance index (mod.rs:194-204)
+    static IVP_HD double rtol(const IvpKArgs &a, int i) { return a.rtol[i]; }   // Tolerance index (mod.rs:194-204)
+    static IVP_HD double atol(const IvpKArgs &a, int i) { return a.atol[i]; }
     template <int N>
     static IVP_HD double sum(const double (&t)[N])
     {
@@ -789,7 +790,7 @@ IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg,
     double t_dnf[N], t_dny[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::tol(a.atol, i) + NormOps<R>::tol(a.rtol, i) * fabs(y[i]);
+        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fabs(y[i]);
         t_dnf[i] = (f0[i] / sk) * (f0[i] / sk);
         t_dny[i] = (y[i] / sk) * (y[i] / sk);
     }
@@ -806,7 +807,7 @@ IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg,
     double t_der2[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::tol(a.atol, i) + NormOps<R>::tol(a.rtol, i) * fabs(y[i]);
+        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fabs(y[i]);
         const double df = (f1[i] - f0[i]) / sk;
         t_der2[i] = df * df;
     }
@@ -1048,7 +1049,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     double t_err[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::tol(a.atol, i) + NormOps<R>::tol(a.rtol, i) * fmax(fabs(y[i]), fabs(y1[i]));
+        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fmax(fabs(y[i]), fabs(y1[i]));
         t_err[i] = (k4[i] / sk) * (k4[i] / sk);
     }
     double err = NormOps<R>::sum(t_err);
@@ -1265,7 +1266,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 { const double cBH1 = KC(BH1), cBH2 = KC(BH2), cBH3 = KC(BH3), cER1 = KC(ER1), cER6 = KC(ER6), cER7 = KC(ER7), cER8 = KC(ER8), cER9 = KC(ER9), cER10 = KC(ER10), cER11 = KC(ER11), cER12 = KC(ER12);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::tol(a.atol, i) + NormOps<R>::tol(a.rtol, i) * fmax(fabs(y[i]), fabs(k5[i]));
+        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fmax(fabs(y[i]), fabs(k5[i]));
         double erri = k4[i] - cBH1 * k1[i] - cBH2 * k9[i] - cBH3 * k3[i];
         double q = erri / sk;
         t_err2[i] = q * q;
@@ -1423,7 +1424,7 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     double t_err[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double tl = NormOps<R>::tol(a.atol, i) + NormOps<R>::tol(a.rtol, i) * fmax(fabs(yt[i]), fabs(y[i]));
+        const double tl = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fmax(fabs(yt[i]), fabs(y[i]));
         const double q = ye[i] / tl;
         t_err[i] = q * q;
     }

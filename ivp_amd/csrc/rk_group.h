@@ -18,7 +18,7 @@
 //              controller runs redundantly in all lanes and accept/reject is a wave-uniform branch;
 //   * OutMap:  local component c lives at global index lane + 64 c of every SoA array.
 // Scalar per-trajectory state (x, h, counters, ...) is held and written redundantly by all 64 lanes (same value,
-// same address).  Tolerances are scalar (the host rejects per-component vectors for these problems).
+// same address).  Per-component tolerance vectors live in device memory (IvpKArgs.rtol_dev / atol_dev).
 #pragma once
 
 namespace IVP_NS {
@@ -65,7 +65,17 @@ struct OutMap<GroupRhs<R>, void> {
 template <class R>
 struct NormOps<GroupRhs<R>, void> {
     enum { NT = R::N };
-    static __device__ __forceinline__ double tol(const double *arr, int) { return arr[0]; }   // scalar tolerances
+    // scalar tolerances in the kernel arguments, or per-component vectors [n] in device memory (Tolerance::Vector)
+    static __device__ __forceinline__ double rtol(const IvpKArgs &a, int c)
+    {
+        const int i = (int)threadIdx.x + IVP_WAVE * c;
+        return (a.rtol_dev && i < NT) ? a.rtol_dev[i] : a.rtol[0];
+    }
+    static __device__ __forceinline__ double atol(const IvpKArgs &a, int c)
+    {
+        const int i = (int)threadIdx.x + IVP_WAVE * c;
+        return (a.atol_dev && i < NT) ? a.atol_dev[i] : a.atol[0];
+    }
     template <int C>
     static __device__ __forceinline__ double sum(const double (&term)[C])
     {

@@ -15,7 +15,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("B", C.c_uint32),
         ("y0", VP), ("params", VP), ("t0", VP), ("t1", VP),
         ("t0_stride", C.c_uint32), ("t1_stride", C.c_uint32),
-        ("rtol", C.c_double * 8), ("atol", C.c_double * 8),
+        ("rtol", C.c_double * 8), ("atol", C.c_double * 8), ("rtol_dev", VP), ("atol_dev", VP),
         ("first_step", C.c_double), ("max_step", C.c_double),
         ("nmax", C.c_uint64),
         ("has_first_step", C.c_int32), ("has_max_step", C.c_int32),

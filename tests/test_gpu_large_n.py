@@ -92,8 +92,22 @@ def test_large_n_unsupported_requests_fail_loudly():
     with pytest.raises(ivp_amd.ConfigError) as e:
         ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="BDF"))
     assert e.value.code == -101
-    with pytest.raises(ivp_amd.ConfigError):
-        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOPRI5", rtol=[1e-6] * 100))
+    with pytest.raises(ivp_amd.ConfigError) as e:   # Tolerance::Vector of the wrong length (mod.rs:156-161)
+        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOPRI5", rtol=[1e-6] * 99))
+    assert e.value.code == -4
+
+
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853"])
+def test_large_n_vector_tolerances(method):
+    """Tolerance::Vector (mod.rs:104-214) with n = 256: per-component rtol / atol travel as device arrays."""
+    y0, p, t0, t1 = _heat_batch(48, seed=41)
+    rng = np.random.default_rng(42)
+    rt = 10.0 ** rng.uniform(-8, -4, 256)
+    at = 10.0 ** rng.uniform(-11, -7, 256)
+    for kw in (dict(rtol=rt, atol=at), dict(rtol=rt, atol=1e-9), dict(rtol=1e-6, atol=at)):
+        ref = oracle_batch("heat1d256", y0, p, t0, t1, method=method, **kw)
+        got = gpu_batch("heat1d256", y0, p, t0, t1, method=method, **kw)
+        assert_bitexact(got, ref, f"vector tol {method} ")
 
 
 @pytest.mark.parametrize("method,tol", [("RK23", (1e-4, 1e-7)), ("DOP853", (1e-9, 1e-11)), ("DOP853", (1e-4, 1e-6)), ("RK4", None)])
