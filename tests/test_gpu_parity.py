@@ -203,6 +203,47 @@ def test_c3_full_size_1m_vdp_dop853():
         assert np.array_equal(np.asarray(g[k])[..., idx].astype(r[k].dtype), r[k]), k
 
 
+def test_maximum_size_batch_16m_trajectories_linearity():
+    """16.7M one-component trajectories in one call (index arithmetic past 2^24, 262144 waves).  y' = -k y is linear in
+    y0 only up to the controller: scaling y0 AND atol by a power of two scales every intermediate exactly, so the
+    second half of the batch must be exactly 4x the first half; a sample is checked against the oracle."""
+    import torch
+    import ivp_amd
+    B = 1 << 24
+    h = B // 2
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda:0")
+    y0 = np.empty((1, B))
+    y0[0, :h] = rng.uniform(0.5, 2.0, h)
+    y0[0, h:] = y0[0, :h]
+    k = np.empty((1, B))
+    k[0, :h] = rng.uniform(0.1, 3.0, h)
+    k[0, h:] = k[0, :h]
+    t1 = np.empty(B)
+    t1[:h] = rng.uniform(0.5, 4.0, h)
+    t1[h:] = t1[:h]
+    f = ivp_amd.ExponentialDecay()
+    o = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=0.0)      # atol = 0: the error norm is scale-free
+    y0d = torch.as_tensor(y0, device=dev)
+    y0d[0, h:] *= 4.0
+    r = ivp_amd.solve_ivp_batch(f, 0.0, torch.as_tensor(t1, device=dev), y0d, torch.as_tensor(k, device=dev), o)
+    ye = r.y_end.cpu().numpy()
+    assert (r.status == 0).all().item()
+    # the last step is h = xend - x and the reference stores x + h (dopri5.rs:280-283,409): equal to xend up to one rounding
+    te = r.t_end.cpu().numpy()
+    assert np.abs(te - t1).max() <= 4.5e-16 * 4.0 and np.mean(te != t1) < 0.05
+    assert np.array_equal(te[h:], te[:h])
+    assert np.array_equal(ye[0, h:], 4.0 * ye[0, :h])
+    assert torch.equal(r.naccpt[h:], r.naccpt[:h]) and torch.equal(r.nfev[h:], r.nfev[:h])
+    np.testing.assert_allclose(ye[0, :h], y0[0, :h] * np.exp(-k[0, :h] * t1[:h]), rtol=2e-5)
+    idx = np.concatenate([rng.choice(h, 128, replace=False), [0, h - 1, h, B - 1]])
+    yy = y0[:, idx].copy()
+    yy[0, idx >= h] *= 4.0
+    ref = oracle_batch("decay", yy, k[:, idx], 0.0, t1[idx], method="DOPRI5", rtol=1e-6, atol=0.0)
+    assert np.array_equal(ye[:, idx], ref["y_end"]) and np.array_equal(r.naccpt.cpu().numpy()[idx].astype(np.uint64), ref["naccpt"])
+    assert np.array_equal(te[idx], ref["t_end"])
+
+
 def test_c5_full_size_10k_stiff_vdp_bdf():
     """BASELINE config C5: 10k stiff Van der Pol (mu ~ 1000), BDF order 1-5, per-trajectory LU in registers."""
     B = 10_000

@@ -1,6 +1,6 @@
 """ad hoc: C3 (DOP853) timing by kernel variant (not a test)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import ivp_amd
 from ivp_amd import workloads as W

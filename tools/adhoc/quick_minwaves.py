@@ -1,6 +1,6 @@
 """ad hoc: compare lean-kernel occupancy hints (not a test).  usage: python tests/quick_minwaves.py <lib.so>"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ivp_amd import _lib
 if len(sys.argv) > 1:
