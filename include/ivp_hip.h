@@ -264,6 +264,24 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
                            void *hip_stream);
 
 /*
+ * The same solve as a resumable operation, so that one host thread can keep several contexts (= several batches,
+ * each on its own stream) in flight: a solve is a sequence of rounds (a few kernel launches, then the count of
+ * still-running trajectories travels to the host), and only the hand-over between rounds needs the host.
+ *   ivp_batch_submit_device  validates, enqueues the init kernel and the first round, returns without waiting;
+ *                            arguments as for ivp_batch_solve_device; one solve in flight per context
+ *   ivp_batch_poll           non-blocking: if the current round has finished, starts the next one or completes the
+ *                            solve; *done = 1 once the results are final (also when nothing is in flight)
+ *   ivp_batch_wait           blocks until the solve is complete
+ * ivp_batch_solve_device() is submit + wait.  A failed poll / wait abandons the solve.
+ */
+int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0,
+                            const double *params, const double *t0, size_t t0_len, const double *t1,
+                            size_t t1_len, const ivp_options_t *opt, ivp_batch_result_t *out,
+                            void *hip_stream);
+int ivp_batch_poll(ivp_ctx_t *ctx, int *done);
+int ivp_batch_wait(ivp_ctx_t *ctx);
+
+/*
  * User-defined right-hand side: the device-side `impl IVP for T { fn ode(..) }` (src/ivp.rs:29).
  * `ode_source` is HIP device code defining
  *     __device__ void ode(double x, const double* y, double* dydx, const double* p);

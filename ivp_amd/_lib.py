@@ -60,7 +60,7 @@ class RunStatsT(C.Structure):
 EXPORTS = (
     "ivp_abi_version", "ivp_device_count", "ivp_ctx_create", "ivp_ctx_destroy", "ivp_last_error_string",
     "ivp_ctx_get_stats", "ivp_options_default", "ivp_options_method_defaults", "ivp_rhs_dims", "ivp_rhs_n_events", "ivp_batch_solve",
-    "ivp_batch_solve_device", "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_free",
+    "ivp_batch_solve_device", "ivp_batch_submit_device", "ivp_batch_poll", "ivp_batch_wait", "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_free",
 )
 
 ERRORS = {
@@ -121,6 +121,12 @@ def load():
     L.ivp_batch_solve.argtypes = solve_args
     L.ivp_batch_solve_device.restype = C.c_int
     L.ivp_batch_solve_device.argtypes = solve_args + [C.c_void_p]
+    L.ivp_batch_submit_device.restype = C.c_int
+    L.ivp_batch_submit_device.argtypes = solve_args + [C.c_void_p]
+    L.ivp_batch_poll.restype = C.c_int
+    L.ivp_batch_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.ivp_batch_wait.restype = C.c_int
+    L.ivp_batch_wait.argtypes = [C.c_void_p]
     L.ivp_rhs_compile.restype = C.c_int
     L.ivp_rhs_compile.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.ivp_rhs_compile_events.restype = C.c_int

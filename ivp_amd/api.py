@@ -646,14 +646,52 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+class PendingBatch:
+    """A solve in flight (``solve_ivp_batch(..., wait=False)``): ``done()`` advances it without blocking,
+    ``result()`` blocks until the results are final.  One per Context at a time."""
+
+    def __init__(self, ctx: "Context", res: "BatchSolution", profile: bool, keep: list):
+        self._ctx, self._res, self._profile, self._keep = ctx, res, profile, keep
+        self._done = False
+
+    def _finish(self):
+        self._done = True
+        self._keep = None
+        if self._profile:
+            self._res.stats = self._ctx.stats()
+
+    def done(self) -> bool:
+        if self._done:
+            return True
+        flag = C.c_int(0)
+        rc = self._ctx.lib.ivp_batch_poll(self._ctx.handle, C.byref(flag))
+        if rc != 0:
+            self._done = True
+            raise ConfigError(rc, self._ctx.last_error())
+        if flag.value:
+            self._finish()
+        return self._done
+
+    def result(self) -> "BatchSolution":
+        if not self._done:
+            rc = self._ctx.lib.ivp_batch_wait(self._ctx.handle)
+            if rc != 0:
+                self._done = True
+                raise ConfigError(rc, self._ctx.last_error())
+            self._finish()
+        return self._res
+
+
 def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ctx: Context = None,
-                    out: BatchSolution = None) -> BatchSolution:
+                    out: BatchSolution = None, wait: bool = True):
     """B independent ``solve_ivp(f, t0[b], t1[b], y0[:, b], options)`` calls on the GPU.
 
     ``y0``: ``[n, B]`` float64, numpy (host path: staged through the library) or a CUDA torch tensor
     (zero-copy device path on torch's current stream).  ``params``: ``[n_params, B]`` per-trajectory
     values of the problem struct's fields; defaults to ``f.params()`` broadcast over the batch.
     ``t0`` / ``t1``: scalars or ``[B]`` arrays of the same kind as ``y0``.
+    ``wait=False`` (device arrays only): enqueue the solve and return a ``PendingBatch``; several contexts can then be
+    driven from one host thread (``ivp_batch_submit_device`` / ``ivp_batch_poll``).
     """
     options = options or Options()
     on_device = _is_torch(y0)
@@ -738,6 +776,16 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
     for name, _ in _lib.BatchResultT._fields_:
         setattr(r, name, ptr(getattr(res, name)))
     prob = _problem_c(f)
+    if not wait:
+        if not on_device:
+            raise ValueError("wait=False needs device arrays (the host-pointer entry point copies results back at the end)")
+        import torch
+        stream = C.c_void_p(torch.cuda.current_stream(y0.device).cuda_stream)
+        rc = ctx.lib.ivp_batch_submit_device(ctx.handle, C.byref(prob), B, ptr(y0), ptr(params), ptr(t0a), t0_len,
+                                             ptr(t1a), t1_len, C.byref(copt), C.byref(r), stream)
+        if rc != 0:
+            raise ConfigError(rc, ctx.last_error())
+        return PendingBatch(ctx, res, bool(options.profile), keep + [y0, params, t0a, t1a, copt, r])
     if on_device:
         import torch
         stream = C.c_void_p(torch.cuda.current_stream(y0.device).cuda_stream)

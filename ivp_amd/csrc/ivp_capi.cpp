@@ -92,6 +92,24 @@ struct ivp_ctx {
     uint32_t *pinned = nullptr;  // host-pinned: active count + misc
     std::vector<hipEvent_t> events;
     ivp_run_stats_t stats{};
+    // ---- the solve in flight (ivp_batch_submit_device .. ivp_batch_poll / ivp_batch_wait) ----
+    struct Pending {
+        bool active = false;
+        IvpKArgs a;
+        ivp_problem_t prob;
+        int method = 0, fp_mode = 0, variant = 0, profile = 0, n = 0;
+        bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false;
+        uint32_t chunk = 64, lanes = 0;
+        size_t B = 0;
+        uint64_t c = 0;             // chunk launches so far
+        bool err_checked = false;
+        hipStream_t stream = nullptr;
+        hipEvent_t round_done = nullptr;
+        size_t ev_used = 0;
+        hipEvent_t ev_t0 = nullptr, ev_init1 = nullptr;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> step_ev;
+        std::vector<char> step_is_coop;
+    } pend;
 };
 
 namespace {
@@ -179,6 +197,144 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     return IVP_OK;
 }
 
+hipEvent_t pend_event(ivp_ctx *ctx)
+{
+    ivp_ctx::Pending &P = ctx->pend;
+    if (P.ev_used == ctx->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->events.push_back(e);
+    }
+    return ctx->events[P.ev_used++];
+}
+
+hipError_t pend_launch(ivp_ctx *ctx, int what, const IvpKArgs &ka, uint32_t lanes, bool use_hoist, bool use_coop)
+{
+    const ivp_ctx::Pending &P = ctx->pend;
+    hipStream_t s = P.stream;
+    const bool fast = P.fp_mode == IVP_FP_FAST;
+    if (P.jit) return ivp_jit_launch(P.prob.jit, (use_coop && what == IVP_LAUNCH_CHUNK) ? IVP_LAUNCH_COOP : what, P.method, P.fp_mode, P.full, ka, lanes, s);
+    if (P.group) return (fast ? ivp_launch_group_fast : ivp_launch_group_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
+    if (use_coop && what == IVP_LAUNCH_CHUNK) return (fast ? ivp_launch_coop_fast : ivp_launch_coop_strict)(P.method, P.prob.rhs_id, P.full, ka, lanes, s);
+    if (use_hoist) return (fast ? ivp_launch_fast_hoist : ivp_launch_strict_hoist)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
+    return (fast ? ivp_launch_fast : ivp_launch_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
+}
+
+// One round = the chunk launches between two host polls of the active count; the still-running ids are compacted on
+// the device from launch to launch.
+// Launch policy.  While the active set still over-subscribes the chip (more than one wave per SIMD:
+// 256 CUs x 4 SIMDs x 64 lanes = 65536 trajectories) short chunks + compaction keep wavefronts dense and
+// the SIMDs evenly loaded.  Once it fits one wave per SIMD, wall time is the sequential attempt latency of
+// the slowest trajectory: compaction cannot help any more and every extra launch only adds a gap, so the
+// remainder runs in long chunks with one launch per host poll.
+int enqueue_round(ivp_ctx *ctx)
+{
+    ivp_ctx::Pending &P = ctx->pend;
+    hipStream_t s = P.stream;
+    const uint32_t kOneWavePerSimd = 256u * 4u * 64u;
+    uint32_t *counts = (uint32_t *)ctx->counts.p;
+    const uint32_t lanes = P.lanes;
+    const bool profile = P.profile != 0;
+    const bool tail = P.adaptive && (size_t)lanes * (P.group ? IVP_WAVE : 1u) <= kOneWavePerSimd;
+    // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
+    // registers; auto = resident once at most two waves per SIMD are left to run
+    // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;
+    //  fast-mode FMA fusion differs between them, so there it is fixed by the batch size to keep every
+    //  trajectory's result independent of what else is in the batch at launch time)
+    const bool use_hoist = !P.has_settings &&   // run-time controller fields exist in the lean builds only
+                           (P.variant == 2 ||
+                            (P.variant == 0 && (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
+    // eight lanes per trajectory pay off once the cooperative waves still fit one per SIMD, and only for systems
+    // with enough components to share out (measured: 1.3-1.45x at n = 6, break-even at n = 3, a loss at n = 2)
+    const bool use_coop = P.coop_ok && (P.variant == 3 ||
+                                        (P.variant == 0 && P.fp_mode == IVP_FP_STRICT && P.adaptive && P.n >= 4 &&
+                                         (size_t)lanes * 8u <= kOneWavePerSimd));
+    const int launches_per_sync = tail ? 1 : 4;
+    const uint32_t this_chunk = tail ? 1024u : P.chunk;
+    for (int r = 0; r < launches_per_sync; ++r, ++P.c) {
+        const uint64_t c = P.c;
+        IvpKArgs ka = P.a;
+        ka.chunk = this_chunk;
+        if (c == 0) {
+            ka.perm_in = nullptr;
+            ka.count_in = nullptr;
+        } else {
+            ka.perm_in = (const uint32_t *)ctx->perm[(c - 1) & 1].p;
+            ka.count_in = counts + ((c - 1) & 3);
+        }
+        ka.perm_out = (uint32_t *)ctx->perm[c & 1].p;
+        ka.count_out = counts + (c & 3);
+        // slot (c+1)&3 is the next launch's count_out: it was zeroed by the initial memset (c = 0) or has to
+        // be reset now; nothing reads it during this launch.
+        if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
+        HIP_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, lanes, use_hoist, use_coop));
+        if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(use_coop ? 1 : 0); }
+        ctx->stats.launches += 1;
+        if (use_coop) ctx->stats.coop_launches += 1;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((P.c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!P.err_checked) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(P.round_done, s));
+    return IVP_OK;
+}
+
+// the round's active count has arrived: finish the solve or enqueue the next round
+int finish_round(ivp_ctx *ctx, int *done)
+{
+    ivp_ctx::Pending &P = ctx->pend;
+    if (!P.err_checked) {
+        P.err_checked = true;
+        if (ctx->pinned[1] & 0x1u) {  // IVP_ERRFLAG_INVALID_STEP: RK4::solve's Err(InvalidStepSize), rk4.rs:81-87
+            P.active = false;
+            return fail(ctx, IVP_ERR_INVALID_STEP_SIZE, "RK4: step size is zero or its sign does not match xend - x0 for at least one trajectory");
+        }
+    }
+    P.lanes = ctx->pinned[0];
+    if (P.lanes != 0) return enqueue_round(ctx);
+    P.active = false;
+    *done = 1;
+    if (P.profile) {
+        hipStream_t s = P.stream;
+        hipEvent_t ev_end = pend_event(ctx);
+        HIP_TRY(ctx, hipEventRecord(ev_end, s));
+        HIP_TRY(ctx, hipEventSynchronize(ev_end));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, P.ev_t0, P.ev_init1));
+        ctx->stats.init_kernel_ms = ms;
+        for (size_t q = 0; q < P.step_ev.size(); ++q) {
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, P.step_ev[q].first, P.step_ev[q].second));
+            ctx->stats.step_kernel_ms += ms;
+            if (P.step_is_coop[q]) ctx->stats.coop_kernel_ms += ms;
+        }
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, P.ev_t0, ev_end));
+        ctx->stats.total_ms = ms;
+        unsigned long long slots[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(slots, ctx->slot.p, sizeof slots, hipMemcpyDeviceToHost));
+        ctx->stats.lane_attempt_slots = slots[0];
+        ctx->stats.lane_launches = slots[1];
+        if (P.profile >= 2) {
+            const size_t B = P.B;
+            std::vector<uint64_t> tmp(B);
+            HIP_TRY(ctx, hipMemcpy(tmp.data(), P.a.naccpt, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+            uint64_t acc = 0, att = 0;
+            for (uint64_t v : tmp) acc += v;
+            ctx->stats.total_accepted = acc;
+            if (P.method == IVP_RK23) {  // RK23 counts only accepted steps in nstep (rk23.rs:238)
+                HIP_TRY(ctx, hipMemcpy(tmp.data(), P.a.nrejct, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+                att = acc;
+                for (uint64_t v : tmp) att += v;
+            } else {
+                HIP_TRY(ctx, hipMemcpy(tmp.data(), P.a.nstep, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+                for (uint64_t v : tmp) att += v;
+            }
+            ctx->stats.total_attempts = att;
+        }
+    }
+    return IVP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -222,6 +378,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->pend.round_done) (void)hipEventDestroy(c->pend.round_done);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
 }
@@ -279,11 +436,12 @@ int ivp_rhs_n_events(int32_t rhs_id)
     return kRhsEvents[rhs_id];
 }
 
-int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0, const double *params,
-                           const double *t0, size_t t0_len, const double *t1, size_t t1_len, const ivp_options_t *opt,
-                           ivp_batch_result_t *out, void *hip_stream)
+int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0, const double *params,
+                            const double *t0, size_t t0_len, const double *t1, size_t t1_len, const ivp_options_t *opt,
+                            ivp_batch_result_t *out, void *hip_stream)
 {
     if (!ctx) return IVP_ERR_BAD_ARGUMENT;
+    if (ctx->pend.active) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "a solve is already in flight on this context");
     ctx->err.clear();
     int n = 0, np = 0;
     int rc = validate(ctx, prob, B, opt, &n, &np);
@@ -448,148 +606,86 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 8, s));
     a.err_flag = (uint32_t *)ctx->counts.p + 4;
 
-    auto launch_lean = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast : ivp_launch_strict;
-    auto launch_hoist = (opt->fp_mode == IVP_FP_FAST) ? ivp_launch_fast_hoist : ivp_launch_strict_hoist;
-    bool use_hoist = false;
-    const bool jit = prob->rhs_id == IVP_RHS_JIT;
-    // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for built-in
-    // problems with n <= 8 and no events.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict
-    // mode the loop switches to it for the latency-bound tail; fast mode only on request (variant 3).
-    const bool coop_ok = !group && n_events == 0 && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
-    bool use_coop = false;
-    const int variant = (opt->variant == 3 && !coop_ok) ? 0 : opt->variant;
-    auto do_launch = [&](int what, const IvpKArgs &ka, uint32_t lanes) -> hipError_t {
-        if (jit) return ivp_jit_launch(prob->jit, (use_coop && what == IVP_LAUNCH_CHUNK) ? IVP_LAUNCH_COOP : what, opt->method, opt->fp_mode, full, ka, lanes, s);
-        if (group) return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_group_fast : ivp_launch_group_strict)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
-        if (use_coop && what == IVP_LAUNCH_CHUNK)
-            return (opt->fp_mode == IVP_FP_FAST ? ivp_launch_coop_fast : ivp_launch_coop_strict)(opt->method, prob->rhs_id, full, ka, lanes, s);
-        return (use_hoist ? launch_hoist : launch_lean)(what, opt->method, prob->rhs_id, full, ka, lanes, s);
-    };
-
-    size_t ev_used = 0;
-    auto ev = [&](void) -> hipEvent_t {
-        if (ev_used == ctx->events.size()) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            ctx->events.push_back(e);
-        }
-        return ctx->events[ev_used++];
-    };
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> step_ev;
-    std::vector<char> step_is_coop;
-    hipEvent_t ev_t0 = nullptr, ev_init1 = nullptr, ev_end = nullptr;
+    ivp_ctx::Pending &P = ctx->pend;
+    P.a = a;
+    P.prob = *prob;
+    P.method = opt->method;
+    P.fp_mode = opt->fp_mode;
+    P.profile = opt->profile;
+    P.n = n;
+    P.full = full;
+    P.group = group;
+    P.jit = prob->rhs_id == IVP_RHS_JIT;
+    P.has_settings = opt->has_settings != 0;
+    // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for problems with
+    // n <= 8 and no events.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict mode
+    // the loop switches to them for the latency-bound tail; fast mode only on request (variant 3).
+    P.coop_ok = !group && n_events == 0 && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
+    P.variant = (opt->variant == 3 && !P.coop_ok) ? 0 : opt->variant;
+    P.chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : 64u;
+    P.adaptive = opt->chunk_attempts == 0;
+    P.B = B;
+    P.lanes = (uint32_t)B;
+    P.c = 0;
+    P.err_checked = false;
+    P.stream = s;
+    P.ev_used = 0;
+    P.step_ev.clear();
+    P.step_is_coop.clear();
+    if (!P.round_done) HIP_TRY(ctx, hipEventCreateWithFlags(&P.round_done, hipEventDisableTiming));
 
     // ---- init: f0, hinit / first_step, initial SolOut call ----
-    a.chunk = 0;
-    a.perm_in = nullptr;
-    a.count_in = nullptr;
-    a.perm_out = nullptr;
-    a.count_out = nullptr;
-    if (profile) { ev_t0 = ev(); HIP_TRY(ctx, hipEventRecord(ev_t0, s)); }
-    HIP_TRY(ctx, do_launch(IVP_LAUNCH_INIT, a, (uint32_t)B));
-    if (profile) { ev_init1 = ev(); HIP_TRY(ctx, hipEventRecord(ev_init1, s)); }
+    IvpKArgs ka = P.a;
+    ka.chunk = 0;
+    ka.perm_in = nullptr;
+    ka.count_in = nullptr;
+    ka.perm_out = nullptr;
+    ka.count_out = nullptr;
+    if (profile) { P.ev_t0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(P.ev_t0, s)); }
+    HIP_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_INIT, ka, (uint32_t)B, false, false));
+    if (profile) { P.ev_init1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(P.ev_init1, s)); }
     ctx->stats.init_launches = 1;
+    P.active = true;
+    rc = enqueue_round(ctx);
+    if (rc != IVP_OK) P.active = false;
+    return rc;
+}
 
-    // ---- chunks of step attempts; the still-running ids are compacted on the device ----
-    // Launch policy.  While the active set still over-subscribes the chip (more than one wave per SIMD:
-    // 256 CUs x 4 SIMDs x 64 lanes = 65536 trajectories) short chunks + compaction keep wavefronts dense and
-    // the SIMDs evenly loaded.  Once it fits one wave per SIMD, wall time is the sequential attempt latency of
-    // the slowest trajectory: compaction cannot help any more and every extra launch only adds a gap, so the
-    // remainder runs in long chunks with one launch per host poll.
-    const uint32_t chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : 64u;
-    const uint32_t kOneWavePerSimd = 256u * 4u * 64u;
-    const bool adaptive = opt->chunk_attempts == 0;
-    uint32_t *counts = (uint32_t *)ctx->counts.p;
-    uint32_t lanes = (uint32_t)B;
-    uint64_t c = 0;  // chunk number
-    bool err_checked = false;
-    for (;;) {
-        const bool tail = adaptive && (size_t)lanes * (group ? IVP_WAVE : 1u) <= kOneWavePerSimd;
-        // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
-        // registers; auto = resident once at most two waves per SIMD are left to run
-        // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;
-        //  fast-mode FMA fusion differs between them, so there it is fixed by the batch size to keep every
-        //  trajectory's result independent of what else is in the batch at launch time)
-        use_hoist = !opt->has_settings &&   // run-time controller fields exist in the lean builds only
-                    (variant == 2 ||
-                     (variant == 0 && (opt->fp_mode == IVP_FP_FAST ? B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
-        // eight lanes per trajectory pay off once the cooperative waves still fit one per SIMD, and only for systems
-        // with enough components to share out (measured: 1.3-1.45x at n = 6, break-even at n = 3, a loss at n = 2)
-        use_coop = coop_ok && (variant == 3 ||
-                               (variant == 0 && opt->fp_mode == IVP_FP_STRICT && adaptive && n >= 4 &&
-                                (size_t)lanes * 8u <= kOneWavePerSimd));
-        const int launches_per_sync = tail ? 1 : 4;
-        const uint32_t this_chunk = tail ? 1024u : chunk;
-        for (int r = 0; r < launches_per_sync; ++r, ++c) {
-            IvpKArgs ka = a;
-            ka.chunk = this_chunk;
-            if (c == 0) {
-                ka.perm_in = nullptr;
-                ka.count_in = nullptr;
-            } else {
-                ka.perm_in = (const uint32_t *)ctx->perm[(c - 1) & 1].p;
-                ka.count_in = counts + ((c - 1) & 3);
-            }
-            ka.perm_out = (uint32_t *)ctx->perm[c & 1].p;
-            ka.count_out = counts + (c & 3);
-            // slot (c+1)&3 is the next launch's count_out: it was zeroed by the initial memset (c = 0) or has to
-            // be reset now; nothing reads it during this launch.
-            if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (profile) { e0 = ev(); HIP_TRY(ctx, hipEventRecord(e0, s)); }
-            HIP_TRY(ctx, do_launch(IVP_LAUNCH_CHUNK, ka, lanes));
-            if (profile) { e1 = ev(); HIP_TRY(ctx, hipEventRecord(e1, s)); step_ev.emplace_back(e0, e1); step_is_coop.push_back(use_coop ? 1 : 0); }
-            ctx->stats.launches += 1;
-            if (use_coop) ctx->stats.coop_launches += 1;
-        }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        if (!err_checked) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (!err_checked) {
-            err_checked = true;
-            if (ctx->pinned[1] & 0x1u)  // IVP_ERRFLAG_INVALID_STEP: RK4::solve's Err(InvalidStepSize), rk4.rs:81-87
-                return fail(ctx, IVP_ERR_INVALID_STEP_SIZE, "RK4: step size is zero or its sign does not match xend - x0 for at least one trajectory");
-        }
-        lanes = ctx->pinned[0];
-        if (lanes == 0) break;
-    }
+int ivp_batch_poll(ivp_ctx_t *ctx, int *done)
+{
+    if (!ctx || !done) return IVP_ERR_BAD_ARGUMENT;
+    *done = 0;
+    if (!ctx->pend.active) { *done = 1; return IVP_OK; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const hipError_t q = hipEventQuery(ctx->pend.round_done);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return IVP_OK; }
+    if (q != hipSuccess) { ctx->pend.active = false; return fail(ctx, IVP_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q)); }
+    const int rc = finish_round(ctx, done);
+    if (rc != IVP_OK) ctx->pend.active = false;
+    return rc;
+}
 
-    if (profile) {
-        ev_end = ev();
-        HIP_TRY(ctx, hipEventRecord(ev_end, s));
-        HIP_TRY(ctx, hipEventSynchronize(ev_end));
-        float ms = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_t0, ev_init1));
-        ctx->stats.init_kernel_ms = ms;
-        for (size_t q = 0; q < step_ev.size(); ++q) {
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, step_ev[q].first, step_ev[q].second));
-            ctx->stats.step_kernel_ms += ms;
-            if (step_is_coop[q]) ctx->stats.coop_kernel_ms += ms;
-        }
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_t0, ev_end));
-        ctx->stats.total_ms = ms;
-        unsigned long long slots[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpy(slots, ctx->slot.p, sizeof slots, hipMemcpyDeviceToHost));
-        ctx->stats.lane_attempt_slots = slots[0];
-        ctx->stats.lane_launches = slots[1];
-        if (opt->profile >= 2) {
-        std::vector<uint64_t> tmp(B);
-        HIP_TRY(ctx, hipMemcpy(tmp.data(), a.naccpt, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
-        uint64_t acc = 0, att = 0;
-        for (uint64_t v : tmp) acc += v;
-        ctx->stats.total_accepted = acc;
-        if (opt->method == IVP_RK23) {  // RK23 counts only accepted steps in nstep (rk23.rs:238)
-            HIP_TRY(ctx, hipMemcpy(tmp.data(), a.nrejct, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
-            att = acc;
-            for (uint64_t v : tmp) att += v;
-        } else {
-            HIP_TRY(ctx, hipMemcpy(tmp.data(), a.nstep, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
-            for (uint64_t v : tmp) att += v;
-        }
-        ctx->stats.total_attempts = att;
-        }
+int ivp_batch_wait(ivp_ctx_t *ctx)
+{
+    if (!ctx) return IVP_ERR_BAD_ARGUMENT;
+    while (ctx->pend.active) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const hipError_t e = hipEventSynchronize(ctx->pend.round_done);
+        if (e != hipSuccess) { ctx->pend.active = false; return fail(ctx, IVP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e)); }
+        int done = 0;
+        const int rc = finish_round(ctx, &done);
+        if (rc != IVP_OK) { ctx->pend.active = false; return rc; }
     }
     return IVP_OK;
+}
+
+int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0, const double *params,
+                           const double *t0, size_t t0_len, const double *t1, size_t t1_len, const ivp_options_t *opt,
+                           ivp_batch_result_t *out, void *hip_stream)
+{
+    const int rc = ivp_batch_submit_device(ctx, prob, B, y0, params, t0, t0_len, t1, t1_len, opt, out, hip_stream);
+    if (rc != IVP_OK) return rc;
+    return ivp_batch_wait(ctx);
 }
 
 int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0, const double *params,

@@ -6,8 +6,11 @@ Independent batches do not have to wait for each other: with one ``Context`` + H
 in-flight batch, the tail of batch i overlaps the throughput-bound head of batch i+1.  Measured on MI355X (C2,
 strict FP): 3.7 ms per solve with one batch in flight, 1.4 ms with four.
 
-The library call blocks its host thread while it polls the active-set counter, hence one Python thread per stream
-(ctypes releases the GIL for the duration of the call).
+A solve is a sequence of rounds (a few kernel launches, then the count of still-running trajectories travels to the
+host); only the hand-over between rounds needs the host.  ``BatchPipeline.map`` therefore drives all streams from ONE
+host thread through the resumable entry points (``ivp_batch_submit_device`` / ``ivp_batch_poll``): whenever a
+context's round has finished it enqueues the next one, and a finished solve hands its context to the next batch.
+``map_threads`` is the older one-blocking-thread-per-stream form (ctypes releases the GIL during the call).
 """
 from __future__ import annotations
 
@@ -27,9 +30,40 @@ class BatchPipeline:
         self.streams = [torch.cuda.Stream(self.device) for _ in range(streams)]
 
     def map(self, f: api.IVP, batches: Sequence[dict], options: api.Options,
-            on_done: Optional[Callable[[int, api.BatchSolution], None]] = None) -> List[api.BatchSolution]:
-        """``batches``: dicts with keys t0, t1, y0, params (CUDA tensors / scalars as for solve_ivp_batch).
-        Batch k is integrated by worker k % streams; results come back in input order."""
+            on_done: Optional[Callable[[int, api.BatchSolution], None]] = None,
+            out_per_context: Optional[Sequence[api.BatchSolution]] = None) -> List[api.BatchSolution]:
+        """``batches``: dicts with keys t0, t1, y0, params (CUDA tensors / scalars as for solve_ivp_batch).  Results
+        come back in input order.  ``out_per_context``: one reusable BatchSolution per stream (results of different
+        batches then alias: consume them in ``on_done``)."""
+        import torch
+        results: List[Optional[api.BatchSolution]] = [None] * len(batches)
+        nxt = 0
+        inflight: List[Optional[tuple]] = [None] * len(self.ctxs)   # (batch index, PendingBatch) per context
+        remaining = len(batches)
+        while remaining:
+            for w in range(len(self.ctxs)):
+                if inflight[w] is not None:
+                    k, pend = inflight[w]
+                    if pend.done():
+                        results[k] = pend.result()
+                        inflight[w] = None
+                        remaining -= 1
+                        if on_done is not None:
+                            on_done(k, results[k])
+                if inflight[w] is None and nxt < len(batches):
+                    b = batches[nxt]
+                    with torch.cuda.stream(self.streams[w]):
+                        out = out_per_context[w] if out_per_context is not None else b.get("out")
+                        inflight[w] = (nxt, api.solve_ivp_batch(f, b["t0"], b["t1"], b["y0"], b.get("params"), options,
+                                                                self.ctxs[w], out, wait=False))
+                    nxt += 1
+            # nothing ready: poll again (a round lasts 0.3-2 ms; each poll is one hipEventQuery per context)
+        torch.cuda.synchronize(self.device)
+        return results  # type: ignore[return-value]
+
+    def map_threads(self, f: api.IVP, batches: Sequence[dict], options: api.Options,
+                    on_done: Optional[Callable[[int, api.BatchSolution], None]] = None) -> List[api.BatchSolution]:
+        """One blocking host thread per stream; batch k is integrated by worker k % streams."""
         import torch
         results: List[Optional[api.BatchSolution]] = [None] * len(batches)
         errors: List[BaseException] = []

@@ -340,7 +340,35 @@ def test_pipelined_batches_give_the_same_bits_as_sequential_solves():
         b = dict(t0=t0, t1=t1, y0=torch.as_tensor(y0, device=dev), params=torch.as_tensor(p, device=dev))
         batches.append(b)
         refs.append(ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, b["y0"], b["params"], opts))
-    res = BatchPipeline(3).map(ivp_amd.CR3BP(), batches, opts)
-    for r, ref in zip(res, refs):
-        for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct"):
-            assert torch.equal(getattr(r, k), getattr(ref, k)), k
+    pipe = BatchPipeline(3)
+    for res in (pipe.map(ivp_amd.CR3BP(), batches, opts), pipe.map_threads(ivp_amd.CR3BP(), batches, opts)):
+        for r, ref in zip(res, refs):
+            for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct"):
+                assert torch.equal(getattr(r, k), getattr(ref, k)), k
+
+
+def test_submit_poll_wait_entry_points():
+    """ivp_batch_submit_device / ivp_batch_poll / ivp_batch_wait: a solve as a resumable operation."""
+    import torch
+    import ivp_amd
+    dev = torch.device("cuda:0")
+    y0, p, t0, t1 = W.cr3bp_batch(5000, seed=5)
+    y0d, pd = torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev)
+    opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, profile=1)
+    ref = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0d, pd, opts)
+    ctx = ivp_amd.Context(0)
+    pend = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0d, pd, opts, ctx, wait=False)
+    with pytest.raises(ivp_amd.ConfigError):          # one solve in flight per context
+        ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0d, pd, opts, ctx, wait=False)
+    polls = 0
+    while not pend.done():
+        polls += 1
+    r = pend.result()
+    assert torch.equal(r.y_end, ref.y_end) and torch.equal(r.naccpt, ref.naccpt) and r.stats["launches"] == ref.stats["launches"]
+    # wait() without polling, then the context is free again; t_eval (host array consumed at submit time) works too
+    pend = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0d, pd, ivp_amd.Options(method="DOP853", rtol=1e-8, atol=1e-10, t_eval=[1.0, 5.0, 17.0]), ctx, wait=False)
+    r2 = pend.result()
+    ref2 = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0d, pd, ivp_amd.Options(method="DOP853", rtol=1e-8, atol=1e-10, t_eval=[1.0, 5.0, 17.0]))
+    assert torch.equal(r2.y_eval, ref2.y_eval) and torch.equal(r2.y_end, ref2.y_end)
+    with pytest.raises(ValueError):
+        ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0, p, opts, ctx, wait=False)      # host arrays cannot be asynchronous
