@@ -1,0 +1,54 @@
+/* A plain-C client of include/ivp_hip.h: proves the header is valid C and that the boundary needs nothing but
+ * pointers and sizes.  Without a GPU it exercises the entry points that need none and exits 0 (printing "no device");
+ * with one it integrates y' = -k y for four trajectories through the host-pointer entry point. */
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ivp_hip.h"
+
+int main(void)
+{
+    if (ivp_abi_version() != IVP_HIP_ABI_VERSION) { printf("abi mismatch\n"); return 2; }
+    ivp_options_t opt;
+    ivp_options_default(&opt);
+    if (opt.method != IVP_DOPRI5 || opt.rtol != 1e-3 || opt.atol != 1e-6 || opt.max_steps != 0) return 3;
+    if (ivp_options_method_defaults(&opt, IVP_DOP853) != IVP_OK || opt.scale_max != 6.0) return 4;
+    ivp_options_default(&opt);
+    int32_t n = 0, np = 0;
+    if (ivp_rhs_dims(IVP_RHS_CR3BP, &n, &np) != IVP_OK || n != 6 || np != 1) return 5;
+    if (ivp_rhs_dims(IVP_RHS_HEAT1D_256, &n, &np) != IVP_OK || n != 256 || np != 1) return 6;
+    if (ivp_rhs_n_events(IVP_RHS_RATIONAL_EV) != 3) return 7;
+    ivp_ctx_t *ctx = NULL;
+    if (ivp_device_count() == 0) {
+        if (ivp_ctx_create(&ctx, 0) != IVP_ERR_NO_DEVICE || ctx != NULL) return 8;   /* no CPU fallback */
+        printf("no device: abi v%d ok\n", ivp_abi_version());
+        return 0;
+    }
+    if (ivp_ctx_create(&ctx, 0) != IVP_OK) return 9;
+    enum { B = 4 };
+    const double y0[B] = {1.0, 2.0, 3.0, 4.0}, k[B] = {0.5, 1.0, 1.5, 2.0}, t0 = 0.0, t1[B] = {1.0, 2.0, 3.0, 0.0};
+    double y_end[B], t_end[B];
+    int32_t status[B];
+    uint64_t naccpt[B];
+    ivp_problem_t prob = {IVP_RHS_DECAY, 1, 1, NULL};
+    ivp_batch_result_t out;
+    memset(&out, 0, sizeof out);
+    out.y_end = y_end; out.t_end = t_end; out.status = status; out.naccpt = naccpt;
+    opt.rtol = 1e-9; opt.atol = 1e-12;
+    int rc = ivp_batch_solve(ctx, &prob, B, y0, k, &t0, 1, t1, B, &opt, &out);
+    if (rc != IVP_OK) { printf("solve failed: %d %s\n", rc, ivp_last_error_string(ctx)); return 10; }
+    for (int b = 0; b < B; ++b) {
+        const double want = y0[b] * exp(-k[b] * t1[b]);
+        if (status[b] != IVP_STATUS_SUCCESS || fabs(y_end[b] - want) > 1e-8 || t_end[b] != t1[b]) {
+            printf("trajectory %d: status %d y %.17g want %.17g\n", b, status[b], y_end[b], want);
+            return 11;
+        }
+    }
+    opt.method = IVP_RADAU;
+    if (ivp_batch_solve(ctx, &prob, B, y0, k, &t0, 1, t1, B, &opt, &out) != IVP_ERR_UNSUPPORTED_METHOD) return 12;
+    ivp_ctx_destroy(ctx);
+    printf("device solve ok: %llu %llu %llu %llu accepted steps\n", (unsigned long long)naccpt[0], (unsigned long long)naccpt[1],
+           (unsigned long long)naccpt[2], (unsigned long long)naccpt[3]);
+    return 0;
+}
