@@ -246,9 +246,10 @@ int enqueue_round(ivp_ctx *ctx)
                             (P.variant == 0 && (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
     // eight lanes per trajectory pay off once the cooperative waves still fit one per SIMD, and only for systems
     // with enough components to share out (measured: 1.3-1.45x at n = 6, break-even at n = 3, a loss at n = 2)
+    // (fast mode: decided by the batch size alone, like the lean / resident choice above)
     const bool use_coop = P.coop_ok && (P.variant == 3 ||
-                                        (P.variant == 0 && P.fp_mode == IVP_FP_STRICT && P.adaptive && P.n >= 4 &&
-                                         (size_t)lanes * 8u <= kOneWavePerSimd));
+                                        (P.variant == 0 && P.adaptive && P.n >= 4 &&
+                                         (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) * 8u <= kOneWavePerSimd));
     const int launches_per_sync = tail ? 1 : 4;
     const uint32_t this_chunk = tail ? 1024u : P.chunk;
     for (int r = 0; r < launches_per_sync; ++r, ++P.c) {
