@@ -162,3 +162,9 @@ def test_method_defaults_are_the_reference_struct_defaults():
         assert (o.method, o.uround, o.safety_factor, o.scale_min, o.scale_max, o.beta, o.stiff_test) == (m, *w)
     for m in (3, 4, 5, 17):
         assert lib.ivp_options_method_defaults(C.byref(o), m) == -100
+
+
+def test_graft_entry_build_passes():
+    """The driver's "does it build" check must keep working when the ABI version moves."""
+    import __graft_entry__ as g
+    g.build()
