@@ -123,31 +123,28 @@ def main():
     n_state = prob.n
     ctx = ivp_amd.Context(local_rank)
     # Two result buffers: with N > 1 the RCCL all-gather of step i (C4: gather of sol.y over xGMI) is asynchronous and
-    # overlaps the integration of step i+1, which writes into the other buffer.
+    # overlaps the integration of step i+1, which writes into the other buffer (ivp_amd.distributed.OverlappedGather).
+    from ivp_amd.distributed import OverlappedGather
     outs = [None, None]
-    works = [None, None]
-    gathered = [torch.empty((world, n_state, B), dtype=torch.float64, device=dev) for _ in range(2)] if dist is not None else None
+    og = OverlappedGather((n_state, B), torch.float64, dev) if dist is not None else None
     step_no = [0]
     out = None
 
     def step():
         nonlocal out
-        k = step_no[0] & 1
-        step_no[0] += 1
-        if works[k] is not None:      # the gather that last read outs[k].y_end must have completed
-            works[k].wait()
-            works[k] = None
+        if og is not None:
+            k = og.slot()
+        else:
+            k = step_no[0] & 1
+            step_no[0] += 1
         outs[k] = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, ctx, outs[k])
         out = outs[k]
-        if dist is not None:
-            works[k] = dist.all_gather_into_tensor(gathered[k], out.y_end, async_op=True)
+        if og is not None:
+            og.launch(k, out.y_end)
 
     def sync_all():
-        for k in range(2):
-            if works[k] is not None:
-                works[k].wait()
-                works[k] = None
-        if dist is not None:
+        if og is not None:
+            og.drain()
             dist.barrier()
         torch.cuda.synchronize()
 

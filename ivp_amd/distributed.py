@@ -120,3 +120,43 @@ def _unpermute(out: dict, perm: np.ndarray, n: int, B: int) -> dict:
         r[..., perm] = v
         res[k] = r
     return res
+
+
+class OverlappedGather:
+    """Double-buffered, asynchronous all-gather of one result array per step, used by bench.py --gpus N.
+
+    Step i's gather (RCCL over xGMI under backend "nccl": the C4 "gather of sol.y") runs while step i+1 integrates
+    into the other buffer; ``slot()`` returns which of the two buffers the next step may write (after making sure the
+    gather that last read it has completed), ``launch(k, tensor)`` starts the gather of that step's result, and
+    ``drain()`` waits for everything outstanding.  Backend-agnostic (gloo on CPU tensors in the tests)."""
+
+    def __init__(self, shape, dtype, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.gathered = [torch.empty((self.world,) + tuple(shape), dtype=dtype, device=device) for _ in range(2)]
+        self.works = [None, None]
+        self.steps = 0
+
+    def slot(self) -> int:
+        k = self.steps & 1
+        self.steps += 1
+        if self.works[k] is not None:   # the gather that last read this slot's result must have completed
+            self.works[k].wait()
+            self.works[k] = None
+        return k
+
+    def launch(self, k: int, tensor) -> None:
+        dist = self._dist
+        if dist.get_backend(self.group) == "gloo":   # gloo has no all_gather_into_tensor
+            self.works[k] = dist.all_gather(list(self.gathered[k].unbind(0)), tensor, group=self.group, async_op=True)
+        else:
+            self.works[k] = dist.all_gather_into_tensor(self.gathered[k], tensor, group=self.group, async_op=True)
+
+    def drain(self) -> None:
+        for k in range(2):
+            if self.works[k] is not None:
+                self.works[k].wait()
+                self.works[k] = None

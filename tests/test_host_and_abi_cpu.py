@@ -168,3 +168,47 @@ def test_graft_entry_build_passes():
     """The driver's "does it build" check must keep working when the ABI version moves."""
     import __graft_entry__ as g
     g.build()
+
+
+_WORKER_OG = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from ivp_amd.distributed import OverlappedGather
+
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+og = OverlappedGather((3, 5), torch.float64, torch.device("cpu"))
+bufs = [torch.empty((3, 5), dtype=torch.float64) for _ in range(2)]
+seen = []
+for step in range(7):                         # the loop bench.py runs: slot -> produce -> launch
+    k = og.slot()                             # waits for the gather that last read bufs[k]
+    if step >= 2:                             # that gather carried step - 2: every rank's result of that step
+        want = torch.stack([torch.full((3, 5), 100.0 * r + (step - 2), dtype=torch.float64) for r in range(2)])
+        assert torch.equal(og.gathered[k], want), (step, og.gathered[k])
+        seen.append(step - 2)
+    bufs[k].fill_(100.0 * rank + step)        # "integrate" step into the free buffer
+    og.launch(k, bufs[k])
+og.drain()
+for step in (5, 6):
+    want = torch.stack([torch.full((3, 5), 100.0 * r + step, dtype=torch.float64) for r in range(2)])
+    assert torch.equal(og.gathered[step & 1], want)
+assert seen == [0, 1, 2, 3, 4]
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_overlapped_gather_double_buffering_under_gloo_world_size_2(tmp_path):
+    """bench.py --gpus N: step i's all-gather overlaps step i+1; a buffer is only rewritten after its gather is done
+    and every gather delivers every rank's result of that step."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker_og.py"
+    script.write_text(_WORKER_OG.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
