@@ -290,6 +290,8 @@ int ivp_batch_wait(ivp_ctx_t *ctx);
  * For 8 < n <= 512 (wave-per-trajectory kernels, see IVP_RHS_LINEAR_DECAY_100) the snippet defines the
  * component form instead -- y points at the whole state, the function returns dy_i/dx:
  *     __device__ double ode_comp(int i, double x, const double* y, const double* p);
+ * Compiled code objects are cached on disk when the environment variable IVP_JIT_CACHE_DIR names an existing
+ * directory (key: hash of the generated source, options and hiprtc version).
  * ivp_rhs_compile_events: the snippet additionally defines the trait's event functions
  *     __device__ void events(double x, const double* y, double* g, const double* p);   // g[0..n_events)
  */

@@ -12,6 +12,8 @@
 #include <hip/hiprtc.h>
 
 #include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <map>
 #include <mutex>
 #include <string>
@@ -98,9 +100,53 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
     return s;
 }
 
+// Optional on-disk cache of compiled code objects (hiprtc takes 1-2 s per module): set IVP_JIT_CACHE_DIR to an
+// existing directory.  Key = FNV-1a of the complete generated source, the compile options and the hiprtc version.
+std::string cache_path(const std::string &src, const std::string &opts)
+{
+    const char *dir = std::getenv("IVP_JIT_CACHE_DIR");
+    if (!dir || !*dir) return std::string();
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const std::string &t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } };
+    mix(src); mix(opts); mix(std::to_string(major) + "." + std::to_string(minor));
+    char name[64];
+    std::snprintf(name, sizeof name, "/ivp_jit_%016llx.hsaco", (unsigned long long)h);
+    return std::string(dir) + name;
+}
+
+int load_module(JitRhs &r, const std::vector<char> &code, JitModule *out)
+{
+    if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) { r.log = "hipModuleLoadData failed"; return IVP_ERR_HIP; }
+    if (hipModuleGetFunction(&out->init, out->mod, "ivp_jit_init") != hipSuccess ||
+        hipModuleGetFunction(&out->chunk, out->mod, "ivp_jit_chunk") != hipSuccess) {
+        r.log = "kernel lookup failed";
+        return IVP_ERR_HIP;
+    }
+    if (hipModuleGetFunction(&out->coop, out->mod, "ivp_jit_coop") != hipSuccess) {   // not every module has one
+        out->coop = nullptr;
+        (void)hipGetLastError();   // the failed lookup must not surface as the "last error" of a later launch
+    }
+    return IVP_OK;
+}
+
 int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitModule *out)
 {
     const std::string src = build_source(r, method, full, ctl);
+    const std::string opt_key = r.arch + (fp_mode == IVP_FP_FAST ? "|fast" : "|strict");
+    const std::string cpath = cache_path(src, opt_key);
+    if (!cpath.empty()) {
+        std::ifstream in(cpath, std::ios::binary);
+        if (in) {
+            std::vector<char> code((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+            if (!code.empty()) {
+                if (!out) return IVP_OK;
+                if (load_module(r, code, out) == IVP_OK) return IVP_OK;
+                (void)hipGetLastError();   // unreadable cache entry: fall through and compile
+            }
+        }
+    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "ivp_user_rhs.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         r.log = "hiprtcCreateProgram failed";
@@ -125,18 +171,17 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitM
     std::vector<char> code(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    if (!cpath.empty()) {   // best effort: write to a temporary name, then rename (atomic on POSIX)
+        const std::string tmp = cpath + ".tmp" + std::to_string((unsigned long long)(uintptr_t)&r);
+        std::ofstream o(tmp, std::ios::binary);
+        if (o) {
+            o.write(code.data(), (std::streamsize)code.size());
+            o.close();
+            if (!o || std::rename(tmp.c_str(), cpath.c_str()) != 0) std::remove(tmp.c_str());
+        }
+    }
     if (!out) return IVP_OK;  // compile-only check
-    if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) { r.log = "hipModuleLoadData failed"; return IVP_ERR_HIP; }
-    if (hipModuleGetFunction(&out->init, out->mod, "ivp_jit_init") != hipSuccess ||
-        hipModuleGetFunction(&out->chunk, out->mod, "ivp_jit_chunk") != hipSuccess) {
-        r.log = "kernel lookup failed";
-        return IVP_ERR_HIP;
-    }
-    if (hipModuleGetFunction(&out->coop, out->mod, "ivp_jit_coop") != hipSuccess) {   // not every module has one
-        out->coop = nullptr;
-        (void)hipGetLastError();   // the failed lookup must not surface as the "last error" of a later launch
-    }
-    return IVP_OK;
+    return load_module(r, code, out);
 }
 
 }  // namespace

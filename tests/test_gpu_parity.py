@@ -372,3 +372,32 @@ def test_submit_poll_wait_entry_points():
     assert torch.equal(r2.y_eval, ref2.y_eval) and torch.equal(r2.y_end, ref2.y_end)
     with pytest.raises(ValueError):
         ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, y0, p, opts, ctx, wait=False)      # host arrays cannot be asynchronous
+
+
+def test_jit_disk_cache_round_trip(tmp_path, monkeypatch):
+    """IVP_JIT_CACHE_DIR: compiled code objects are stored and reused; a cached module gives the same bits."""
+    import time
+    import ivp_amd
+    monkeypatch.setenv("IVP_JIT_CACHE_DIR", str(tmp_path))
+    src = CR3BP_SRC + "\n// cache-test variant\n"
+    y0, p, t0, t1 = W.cr3bp_batch(300)
+    opts = ivp_amd.Options(method="DOP853", rtol=1e-8, atol=1e-10)
+    t = time.perf_counter()
+    f1 = ivp_amd.DeviceIVP(src, n=6, params=(W.ARENSTORF_MU,))
+    r1 = ivp_amd.solve_ivp_batch(f1, t0, t1, y0, p, opts)
+    cold = time.perf_counter() - t
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) >= 2 and all(f.endswith(".hsaco") for f in files), files     # the syntax-check module + DOP853
+    t = time.perf_counter()
+    f2 = ivp_amd.DeviceIVP(src, n=6, params=(W.ARENSTORF_MU,))
+    r2 = ivp_amd.solve_ivp_batch(f2, t0, t1, y0, p, opts)
+    warm = time.perf_counter() - t
+    assert np.array_equal(r1.y_end, r2.y_end) and np.array_equal(r1.nfev, r2.nfev)
+    assert sorted(os.listdir(tmp_path)) == files and warm < 0.5 * cold, (cold, warm)
+    # a corrupted entry is ignored (recompiled), not fatal
+    for f in files:
+        with open(os.path.join(tmp_path, f), "wb") as fh:
+            fh.write(b"not a code object")
+    f3 = ivp_amd.DeviceIVP(src, n=6, params=(W.ARENSTORF_MU,))
+    r3 = ivp_amd.solve_ivp_batch(f3, t0, t1, y0, p, opts)
+    assert np.array_equal(r1.y_end, r3.y_end)
