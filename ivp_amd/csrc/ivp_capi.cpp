@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -244,13 +245,16 @@ int enqueue_round(ivp_ctx *ctx)
     const bool use_hoist = !P.has_settings &&   // run-time controller fields exist in the lean builds only
                            (P.variant == 2 ||
                             (P.variant == 0 && (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
-    // eight lanes per trajectory pay off once the cooperative waves still fit one per SIMD, and only for systems
+    // eight lanes per trajectory pay off once the cooperative waves fit two per SIMD, and only for systems
     // with enough components to share out (measured: 1.3-1.45x at n = 6, break-even at n = 3, a loss at n = 2)
     // (fast mode: decided by the batch size alone, like the lean / resident choice above)
+    const size_t coop_cap = 2 * (size_t)kOneWavePerSimd;   // a cooperative wave keeps its SIMD < 60 % busy: two share one well
     const bool use_coop = P.coop_ok && (P.variant == 3 ||
                                         (P.variant == 0 && P.adaptive && P.n >= 4 &&
-                                         (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) * 8u <= kOneWavePerSimd));
-    const int launches_per_sync = tail ? 1 : 4;
+                                         (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) * 8u <= coop_cap));
+    // three short launches per poll: measured on C2 (attempts per trajectory peak at 160-200) the hand-over to the
+    // cooperative kernel then happens after 192 instead of 256 attempts (3.33 -> 3.25 ms); more polls cost ~40 us each
+    const int launches_per_sync = tail ? 1 : 3;
     const uint32_t this_chunk = tail ? 1024u : P.chunk;
     for (int r = 0; r < launches_per_sync; ++r, ++P.c) {
         const uint64_t c = P.c;
