@@ -94,7 +94,8 @@ typedef enum {
     IVP_RHS_BUILTIN_COUNT = 15,
     /* Large state dimensions (8 < n <= 512): one 64-lane wavefront integrates one trajectory, the state is
      * distributed over its lanes and the error norm is a wavefront reduction.  RK23 / DOPRI5 / DOP853 / RK4 with
-     * every output mode (t_eval, step log, dense output) and scalar or vector tolerances; no events, no BDF. */
+     * every output mode (t_eval, step log, dense output), events (hiprtc problems) and scalar or vector tolerances;
+     * no BDF. */
     IVP_RHS_LINEAR_DECAY_100 = 100, /* y' = -y                            n=100 benches/benchmark.py:40-42,139-148 */
     IVP_RHS_HEAT1D_256 = 101,       /* y_i' = k (y_{i-1} - 2 y_i + y_{i+1}), p={k}  n=256 (method of lines)  */
     IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */
@@ -290,6 +291,7 @@ int ivp_batch_wait(ivp_ctx_t *ctx);
  * For 8 < n <= 512 (wave-per-trajectory kernels, see IVP_RHS_LINEAR_DECAY_100) the snippet defines the
  * component form instead -- y points at the whole state, the function returns dy_i/dx:
  *     __device__ double ode_comp(int i, double x, const double* y, const double* p);
+ * (its events(), if any, keep the whole-state signature below).
  * Compiled code objects are cached on disk when the environment variable IVP_JIT_CACHE_DIR names an existing
  * directory (key: hash of the generated source, options and hiprtc version).
  * ivp_rhs_compile_events: the snippet additionally defines the trait's event functions

@@ -282,7 +282,7 @@ class DeviceIVP(IVP):
     ``params`` are the values of the struct's fields (``p[...]`` inside ``ode``).
     For ``8 < n <= 512`` the snippet defines the component form
     ``__device__ double ode_comp(int i, double x, const double* y, const double* p)`` instead (one wavefront per
-    trajectory; RK23 / DOPRI5 / DOP853 / RK4, scalar tolerances, no events).
+    trajectory; RK23 / DOPRI5 / DOP853 / RK4; ``events`` keeps the whole-state signature).
     """
     rhs_id = 1000
 

@@ -779,7 +779,6 @@ int ivp_rhs_compile_events(ivp_ctx_t *ctx, const char *ode_source, int32_t n, in
     if (!ctx || !ode_source || !handle) return IVP_ERR_BAD_ARGUMENT;
     if (n < 1 || n > IVP_MAX_GROUP_N || n_params < 0 || n_params > IVP_MAX_P || n_events < 0 || n_events > 4)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
-    if (n > IVP_MAX_N && n_events > 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "large-n problems cannot carry events");
     std::string log;
     int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, n_events, handle, &log);
     if (rc != IVP_OK) ctx->err = log;

@@ -65,8 +65,11 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
     if (group) {
         s += join(k_src_rk_group_h);
         std::snprintf(buf, sizeof buf,
-                      "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d };\n"
+                      "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d, NE = IVP_USER_NE };\n"
                       "  static __device__ __forceinline__ double ode_comp(int i, double x, const double* y, const double* p) { return ::ode_comp(i, x, y, p); }\n"
+                      "#if IVP_USER_NE > 0\n"
+                      "  static __device__ __forceinline__ void events(double x, const double* y, double* g, const double* p) { ::events(x, y, g, p); }\n"
+                      "#endif\n"
                       "}; }\n"
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<%d, ivp_jit::RhsUser, %s>(a); }\n"
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<%d, ivp_jit::RhsUser, %s>(a); }\n",

@@ -628,6 +628,7 @@ IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double
                       const double *y, const double *yold, const double *cont, double h, double ixold)
 {
     constexpr int N = R::N, P = R::P, NE = R::NE > 0 ? R::NE : 1;
+    using MAP = typename OutMap<R>::type;
     const size_t B = a.B;
     double g_curr[NE];
     R::events(x, y, g_curr, L.p);
@@ -734,14 +735,15 @@ IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double
             if (k < a.max_events) {
                 a.t_events[((size_t)i * a.max_events + k) * B + j] = det_t[u];
 #pragma unroll
-                for (int c = 0; c < N; ++c) a.y_events[(((size_t)i * a.max_events + k) * N + c) * B + j] = det_y[u][c];
+                for (int c = 0; c < N; ++c)
+                    if (MAP::own(c)) a.y_events[(((size_t)i * a.max_events + k) * MAP::NT + MAP::gi(c)) * B + j] = det_y[u][c];
             }
             a.n_ev[(size_t)i * B + j] = k + 1;   // event_hits
             const uint32_t term = a.ev_terminal[i];
             if (term != 0 && k + 1 >= term) {
                 // the terminal event point is appended to Solution.t / Solution.y (solout.rs:316-319)
-                if (a.n_eval >= 0) { so_emit_eval<M, N, P>(a, j, L, -1, det_y[u]); if (a.t_term) a.t_term[j] = det_t[u]; }
-                else if (a.t_log != nullptr) so_push_log<M, N, P>(a, j, L, det_t[u], det_y[u]);
+                if (a.n_eval >= 0) { so_emit_eval<M, N, P, MAP>(a, j, L, -1, det_y[u]); if (a.t_term) a.t_term[j] = det_t[u]; }
+                else if (a.t_log != nullptr) so_push_log<M, N, P, MAP>(a, j, L, det_t[u], det_y[u]);
                 interrupt = true;
             }
         }

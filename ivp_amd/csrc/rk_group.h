@@ -19,6 +19,7 @@
 //   * OutMap:  local component c lives at global index lane + 64 c of every SoA array.
 // Scalar per-trajectory state (x, h, counters, ...) is held and written redundantly by all 64 lanes (same value,
 // same address).  Per-component tolerance vectors live in device memory (IvpKArgs.rtol_dev / atol_dev).
+// Event functions (hiprtc user code) are evaluated on the LDS copy of the state by every lane.
 #pragma once
 
 namespace IVP_NS {
@@ -38,9 +39,28 @@ struct RhsHeat1D256 {        // method-of-lines heat equation, Dirichlet ends: y
     }
 };
 
+// number of event functions of a component-form functor (hiprtc user code defines NE; the built-ins have none)
+template <class R, class = void>
+struct GroupNE { enum { v = 0 }; };
+template <class R>
+struct GroupNE<R, decltype((void)R::NE)> { enum { v = R::NE }; };
+
 template <class R>
 struct GroupRhs {
-    enum { NT = R::N, N = (R::N + IVP_WAVE - 1) / IVP_WAVE, P = R::P, NE = 0 };
+    enum { NT = R::N, N = (R::N + IVP_WAVE - 1) / IVP_WAVE, P = R::P, NE = GroupNE<R>::v };
+    // event functions see the whole state: publish it through LDS, every lane evaluates them (same values in all lanes,
+    // so the root finder of so_events stays wave-uniform)
+    static __device__ __forceinline__ void events(double x, const double *ys, double *g, const double *p)
+    {
+        if constexpr (NE > 0) {
+            __shared__ double estage[NT];
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < N; ++c) { const int i = (int)threadIdx.x + IVP_WAVE * c; if (i < NT) estage[i] = ys[c]; }
+            __syncthreads();
+            R::events(x, estage, g, p);
+        }
+    }
     static __device__ __forceinline__ void ode(double t, const double *ys, double *k, const double *p)
     {
         __shared__ double stage[NT];

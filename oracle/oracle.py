@@ -222,7 +222,7 @@ class OracleSolution:
 
 
 def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Sequence[float] = (),
-              detpow: bool = False, **options) -> OracleSolution:
+              detpow: bool = False, events=None, n_events: int = 0, **options) -> OracleSolution:
     """One reference-style ``solve_ivp`` call.  ``fun`` is a built-in RHS name (see ``RHS``) or a
     Python callable ``f(x, y, p) -> dydx`` (slow; small cases only)."""
     L = lib(detpow)
@@ -245,7 +245,17 @@ def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Seque
         keep = _ODE_FN(_tramp)
         fptr = C.cast(keep, C.c_void_p).value
     oh = _OptHolder(**options)
-    if isinstance(fun, str):
+    keep_ev = None
+    if events is not None:   # Python callable g = events(x, y, p) -> n_events values (trait IVP::events, src/ivp.rs:31-40)
+        def _ev_tramp(x, yp, gp, pp):
+            yy = np.ctypeslib.as_array(yp, shape=(n,))
+            pv = np.ctypeslib.as_array(pp, shape=(pa.size,))
+            g = np.asarray(events(x, yy, pv), dtype=np.float64).ravel()
+            for i in range(n_events):
+                gp[i] = g[i]
+        keep_ev = _ODE_FN(_ev_tramp)
+        oh.c.events, oh.c.n_events = C.cast(keep_ev, C.c_void_p).value, int(n_events)
+    elif isinstance(fun, str):
         ne = C.c_int()
         evp = L.orc_builtin_events(RHS[fun], C.byref(ne))
         if evp:

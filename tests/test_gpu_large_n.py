@@ -191,3 +191,48 @@ def test_large_n_single_solve_ivp_and_jit_component_form():
         assert int(s.status) == 0 and (s.naccpt, s.nrejct, s.nfev) == (o.naccpt, o.nrejct, o.nfev)
         # numpy's roll-based RHS adds in the same order as the snippet: bit-exact samples
         assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
+
+
+@pytest.mark.parametrize("method", ["DOPRI5", "DOP853", "RK23"])
+def test_large_n_events_match_oracle(method):
+    """Event detection (solout.rs:158-331) on the wave-per-trajectory path: the user's event functions see the whole
+    state (LDS copy); detected times / states, direction filter and a terminal count agree with the oracle bit for bit."""
+    import ivp_amd
+    from oracle import oracle as O
+    src = r'''
+    __device__ double ode_comp(int i, double t, const double* y, const double* p)
+    {   // 20 masses on a ring: y[0..20) positions, y[20..40) velocities
+        if (i < 20) return y[20 + i];
+        const int k = i - 20, l = (k + 19) % 20, r = (k + 1) % 20;
+        return p[0] * (y[l] - 2.0 * y[k] + y[r]);
+    }
+    __device__ void events(double t, const double* y, double* g, const double* p)
+    {
+        g[0] = y[0];                 // mass 0 passes the origin
+        g[1] = y[5] - y[15];         // two masses at the same displacement
+    }'''
+
+    def ring(t, y, p):
+        d = np.empty(40)
+        d[:20] = y[20:]
+        q = y[:20]
+        d[20:] = p[0] * (np.roll(q, 1) - 2.0 * q + np.roll(q, -1))
+        return d
+
+    ev = lambda t, y, p: [y[0], y[5] - y[15]]
+    rng = np.random.default_rng(6)
+    y0 = rng.standard_normal(40)
+    tol = dict(RK23=(1e-5, 1e-8), DOPRI5=(1e-7, 1e-9), DOP853=(1e-9, 1e-11))[method]
+    for cfgs, okw in (([ivp_amd.EventConfig(), ivp_amd.EventConfig()], dict(event_direction=[0, 0], event_terminal=[0, 0])),
+                      ([ivp_amd.EventConfig().positive(), ivp_amd.EventConfig(ivp_amd.Direction.Negative, 2)],
+                       dict(event_direction=[1, -1], event_terminal=[0, 2]))):
+        f = ivp_amd.DeviceIVP(src, n=40, params=(3.0,), events=cfgs)
+        s = ivp_amd.solve_ivp(f, 0.0, 6.0, y0, ivp_amd.Options(method=method, rtol=tol[0], atol=tol[1]))
+        o = O.solve_ivp(ring, 0.0, 6.0, list(y0), params=[3.0], method=method, rtol=tol[0], atol=tol[1], detpow=True,
+                        events=ev, n_events=2, **okw)
+        assert int(s.status) == o.status and (s.naccpt, s.nrejct, s.nfev) == (o.naccpt, o.nrejct, o.nfev)
+        assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
+        for i in range(2):
+            assert np.array_equal(s.t_events[i], o.t_events[i]), (i, s.t_events[i], o.t_events[i])
+            assert np.array_equal(s.y_events[i], o.y_events[i])
+        assert sum(len(t) for t in s.t_events) >= 3
