@@ -623,9 +623,9 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.jit = prob->rhs_id == IVP_RHS_JIT;
     P.has_settings = opt->has_settings != 0;
     // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for problems with
-    // n <= 8 and no events.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict mode
+    // n <= 8.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict mode
     // the loop switches to them for the latency-bound tail; fast mode only on request (variant 3).
-    P.coop_ok = !group && n_events == 0 && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
+    P.coop_ok = !group && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
     P.variant = (opt->variant == 3 && !P.coop_ok) ? 0 : opt->variant;
     P.chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : 64u;
     P.adaptive = opt->chunk_attempts == 0;

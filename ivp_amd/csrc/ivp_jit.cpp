@@ -93,7 +93,7 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
                   r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false",
                   (ctl && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? "true" : "false");
     s += buf;
-    if (r.ne == 0 && (method == IVP_DOPRI5 || method == IVP_DOP853)) {   // eight lanes per trajectory for the tail of a batch
+    if ((r.ne == 0 || full) && (method == IVP_DOPRI5 || method == IVP_DOP853)) {   // eight lanes per trajectory for the tail of a batch
         s += join(k_src_rk_coop_h);
         std::snprintf(buf, sizeof buf,
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_coop(const IvpKArgs a)\n"

@@ -70,12 +70,22 @@ __device__ __forceinline__ double coop_ode(double t, double ystage, uint32_t bas
 
 template <class R>
 struct CoopRhs {
-    enum { NT = R::N, N = 1, P = R::P, NE = 0 };
+    enum { NT = R::N, N = 1, P = R::P, NE = R::NE };
     static_assert(R::N <= 8, "eight lanes per trajectory");
     static __device__ __forceinline__ void ode(double t, const double *ys, double *k, const double *p)
     {
         const uint32_t lane = threadIdx.x;
         k[0] = coop_ode<R>(t, ys[0], lane & ~7u, lane & 7u, p);
+    }
+    // event functions see the whole state: gathered by shuffles, evaluated by every lane of the group (same values in
+    // all of them, so the root finder of so_events stays group-uniform)
+    static __device__ __forceinline__ void events(double x, const double *ys, double *g, const double *p)
+    {
+        if constexpr (NE > 0) {
+            double yf[R::N];
+            coop_gather<R::N>(ys[0], threadIdx.x & ~7u, yf);
+            R::events(x, yf, g, p);
+        }
     }
 };
 template <class R>

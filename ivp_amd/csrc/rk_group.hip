@@ -62,8 +62,11 @@ template <class R>
 hipError_t launch_coop(int method, bool full, const IvpKArgs &a, uint32_t n, hipStream_t s)
 {
     using namespace IVP_NS;
-    if constexpr (R::NE > 0) {
-        return hipErrorInvalidValue;   // event problems always run FULL kernels with events: not cooperative
+    if constexpr (R::NE > 0) {   // a problem with event functions always runs its FULL kernels
+        if (!full) return hipErrorInvalidValue;
+        if (method == M_DOPRI5) return launch_coop_one<M_DOPRI5, R, true>(a, n, s);
+        if (method == M_DOP853) return launch_coop_one<M_DOP853, R, true>(a, n, s);
+        return hipErrorInvalidValue;
     } else {
         if (method == M_DOPRI5) return full ? launch_coop_one<M_DOPRI5, R, true>(a, n, s) : launch_coop_one<M_DOPRI5, R, false>(a, n, s);
         if (method == M_DOP853) return full ? launch_coop_one<M_DOP853, R, true>(a, n, s) : launch_coop_one<M_DOP853, R, false>(a, n, s);

@@ -77,3 +77,19 @@ def test_coop_handles_ragged_groups_and_all_rhs():
             ref = oracle_batch(rhs, y0, p, 0.0, t1, **o)
             got = gpu_batch(rhs, y0, p, 0.0, t1, variant=3, **o)
             assert_bitexact(got, ref, f"{rhs} B={B}: ")
+
+
+from tests.cases import EVENT_CASES, check_events_against_oracle  # noqa: E402
+
+COOP_EVENT_CASES = [c for c in EVENT_CASES if c[0].endswith("DOPRI5") or c[0].endswith("DOP853")]
+
+
+@pytest.mark.parametrize("case", COOP_EVENT_CASES, ids=[c[0] for c in COOP_EVENT_CASES])
+def test_coop_event_detection_matches_oracle(case):
+    """Event problems through the cooperative kernels (variant 3): the event functions are evaluated on the gathered
+    state by every lane of a group; detections, terminal handling and outputs are the oracle's."""
+    exact = not case[1].startswith("rational")
+    check_events_against_oracle(lambda rhs, y0, p, t0, t1, **kw: gpu_batch(rhs, y0, p, t0, t1, chunk=5, variant=3, **kw), case, exact=exact)
+    stats_probe = gpu_batch(case[1], np.asarray(case[4], float).reshape(-1, 1), None if not len(case[5]) else np.asarray(case[5], float).reshape(-1, 1),
+                            case[2], case[3], variant=3, profile=1, max_log=64, **{k: v for k, v in case[6].items() if k != "t_eval"})
+    assert stats_probe["stats"]["coop_launches"] == stats_probe["stats"]["launches"] > 0
