@@ -401,3 +401,15 @@ def test_jit_disk_cache_round_trip(tmp_path, monkeypatch):
     f3 = ivp_amd.DeviceIVP(src, n=6, params=(W.ARENSTORF_MU,))
     r3 = ivp_amd.solve_ivp_batch(f3, t0, t1, y0, p, opts)
     assert np.array_equal(r1.y_end, r3.y_end)
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_configurations_bitexact_on_the_gpu(block):
+    """tests/test_differential_random_cpu.py's generator against the product: random method / problem / options /
+    output-mode combinations through the C ABI, default kernel choice and the cooperative kernels."""
+    from tests.test_differential_random_cpu import compare, random_case
+
+    for seed in range(3000 + 20 * block, 3000 + 20 * (block + 1)):
+        compare(lambda rhs, y0, p, t0, t1, **kw: gpu_batch(rhs, y0, p, t0, t1, **kw), seed)
+        if random_case(seed)[5]["method"] in ("DOPRI5", "DOP853"):
+            compare(lambda rhs, y0, p, t0, t1, **kw: gpu_batch(rhs, y0, p, t0, t1, variant=3, **kw), seed)
