@@ -54,7 +54,7 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
     sh_p = None if params is None else np.ascontiguousarray(np.asarray(params, dtype=np.float64)[:, idx])
 
     backend = dist.get_backend(group) if dist.is_initialized() else None
-    use_cuda = backend == "nccl" or (device is not None and str(device).startswith("cuda"))
+    use_cuda = backend == "nccl"   # the packed gather buffer follows the backend (RCCL: device memory; gloo: host memory)
     if solve_fn is None:
         dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         r = api.solve_ivp_batch(f, torch.as_tensor(sh_t0, device=dev) if sh_t0.size > 1 else float(sh_t0[0]),
