@@ -236,7 +236,7 @@ int enqueue_round(ivp_ctx *ctx)
     uint32_t *counts = (uint32_t *)ctx->counts.p;
     const uint32_t lanes = P.lanes;
     const bool profile = P.profile != 0;
-    const bool tail = P.adaptive && (size_t)lanes * (P.group ? IVP_WAVE : 1u) <= kOneWavePerSimd;
+    const bool tail = P.adaptive && (size_t)lanes * (P.group ? (P.jit ? (uint32_t)ivp_group_width(P.n) : (uint32_t)IVP_WAVE) : 1u) <= kOneWavePerSimd;
     // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
     // registers; auto = resident once at most two waves per SIMD are left to run
     // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;

@@ -63,6 +63,8 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
     s += join(k_src_rk_core_h);
     char buf[4096];
     if (group) {
+        s += join(k_src_bdf_core_h);
+        s += join(k_src_rk_global_h);   // compact_append
         s += join(k_src_rk_group_h);
         std::snprintf(buf, sizeof buf,
                       "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d, NE = IVP_USER_NE };\n"
@@ -71,9 +73,9 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
                       "  static __device__ __forceinline__ void events(double x, const double* y, double* g, const double* p) { ::events(x, y, g, p); }\n"
                       "#endif\n"
                       "}; }\n"
-                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<%d, ivp_jit::RhsUser, %s>(a); }\n"
-                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<%d, ivp_jit::RhsUser, %s>(a); }\n",
-                      r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false");
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<%d, ivp_jit::RhsUser, %s, %d>(a); }\n"
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<%d, ivp_jit::RhsUser, %s, %d>(a); }\n",
+                      r.n, r.np, method, full ? "true" : "false", ivp_group_width(r.n), method, full ? "true" : "false", ivp_group_width(r.n));
         s += buf;
         return s;
     }
@@ -254,7 +256,11 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool 
         }
         m = it->second;
     }
-    unsigned grid = r->n > IVP_MAX_N ? lanes : (lanes + IVP_WAVE - 1) / IVP_WAVE;   // large n: one wave per trajectory
+    unsigned grid = (lanes + IVP_WAVE - 1) / IVP_WAVE;
+    if (r->n > IVP_MAX_N) {   // large n: a group of G lanes per trajectory, 64 / G trajectories per wave
+        const unsigned per_wave = IVP_WAVE / (unsigned)ivp_group_width(r->n);
+        grid = (lanes + per_wave - 1) / per_wave;
+    }
     hipFunction_t fn = what == IVP_LAUNCH_INIT ? m.init : m.chunk;
     if (what == IVP_LAUNCH_COOP) {
         if (!m.coop) return hipErrorInvalidValue;

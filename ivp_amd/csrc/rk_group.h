@@ -20,6 +20,11 @@
 // Scalar per-trajectory state (x, h, counters, ...) is held and written redundantly by all 64 lanes (same value,
 // same address).  Per-component tolerance vectors live in device memory (IvpKArgs.rtol_dev / atol_dev).
 // Event functions (hiprtc user code) are evaluated on the LDS copy of the state by every lane.
+//
+// Group width.  G = 64 (one wavefront per trajectory) for the built-in problems; hiprtc modules of smaller systems use
+// G = 16 (n <= 16) or G = 32 (n <= 32), i.e. 4 or 2 trajectories per wavefront, each with its own LDS region.  The
+// groups of a wavefront then diverge like the lanes of the thread-per-trajectory kernels do (predication); a barrier
+// inside a divergent branch is harmless here because the workgroup is a single wavefront.
 #pragma once
 
 namespace IVP_NS {
@@ -45,107 +50,125 @@ struct GroupNE { enum { v = 0 }; };
 template <class R>
 struct GroupNE<R, decltype((void)R::NE)> { enum { v = R::NE }; };
 
-template <class R>
+template <class R, int G = IVP_WAVE>
 struct GroupRhs {
-    enum { NT = R::N, N = (R::N + IVP_WAVE - 1) / IVP_WAVE, P = R::P, NE = GroupNE<R>::v };
-    // event functions see the whole state: publish it through LDS, every lane evaluates them (same values in all lanes,
-    // so the root finder of so_events stays wave-uniform)
+    enum { NT = R::N, N = (R::N + G - 1) / G, P = R::P, NE = GroupNE<R>::v, GW = G, NGROUP = IVP_WAVE / G };
+    static_assert(G == 16 || G == 32 || G == 64, "group width");
+    static __device__ __forceinline__ int gl() { return (int)threadIdx.x & (G - 1); }   // lane within the group
+    static __device__ __forceinline__ int gb() { return ((int)threadIdx.x / G) * NT; }   // this group's LDS region
+    static __device__ __forceinline__ void ode(double t, const double *ys, double *k, const double *p)
+    {
+        __shared__ double stage[NGROUP * NT];
+        double *st = stage + gb();
+        __syncthreads();   // earlier readers of `stage` are done
+#pragma unroll
+        for (int c = 0; c < N; ++c) { const int i = gl() + G * c; if (i < NT) st[i] = ys[c]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < N; ++c) { const int i = gl() + G * c; k[c] = i < NT ? R::ode_comp(i, t, st, p) : 0.0; }
+    }
+    // event functions see the whole state: publish it through LDS, every lane evaluates them (same values in all lanes
+    // of the group, so the root finder of so_events stays group-uniform)
     static __device__ __forceinline__ void events(double x, const double *ys, double *g, const double *p)
     {
         if constexpr (NE > 0) {
-            __shared__ double estage[NT];
+            __shared__ double estage[NGROUP * NT];
+            double *st = estage + gb();
             __syncthreads();
 #pragma unroll
-            for (int c = 0; c < N; ++c) { const int i = (int)threadIdx.x + IVP_WAVE * c; if (i < NT) estage[i] = ys[c]; }
+            for (int c = 0; c < N; ++c) { const int i = gl() + G * c; if (i < NT) st[i] = ys[c]; }
             __syncthreads();
-            R::events(x, estage, g, p);
+            R::events(x, st, g, p);
         }
-    }
-    static __device__ __forceinline__ void ode(double t, const double *ys, double *k, const double *p)
-    {
-        __shared__ double stage[NT];
-        __syncthreads();   // earlier readers of `stage` are done
-#pragma unroll
-        for (int c = 0; c < N; ++c) { const int i = (int)threadIdx.x + IVP_WAVE * c; if (i < NT) stage[i] = ys[c]; }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < N; ++c) { const int i = (int)threadIdx.x + IVP_WAVE * c; k[c] = i < NT ? R::ode_comp(i, t, stage, p) : 0.0; }
     }
 };
 
-template <class R>
-struct OutMap<GroupRhs<R>, void> {
+template <class R, int G>
+struct OutMap<GroupRhs<R, G>, void> {
     struct type {
         enum { NT = R::N };
-        static __device__ __forceinline__ int gi(int c) { return (int)threadIdx.x + IVP_WAVE * c; }
+        static __device__ __forceinline__ int gi(int c) { return GroupRhs<R, G>::gl() + G * c; }
         static __device__ __forceinline__ bool own(int c) { return gi(c) < NT; }
     };
 };
 
-template <class R>
-struct NormOps<GroupRhs<R>, void> {
+template <class R, int G>
+struct NormOps<GroupRhs<R, G>, void> {
     enum { NT = R::N };
     // scalar tolerances in the kernel arguments, or per-component vectors [n] in device memory (Tolerance::Vector)
     static __device__ __forceinline__ double rtol(const IvpKArgs &a, int c)
     {
-        const int i = (int)threadIdx.x + IVP_WAVE * c;
+        const int i = GroupRhs<R, G>::gl() + G * c;
         return (a.rtol_dev && i < NT) ? a.rtol_dev[i] : a.rtol[0];
     }
     static __device__ __forceinline__ double atol(const IvpKArgs &a, int c)
     {
-        const int i = (int)threadIdx.x + IVP_WAVE * c;
+        const int i = GroupRhs<R, G>::gl() + G * c;
         return (a.atol_dev && i < NT) ? a.atol_dev[i] : a.atol[0];
     }
     template <int C>
     static __device__ __forceinline__ double sum(const double (&term)[C])
     {
-        const int lane = (int)threadIdx.x;
+        const int gl = GroupRhs<R, G>::gl();
 #if IVP_FAST
         double part = 0.0;
 #pragma unroll
-        for (int c = 0; c < C; ++c) if (lane + IVP_WAVE * c < NT) part += term[c];
+        for (int c = 0; c < C; ++c) if (gl + G * c < NT) part += term[c];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        for (int o = G / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);   // stays inside the group: o < G
         return part;
 #else
-        __shared__ double red[NT];
+        __shared__ double red[GroupRhs<R, G>::NGROUP * NT];
+        double *rd = red + GroupRhs<R, G>::gb();
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < C; ++c) { const int i = lane + IVP_WAVE * c; if (i < NT) red[i] = term[c]; }
+        for (int c = 0; c < C; ++c) { const int i = gl + G * c; if (i < NT) rd[i] = term[c]; }
         __syncthreads();
         double s = 0.0;
 #pragma unroll 8
-        for (int i = 0; i < NT; ++i) s += red[i];
+        for (int i = 0; i < NT; ++i) s += rd[i];
         return s;
 #endif
     }
 };
 
-// init: one wave per trajectory
-template <int M, class R, bool FULL>
+// init: one group of G lanes per trajectory, 64 / G trajectories per wavefront
+template <int M, class R, bool FULL, int G = IVP_WAVE>
 __device__ __forceinline__ void group_init_body(const IvpKArgs &a)
 {
-    const uint32_t j = blockIdx.x;
+    const uint32_t j = blockIdx.x * (IVP_WAVE / G) + threadIdx.x / G;
     if (j >= a.B) return;
-    (void)init_body<M, GroupRhs<R>, FULL>(a, j);
+    (void)init_body<M, GroupRhs<R, G>, FULL>(a, j);
 }
 
-// up to a.chunk step attempts for the trajectory of this wave; controller fields from IvpKArgs (CTL = true)
-template <int M, class R, bool FULL>
+// up to a.chunk step attempts for the trajectories of this wave; controller fields from IvpKArgs (CTL = true)
+template <int M, class R, bool FULL, int G = IVP_WAVE>
 __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
 {
+    constexpr uint32_t NG = IVP_WAVE / G;
     const uint32_t count = a.perm_in ? *a.count_in : a.B;
-    if (blockIdx.x >= count) return;
-    const uint32_t j = a.perm_in ? a.perm_in[blockIdx.x] : blockIdx.x;
-    if (a.status[j] != IVP_RUNNING) return;
+    if (blockIdx.x * NG >= count) return;   // whole wave beyond the active set (stale grid bound)
+    const uint32_t i = blockIdx.x * NG + threadIdx.x / G;
+    uint32_t j = 0;
+    bool active = false;
+    if (i < count) {
+        j = a.perm_in ? a.perm_in[i] : i;
+        active = a.status[j] == IVP_RUNNING;
+    }
     int32_t st = 0;
+    uint32_t it = 0;
     constexpr bool kCtl = M == M_RK23 || M == M_DOPRI5 || M == M_DOP853;
-    const uint32_t it = chunk_body<M, GroupRhs<R>, FULL, kCtl>(a, j, st);
-    if (threadIdx.x == 0) {
-        if (st == IVP_RUNNING) a.perm_out[atomicAdd(a.count_out, 1u)] = j;   // still running: next launch's list
-        if (a.slot_counter) {
-            atomicAdd(a.slot_counter, (unsigned long long)it * IVP_WAVE);
-            atomicAdd(a.slot_counter + 1, 1ull);
+    if (active) it = chunk_body<M, GroupRhs<R, G>, FULL, kCtl>(a, j, st);
+    const bool lead = (threadIdx.x & (G - 1)) == 0;
+    compact_append(a, j, active && lead && st == IVP_RUNNING);   // still running: next launch's list
+    if (a.slot_counter) {
+        uint32_t mx = it;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        const unsigned long long act = __ballot(active && lead);
+        if (threadIdx.x == 0) {
+            atomicAdd(a.slot_counter, (unsigned long long)mx * IVP_WAVE);
+            atomicAdd(a.slot_counter + 1, (unsigned long long)__popcll(act));
         }
     }
 }

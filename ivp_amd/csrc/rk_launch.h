@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include "ivp_kargs.h"
 
+// lanes per trajectory of the large-n kernels (rk_group.h): hiprtc modules of systems with n <= 16 / n <= 32 put 4 / 2
+// trajectories into a wavefront, everything larger (and every built-in) uses the whole wavefront
+static inline int ivp_group_width(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+
 enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1, IVP_LAUNCH_COOP = 2 /* hiprtc modules only */ };
 
 // `lanes` = upper bound of trajectories the launch has to cover (grid = ceil(lanes / 64) one-wave blocks).

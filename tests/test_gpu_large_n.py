@@ -236,3 +236,53 @@ def test_large_n_events_match_oracle(method):
             assert np.array_equal(s.t_events[i], o.t_events[i]), (i, s.t_events[i], o.t_events[i])
             assert np.array_equal(s.y_events[i], o.y_events[i])
         assert sum(len(t) for t in s.t_events) >= 3
+
+
+@pytest.mark.parametrize("K", [6, 12, 20])          # n = 12 (16 lanes per trajectory), 24 (32 lanes), 40 (whole wavefront)
+@pytest.mark.parametrize("method", ["DOPRI5", "DOP853", "RK23"])
+def test_group_width_follows_the_system_size(K, method):
+    """hiprtc modules of systems with n <= 16 / n <= 32 put 4 / 2 trajectories into one wavefront (own LDS region each,
+    groups diverge by predication); results are the oracle's bit for bit for every trajectory of a ragged batch,
+    including t_eval samples and a terminal event."""
+    import ivp_amd
+    from oracle import oracle as O
+    n = 2 * K
+    src = r'''
+    #define K %d
+    __device__ double ode_comp(int i, double t, const double* y, const double* p)
+    {   // K masses on a ring: y[0..K) positions, y[K..2K) velocities
+        if (i < K) return y[K + i];
+        const int k = i - K, l = (k + K - 1) %% K, r = (k + 1) %% K;
+        return p[0] * (y[l] - 2.0 * y[k] + y[r]);
+    }
+    __device__ void events(double t, const double* y, double* g, const double* p) { g[0] = y[0] - y[K / 2]; }
+    ''' % K
+
+    def ring(t, y, p):
+        d = np.empty(n)
+        d[:K] = y[K:]
+        q = y[:K]
+        d[K:] = p[0] * (np.roll(q, 1) - 2.0 * q + np.roll(q, -1))
+        return d
+
+    rng = np.random.default_rng(10 + K)
+    B = 11
+    y0 = rng.standard_normal((n, B))
+    par = rng.uniform(1.0, 4.0, (1, B))
+    t1 = rng.uniform(1.0, 5.0, B)
+    tol = dict(RK23=(1e-5, 1e-8), DOPRI5=(1e-7, 1e-9), DOP853=(1e-9, 1e-11))[method]
+    # end states of the whole batch (no events: a problem without event functions)
+    f = ivp_amd.DeviceIVP(src.replace("__device__ void events", "__device__ void unused_events"), n=n, params=(3.0,))
+    r = ivp_amd.solve_ivp_batch(f, 0.0, t1, y0, par, ivp_amd.Options(method=method, rtol=tol[0], atol=tol[1], chunk_attempts=7))
+    for b in range(B):
+        o = O.solve_ivp(ring, 0.0, t1[b], list(y0[:, b]), params=[par[0, b]], method=method, rtol=tol[0], atol=tol[1], detpow=True)
+        assert np.array_equal(r.y_end[:, b], o.y[-1]) and (int(r.naccpt[b]), int(r.nrejct[b]), int(r.nfev[b])) == (o.naccpt, o.nrejct, o.nfev), b
+    # one trajectory with t_eval and a terminal event (second crossing)
+    fe = ivp_amd.DeviceIVP(src, n=n, params=(3.0,), events=[ivp_amd.EventConfig(ivp_amd.Direction.All, 2)])
+    te = np.linspace(0.0, 6.0, 13)
+    s = ivp_amd.solve_ivp(fe, 0.0, 6.0, y0[:, 0], ivp_amd.Options(method=method, rtol=tol[0], atol=tol[1], t_eval=te))
+    o = O.solve_ivp(ring, 0.0, 6.0, list(y0[:, 0]), params=[3.0], method=method, rtol=tol[0], atol=tol[1], detpow=True, t_eval=te,
+                    events=lambda t, y, p: [y[0] - y[K // 2]], n_events=1, event_direction=[0], event_terminal=[2])
+    assert int(s.status) == o.status == 1
+    assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
+    assert np.array_equal(s.t_events[0], o.t_events[0]) and np.array_equal(s.y_events[0], o.y_events[0])
