@@ -35,11 +35,19 @@ struct BdfTables {
     }
 };
 
+// t[i] for a run-time i in 0..5 as a select chain over register values.  The opaque copies keep LLVM from folding the
+// chain into "select the ADDRESS, then load": that would turn a constant table into a global-memory lookup and a lane's
+// difference array into a scratch object -- several hundred cycles of latency on a lone wave's critical path each time.
 IVP_HD double bdf_sel6(const double *t, int i)
 {
     double v = t[0];
+    IVP_OPAQUE_V(v);
 #pragma unroll
-    for (int k = 1; k < 6; ++k) v = (i == k) ? t[k] : v;
+    for (int k = 1; k < 6; ++k) {
+        double tk = t[k];
+        IVP_OPAQUE_V(tk);
+        v = (i == k) ? tk : v;
+    }
     return v;
 }
 
@@ -525,8 +533,9 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 double dv = S.d[1][i];
+                IVP_OPAQUE_V(dv);
 #pragma unroll
-                for (int k = 2; k < 6; ++k) dv = (k == order) ? S.d[k][i] : dv;
+                for (int k = 2; k < 6; ++k) { double dk = S.d[k][i]; IVP_OPAQUE_V(dk); dv = (k == order) ? dk : dv; }
                 rhs[i] = ecm * dv;
             }
             err_m = bdf_wrms<N>(rhs, scale);
@@ -536,8 +545,9 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 double dv = S.d[3][i];
+                IVP_OPAQUE_V(dv);
 #pragma unroll
-                for (int k = 4; k < 8; ++k) dv = (k == order + 2) ? S.d[k][i] : dv;
+                for (int k = 4; k < 8; ++k) { double dk = S.d[k][i]; IVP_OPAQUE_V(dk); dv = (k == order + 2) ? dk : dv; }
                 rhs[i] = ecp * dv;
             }
             err_p = bdf_wrms<N>(rhs, scale);
