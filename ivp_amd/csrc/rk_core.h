@@ -1363,7 +1363,10 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         for (int i = 0; i < N; ++i) { L.k1[i] = k4[i]; L.y[i] = k5[i]; }
         L.x = xph;
         if (FULL) {
-            if (solout_full<M_DOP853, R>(a, j, L, x, xph, L.y, cont, need_dense ? cont : nullptr, h, x)) { L.h = h; L.status = 1; return false; }
+            // `cont` is passed even when its dense rows were not computed (need_dense false): every reader is guarded
+            // by exactly the conditions so_needs_dense() tests, and a pointer selected at run time (cont or nullptr)
+            // would force the whole array out of registers into scratch memory
+            if (solout_full<M_DOP853, R>(a, j, L, x, xph, L.y, cont, cont, h, x)) { L.h = h; L.status = 1; return false; }
         }
         if (last) { L.h = hnew; L.status = 0; return false; }
         if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
