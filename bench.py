@@ -217,6 +217,7 @@ def main():
             "accepted_steps_per_batch": total_acc_per_step,
             "all_success": ok,
             "wave_lane_utilisation": attempts / slots if slots else None,
+            "attempts_per_s": attempts / elapsed * world, "rejection_ratio": float(out.nrejct.sum().item()) / max(float(out.nstep.sum().item()), 1.0),
             "roofline": {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
@@ -244,6 +245,7 @@ def main():
             res["pipelined"] = pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, opts.fp_mode, args)
         if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
+            res["accuracy"] = accuracy_vs_truth(ivp_amd, prob, opts, ctx, dev)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)
@@ -308,16 +310,50 @@ def cpu_baseline(y0, p, t0, t1):
     dt1 = time.perf_counter() - t
     single = r1["total_accepted"] / dt1
     nall = y0.shape[1]
-    t = time.perf_counter()
-    r = O.solve_batch("cr3bp", y0[:, :nall], p[:, :nall], t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=cores)
-    dt = time.perf_counter() - t
+    walls = []
+    for rep in range(6):   # one warm-up + five timed runs, median (the protocol of benches/benchmark.py:56-78)
+        t = time.perf_counter()
+        r = O.solve_batch("cr3bp", y0[:, :nall], p[:, :nall], t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=cores)
+        if rep:
+            walls.append(time.perf_counter() - t)
+    dt = float(np.median(walls))
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    rej = float(r["nrejct"].sum()) / max(float(r["nstep"].sum()), 1.0)
     return {
         "value": r["total_accepted"] / dt, "unit": "steps/s", "cores": cores, "kind": "port",
         "sample": f"the same {nall} CR3BP trajectories, one solve_ivp call each, OpenMP over trajectories "
-                  f"({cores} threads, {dt:.2f} s wall); single thread on the first {n1}: {single:.3e} steps/s",
-        "single_core_value": single,
+                  f"({cores} threads, median of 5 runs after a warm-up: {dt:.2f} s wall); single thread on the first {n1}: {single:.3e} steps/s",
+        "single_core_value": single, "cpu_model": model, "wall_s": dt,
+        "attempts_per_s": float(r["nstep"].sum()) / dt, "rejection_ratio": rej,
         "what": "oracle/ivp_oracle.c: C restatement of the reference (Rust) algorithm; the crate cannot be built here",
     }
+
+
+def accuracy_vs_truth(ivp_amd, prob, opts, ctx, dev):
+    """End-state error of the GPU path and of the CPU oracle against the committed SciPy DOP853 @ 1e-13 truth for the
+    first trajectories of the C2 batch (tests/golden/scipy_truth.json; BASELINE target: within 10x of the CPU's)."""
+    import torch
+    from ivp_amd import workloads as W
+    from oracle import oracle as O
+    truth = json.load(open(os.path.join(ROOT, "tests", "golden", "scipy_truth.json")))["truth"]["cr3bp"]
+    n = int(truth["subset"])
+    y0, p, t0, t1 = W.cr3bp_batch(256)
+    y0, p = np.ascontiguousarray(y0[:, :n]), np.ascontiguousarray(p[:, :n])
+    ref = np.asarray(truth["y_end"]).T
+    r = ivp_amd.solve_ivp_batch(prob, t0, t1, torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev),
+                                ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=opts.fp_mode), ctx)
+    o = O.solve_batch("cr3bp", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9)
+    eg = float(np.abs(r.y_end.cpu().numpy() - ref).max())
+    ec = float(np.abs(o["y_end"] - ref).max())
+    return {"subset": n, "truth": "SciPy DOP853 rtol=atol=1e-13 (tests/golden/scipy_truth.json)", "gpu_max_abs_err": eg,
+            "cpu_max_abs_err": ec, "ratio": eg / ec if ec > 0 else None}
 
 
 if __name__ == "__main__":
