@@ -422,6 +422,7 @@ class Context:
                            "(libivp_hip needs a HIP device; there is no CPU fallback)")
         self.handle = h
         self.device = device
+        self._scalars = {}   # device copies of scalar t0 / t1 values (saves two tiny host-to-device copies per call)
 
     def last_error(self) -> str:
         return self.lib.ivp_last_error_string(self.handle).decode(errors="replace")
@@ -702,9 +703,21 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         if y0.dtype != torch.float64 or not y0.is_contiguous():
             raise ValueError("y0 must be a contiguous float64 tensor [n, B]")
         ptr = lambda a: None if a is None else C.c_void_p(a.data_ptr())
-        as_arr = lambda v: (v if _is_torch(v) else torch.as_tensor(np.atleast_1d(np.asarray(v, dtype=np.float64)), device=y0.device))
         dev_index = y0.device.index or 0
         ctx = ctx or default_context(dev_index)
+
+        def as_arr(v):
+            if _is_torch(v):
+                return v
+            if np.ndim(v) == 0:   # a scalar t0 / t1: one 8-byte device tensor per distinct value, kept on the context
+                key = (str(y0.device), float(v))
+                t = ctx._scalars.get(key)
+                if t is None:
+                    if len(ctx._scalars) > 256:
+                        ctx._scalars.clear()
+                    t = ctx._scalars[key] = torch.as_tensor(np.array([float(v)]), device=y0.device)
+                return t
+            return torch.as_tensor(np.atleast_1d(np.asarray(v, dtype=np.float64)), device=y0.device)
     else:
         y0 = np.ascontiguousarray(y0, dtype=np.float64)
         xp_zeros = lambda shape, dt: np.zeros(shape, dtype=dt)
