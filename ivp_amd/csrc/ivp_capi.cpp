@@ -103,6 +103,7 @@ struct ivp_ctx {
         uint32_t chunk = 64, lanes = 0;
         size_t B = 0;
         uint64_t c = 0;             // chunk launches so far
+        bool spec = false;          // the last launch of the round in flight was a speculative cooperative one
         bool err_checked = false;
         hipStream_t stream = nullptr;
         hipEvent_t round_done = nullptr;
@@ -198,6 +199,9 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     return IVP_OK;
 }
 
+// lanes (8 per trajectory) up to which the lane-cooperative kernels take over: two waves per SIMD
+constexpr size_t kCoopCapLanes = 2u * 256u * 4u * 64u;
+
 hipEvent_t pend_event(ivp_ctx *ctx)
 {
     ivp_ctx::Pending &P = ctx->pend;
@@ -248,7 +252,7 @@ int enqueue_round(ivp_ctx *ctx)
     // eight lanes per trajectory pay off once the cooperative waves fit two per SIMD, and only for systems
     // with enough components to share out (measured: 1.3-1.45x at n = 6, break-even at n = 3, a loss at n = 2)
     // (fast mode: decided by the batch size alone, like the lean / resident choice above)
-    const size_t coop_cap = 2 * (size_t)kOneWavePerSimd;   // a cooperative wave keeps its SIMD < 60 % busy: two share one well
+    const size_t coop_cap = kCoopCapLanes;   // a cooperative wave keeps its SIMD < 60 % busy: two share one well
     const bool use_coop = P.coop_ok && (P.variant == 3 ||
                                         (P.variant == 0 && P.adaptive && P.n >= 4 &&
                                          (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) * 8u <= coop_cap));
@@ -279,6 +283,28 @@ int enqueue_round(ivp_ctx *ctx)
         ctx->stats.launches += 1;
         if (use_coop) ctx->stats.coop_launches += 1;
     }
+    // Speculative hand-over: after a round of bulk launches the cooperative kernel is enqueued right away, sized for
+    // the largest set it may take; it does nothing unless the active count turned out small enough.  When it runs, the
+    // poll between the bulk and the tail of a batch (~40 us of host round trip) disappears.
+    P.spec = false;
+    if (!tail && !use_coop && P.coop_ok && P.variant == 0 && P.adaptive && P.n >= 4 && P.fp_mode == IVP_FP_STRICT && !P.jit) {
+        const uint64_t c = P.c;
+        IvpKArgs ka = P.a;
+        ka.chunk = 1024u;
+        ka.spec_cap = (uint32_t)(coop_cap / 8u);
+        ka.perm_in = (const uint32_t *)ctx->perm[(c - 1) & 1].p;
+        ka.count_in = counts + ((c - 1) & 3);
+        ka.perm_out = (uint32_t *)ctx->perm[c & 1].p;
+        ka.count_out = counts + (c & 3);
+        if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
+        HIP_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, std::min<uint32_t>(lanes, ka.spec_cap), false, true));
+        if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(1); }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 2, counts + ((c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // what the bulk left
+        P.c += 1;
+        P.spec = true;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((P.c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (!P.err_checked) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(P.round_done, s));
@@ -297,6 +323,18 @@ int finish_round(ivp_ctx *ctx, int *done)
         }
     }
     P.lanes = ctx->pinned[0];
+    if (P.spec) {
+        P.spec = false;
+        const uint32_t left_by_bulk = ctx->pinned[2];
+        if ((size_t)left_by_bulk * 8u > kCoopCapLanes) {   // the speculative launch declined: nothing moved, its slot is reused
+            P.c -= 1;
+            P.lanes = left_by_bulk;
+            if (!P.step_is_coop.empty()) P.step_is_coop.back() = 0;   // its few microseconds count as plain stepping time
+        } else {
+            ctx->stats.launches += 1;
+            ctx->stats.coop_launches += 1;
+        }
+    }
     if (P.lanes != 0) return enqueue_round(ctx);
     P.active = false;
     *done = 1;

@@ -103,4 +103,7 @@ struct IvpKArgs {
     uint32_t *err_flag;       // device word: IVP_ERRFLAG_* bits raised by the init kernel
     // ---- profiling ----
     unsigned long long *slot_counter;  // optional: += lanes x attempts the wave executed
+    // ---- speculative launch of the lane-cooperative kernel (rk_coop.h) ----
+    uint32_t spec_cap;        // != 0: do nothing unless *count_in <= spec_cap (the host enqueued this launch before
+                              // it knew the active count; it reads count_in afterwards to see which way it went)
 };

@@ -93,3 +93,18 @@ def test_coop_event_detection_matches_oracle(case):
     stats_probe = gpu_batch(case[1], np.asarray(case[4], float).reshape(-1, 1), None if not len(case[5]) else np.asarray(case[5], float).reshape(-1, 1),
                             case[2], case[3], variant=3, profile=1, max_log=64, **{k: v for k, v in case[6].items() if k != "t_eval"})
     assert stats_probe["stats"]["coop_launches"] == stats_probe["stats"]["launches"] > 0
+
+
+def test_speculative_hand_over_declines_then_accepts():
+    """Tight tolerances: after each bulk round the speculative cooperative launch finds the active set still too large
+    and does nothing (several times) before it finally takes over.  Results equal the lean-only run bit for bit."""
+    y0, p, t0, t1 = W.cr3bp_batch(100000)      # > 65536 trajectories: the first rounds are bulk rounds
+    o = dict(method="DOPRI5", rtol=1e-9, atol=1e-12)
+    auto = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, profile=1, **o)
+    lean = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, variant=1, **o)
+    assert_bitexact(auto, lean, "auto vs lean ")
+    st = auto["stats"]
+    assert st["coop_launches"] >= 1 and st["launches"] - st["coop_launches"] >= 6     # at least two bulk rounds => a declined launch
+    ref = oracle_batch("cr3bp", y0[:, :512], p[:, :512], t0, t1, **o)
+    sub = {k: (v[..., :512] if isinstance(v, np.ndarray) else v) for k, v in auto.items()}
+    assert_bitexact(sub, ref, "auto vs oracle ")
