@@ -108,3 +108,9 @@ def test_speculative_hand_over_declines_then_accepts():
     ref = oracle_batch("cr3bp", y0[:, :512], p[:, :512], t0, t1, **o)
     sub = {k: (v[..., :512] if isinstance(v, np.ndarray) else v) for k, v in auto.items()}
     assert_bitexact(sub, ref, "auto vs oracle ")
+    # the DOP853 instantiation of the same mechanism
+    o = dict(method="DOP853", rtol=1e-8, atol=1e-10)
+    auto = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, profile=1, **o)
+    lean = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, variant=1, **o)
+    assert_bitexact(auto, lean, "DOP853 auto vs lean ")
+    assert auto["stats"]["coop_launches"] >= 1
