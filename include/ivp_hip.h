@@ -235,7 +235,8 @@ int ivp_ctx_get_stats(const ivp_ctx_t *ctx, ivp_run_stats_t *stats);
 /* Options::builder().build() defaults (src/solve/options.rs:75-123). */
 void ivp_options_default(ivp_options_t *opt);
 
-/* Sets method and fills uround .. stiff_test with that method's struct defaults (has_settings stays as it is). */
+/* `DOPRI5::default()` / `DOP853::default()` / `RK23::default()` (src/methods/dopri5.rs:34-72, dop853.rs:34-81,
+ * rk23.rs:17-50): sets method and fills uround .. stiff_test with that struct's defaults (has_settings stays as it is). */
 int ivp_options_method_defaults(ivp_options_t *opt, int32_t method);
 
 /* Dimension lookup for built-in right-hand sides; ivp_rhs_n_events = IVP::n_events() (src/ivp.rs:42-46). */
@@ -265,7 +266,7 @@ int ivp_batch_solve_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
                            void *hip_stream);
 
 /*
- * The same solve as a resumable operation, so that one host thread can keep several contexts (= several batches,
+ * The same solve (src/solve/solve_ivp.rs:99-108, B calls) as a resumable operation, so that one host thread can keep several contexts (= several batches,
  * each on its own stream) in flight: a solve is a sequence of rounds (a few kernel launches, then the count of
  * still-running trajectories travels to the host), and only the hand-over between rounds needs the host.
  *   ivp_batch_submit_device  validates, enqueues the init kernel and the first round, returns without waiting;
