@@ -40,24 +40,32 @@ class BatchPipeline:
         nxt = 0
         inflight: List[Optional[tuple]] = [None] * len(self.ctxs)   # (batch index, PendingBatch) per context
         remaining = len(batches)
-        while remaining:
-            for w in range(len(self.ctxs)):
-                if inflight[w] is not None:
-                    k, pend = inflight[w]
-                    if pend.done():
-                        results[k] = pend.result()
-                        inflight[w] = None
-                        remaining -= 1
-                        if on_done is not None:
-                            on_done(k, results[k])
-                if inflight[w] is None and nxt < len(batches):
-                    b = batches[nxt]
-                    with torch.cuda.stream(self.streams[w]):
-                        out = out_per_context[w] if out_per_context is not None else b.get("out")
-                        inflight[w] = (nxt, api.solve_ivp_batch(f, b["t0"], b["t1"], b["y0"], b.get("params"), options,
-                                                                self.ctxs[w], out, wait=False))
-                    nxt += 1
-            # nothing ready: poll again (a round lasts 0.3-2 ms; each poll is one hipEventQuery per context)
+        try:
+            while remaining:
+                for w in range(len(self.ctxs)):
+                    if inflight[w] is not None:
+                        k, pend = inflight[w]
+                        if pend.done():
+                            results[k] = pend.result()
+                            inflight[w] = None
+                            remaining -= 1
+                            if on_done is not None:
+                                on_done(k, results[k])
+                    if inflight[w] is None and nxt < len(batches):
+                        b = batches[nxt]
+                        with torch.cuda.stream(self.streams[w]):
+                            out = out_per_context[w] if out_per_context is not None else b.get("out")
+                            inflight[w] = (nxt, api.solve_ivp_batch(f, b["t0"], b["t1"], b["y0"], b.get("params"), options,
+                                                                    self.ctxs[w], out, wait=False))
+                        nxt += 1
+                # nothing ready: poll again (a round lasts 0.3-2 ms; each poll is one hipEventQuery per context)
+        finally:
+            for slot in inflight:   # an exception must not leave solves in flight on the pipeline's contexts
+                if slot is not None:
+                    try:
+                        slot[1].result()
+                    except Exception:
+                        pass
         torch.cuda.synchronize(self.device)
         return results  # type: ignore[return-value]
 

@@ -454,3 +454,19 @@ def test_c4_sharded_solve_two_ranks_sharing_the_gpu(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-2000:]
+
+
+def test_pipeline_recovers_after_a_failing_batch():
+    """A batch that fails validation (RK4 with a wrong-signed step) raises, and the pipeline's contexts are usable again."""
+    import torch
+    import ivp_amd
+    from ivp_amd.pipeline import BatchPipeline
+    dev = torch.device("cuda:0")
+    y0, p, t0, t1 = W.cr3bp_batch(2000, seed=9)
+    b = dict(t0=t0, t1=t1, y0=torch.as_tensor(y0, device=dev), params=torch.as_tensor(p, device=dev))
+    pipe = BatchPipeline(2)
+    with pytest.raises(ivp_amd.ConfigError):
+        pipe.map(ivp_amd.CR3BP(), [b, b, b], ivp_amd.Options(method="RK4", first_step=-0.01))
+    good = pipe.map(ivp_amd.CR3BP(), [b, b, b], ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
+    ref = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, b["y0"], b["params"], ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
+    assert all(torch.equal(g.y_end, ref.y_end) for g in good)
