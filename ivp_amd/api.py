@@ -347,7 +347,8 @@ class Options:
     chunk_attempts: int = 0
     max_log: int = 0
     max_events: int = 64               # capacity of t_events / y_events per event and trajectory
-    variant: int = 0                   # stepping-kernel variant: 0 auto, 1 lean registers, 2 coefficients resident
+    variant: int = 0                   # stepping-kernel variant: 0 auto, 1 lean registers, 2 coefficients resident,
+                                       # 3 lane-cooperative (8 lanes per trajectory; DOPRI5 / DOP853) -- strict results never depend on it
     profile: int = 0                   # 1: HIP-event kernel timing, 2: + batch totals (see ivp_run_stats_t)
 
     def _c(self, n: int, keep: list) -> _lib.OptionsT:
