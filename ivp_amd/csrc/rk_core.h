@@ -50,9 +50,27 @@
 #if defined(__HIP_DEVICE_COMPILE__) && !IVP_HOIST
 #define KC_SCOPE const uint64_t ivp_kz = IVP_NS::ivp_opaque_zero();
 #define KC(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kz)
+#elif defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 2
+// Build variant IVP_HOIST=2 (kernels in which a lone wave owns its SIMD: rk_coop.h, rk_group.h): every
+// coefficient is PINNED in a vector register for the whole attempt loop.  The XOR partner is an opaque zero
+// defined once before the attempt loop (Lane::kz), so loop-invariant code motion hoists the XOR and the
+// result cannot be re-materialised as a literal.  A lone wave pays a full issue slot for every s_mov / v_mov
+// that re-creates a constant (measured: ~100 of ~1350 slots per DOPRI5 attempt), and has registers to spare.
+#define KC_SCOPE const uint64_t ivp_kz = 0;   /* code outside the attempt loop (init kernel): plain literals */
+#define KC(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kz)
 #else
 #define KC_SCOPE
 #define KC(c) (c)
+#endif
+// KC_SCOPE_KZ(z): like KC_SCOPE inside the attempt loop; in the pinned variant the XOR partner is the opaque vector
+// zero `z` that chunk_body defined BEFORE the loop (Lane::kz), so `literal ^ z` is loop-invariant and gets hoisted.
+// IVP_KZ_ARG hands the partner on to helpers that have no Lane (ivp_pow).
+#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 2
+#define KC_SCOPE_KZ(z) const uint64_t ivp_kz = (z);
+#define IVP_KZ_ARG ivp_kz
+#else
+#define KC_SCOPE_KZ(z) KC_SCOPE
+#define IVP_KZ_ARG 0ull
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define IVP_OPAQUE_V(v) asm volatile("" : "+v"(v))
@@ -71,6 +89,12 @@ __device__ __forceinline__ uint64_t ivp_opaque_zero()
     uint64_t z = 0;
     asm volatile("" : "+s"(z));
     return z;
+}
+__device__ __forceinline__ uint64_t ivp_opaque_zero_v()
+{
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    return ((uint64_t)z << 32) | z;
 }
 #endif
 // whole-call validation failures that can only be detected per trajectory (the reference's Err(Error::Config))
@@ -91,22 +115,21 @@ IVP_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 // exp2(e*log2 x) from IEEE +,-,*,/,fma,rint and bit moves only, ~2 ulp.  Replaces f64::powf
 // (dopri5.rs:351-353, dop853.rs:432-434, rk23.rs:289,303, mod.rs:276); deterministic on any IEEE
 // machine, which is what makes the strict path bit-comparable with a CPU restatement.
-IVP_HD double ivp_pow(double x, double e)
+// Two entry points with identical results: ivp_pow_full is the definition (every special case in order);
+// ivp_pow takes the common case -- x a positive normal number, e finite and non-zero -- through one
+// straight-line instruction stream (no exec-mask branches: the out-of-range results are selected at the
+// end) and hands everything else to ivp_pow_full.
+IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
 {
-    KC_SCOPE
-    if (e == 0.0) return 1.0;
-    if (x != x || e != e) return x + e;
-    if (x < 0.0) return u2d(0x7FF8000000000000ull);
-    if (x == 0.0) return e > 0.0 ? 0.0 : u2d(0x7FF0000000000000ull);
-    if (x == u2d(0x7FF0000000000000ull)) return e > 0.0 ? x : 0.0;
-    int k = 0;
-    uint64_t u = d2u(x);
-    if ((u >> 52) == 0) { x *= 0x1p54; u = d2u(x); k = -54; }
+    KC_SCOPE_KZ(kz)
+    (void)kz;
+    int k = k0;
+    const uint64_t u = d2u(x);
     int ex = (int)(u >> 52) - 1023;
     const uint64_t mant = u & 0x000FFFFFFFFFFFFFull;
-    double m;
-    if (mant > 0x6A09E667F3BCDull) { m = u2d(mant | 0x3FE0000000000000ull); ex += 1; }
-    else { m = u2d(mant | 0x3FF0000000000000ull); }
+    const bool hi = mant > 0x6A09E667F3BCDull;
+    const double m = u2d(mant | (hi ? 0x3FE0000000000000ull : 0x3FF0000000000000ull));
+    ex += hi ? 1 : 0;
     k += ex;
     const double t = (m - 1.0) / (m + 1.0);
     const double z = t * t;
@@ -126,8 +149,7 @@ IVP_HD double ivp_pow(double x, double e)
     const double lnm = (2.0 * t) * p;
     const double l2 = fma(lnm, KC(0x1.71547652b82fep+0), (double)k);
     const double w = e * l2;
-    if (w >= 1024.0) return u2d(0x7FF0000000000000ull);
-    if (w <= -1022.0) return 0.0;
+    // w >= 1024 -> +inf and w <= -1022 -> 0 are selected at the end; a NaN w (e = +-inf with x == 1) travels through
     const double kd = rint(w);
     const double r = w - kd;
     const double v = r * KC(0x1.62e42fefa39efp-1);
@@ -146,8 +168,36 @@ IVP_HD double ivp_pow(double x, double e)
     q = fma(q, v, 0.5);
     q = fma(q, v, 1.0);
     q = fma(q, v, 1.0);
-    const int ki = (int)kd;
-    return q * u2d((uint64_t)(ki + 1023) << 52);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int ki = (int)kd;   // v_cvt_i32_f64 saturates; kd is out of range only where the result is replaced below
+#else
+    const int ki = (kd >= -2000.0 && kd <= 2000.0) ? (int)kd : 0;
+#endif
+    double res = q * u2d((uint64_t)((uint32_t)ki + 1023u) << 52);
+    res = (w <= -1022.0) ? 0.0 : res;
+    res = (w >= 1024.0) ? u2d(0x7FF0000000000000ull) : res;
+    return res;
+}
+IVP_HD double ivp_pow_full(double x, double e, uint64_t kz)
+{
+    if (e == 0.0) return 1.0;
+    if (x != x || e != e) return x + e;
+    if (x < 0.0) return u2d(0x7FF8000000000000ull);
+    if (x == 0.0) return e > 0.0 ? 0.0 : u2d(0x7FF0000000000000ull);
+    if (x == u2d(0x7FF0000000000000ull)) return e > 0.0 ? x : 0.0;
+    int k = 0;
+    if ((d2u(x) >> 52) == 0) { x *= 0x1p54; k = -54; }
+    const double r = ivp_pow_core(x, e, k, kz);
+    // e = +-inf with x == 1 gives w = NaN: neither range test holds and the NaN travels through the polynomial
+    return r;
+}
+IVP_HD double ivp_pow(double x, double e, uint64_t kz = 0)
+{
+    const uint64_t ux = d2u(x);
+    const bool common = (ux - 0x0010000000000000ull) < 0x7FE0000000000000ull   // x positive, normal, finite
+                        && fabs(e) < u2d(0x7FF0000000000000ull) && e != 0.0;     // e finite, non-zero
+    if (common) return ivp_pow_core(x, e, 0, kz);
+    return ivp_pow_full(x, e, kz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -199,36 +249,18 @@ struct RhsCr3bp {    // examples/cr3bp.rs:23-36
         d[5] = -(1.0 - mu) * z / r13 - mu * z / r23;
 #endif
     }
-#if defined(__HIPCC__) && !IVP_FAST
-    // Lane-cooperative form for rk_coop.h: lane c (0..7) of an 8-lane group holds component c of the stage state in
-    // `ys` and returns component c of f.  One uniform instruction stream for all lanes (per-lane operands are picked
-    // with selects, so there is no divergence): every lane computes r13 and r23, then a single
-    //     d = (lin + ((-(1-mu)) * q) / r13) - (mu * q2) / r23
-    // which is the reference expression of its component bit for bit: u - v == u + (-v), (-s) * t == -(s * t) and
-    // (-s) / t == -(s / t) hold exactly in IEEE arithmetic, and lin = -0.0 reproduces the leading unary minus of d[5]
-    // including the sign of a zero result.
-    static __device__ __forceinline__ double ode_coop(double, double ys, uint32_t base, uint32_t c, const double *p)
-    {
-        const double mu = p[0];
-        const double x = __shfl(ys, (int)base), y = __shfl(ys, (int)base + 1), z = __shfl(ys, (int)base + 2);
-        // lanes 0..2 return vx, vy, vz; lane 3 needs vy, lane 4 needs vx
-        const uint32_t src = c < 3u ? c + 3u : (c == 3u ? 4u : 3u);
-        const double w = __shfl(ys, (int)(base + src));
-        const double a = x + mu;
-        const double b = x - 1.0 + mu;
-        const double r1 = sqrt(a * a + y * y + z * z);
-        const double r2 = sqrt(b * b + y * y + z * z);
-        const double r13 = r1 * r1 * r1;
-        const double r23 = r2 * r2 * r2;
-        const double q = c == 3u ? a : (c == 4u ? y : z);
-        const double q2 = c == 3u ? b : (c == 4u ? y : z);
-        const double P = c == 3u ? x : y;
-        const double sgn2 = c == 3u ? 2.0 : -2.0;
-        double lin = P + sgn2 * w;
-        lin = c == 5u ? -0.0 : lin;
-        const double d = (lin + (-(1.0 - mu)) * q / r13) - mu * q2 / r23;
-        return c < 3u ? w : d;
-    }
+#if defined(__HIPCC__)
+    // Lane-cooperative form for rk_coop.h.  Layout inside the 8-lane group: lanes 0..2 hold x, y, z, lanes 4..6 hold
+    // vx, vy, vz (lanes 3 and 7 idle), so that every exchange below is one DPP hop.  The two quads run ONE instruction
+    // stream: the lower quad evaluates the attraction of the first primary (offset a = x + mu, coefficient 1 - mu), the
+    // upper quad that of the second (b = x - 1 + mu, coefficient mu) -- one sqrt and one division per lane.  Lane i of
+    // a quad handles numerator i of (a|b, y, z).  The upper quad then combines
+    //     d = (lin - T1) - T2,   T1 = ((1-mu) q1) / r1^3 from the lane four below,   T2 = (mu q2) / r2^3 its own,
+    // which is the reference expression of d[3], d[4], d[5] bit for bit: x + (-0.0) == x, x + (-1.0) == x - 1.0,
+    // y + (-2.0) vx == y - 2.0 vx, and lin = -0.0 reproduces the leading unary minus of d[5] including the sign of a
+    // zero result ((-s) * t == -(s * t) and (-s) / t == -(s / t) hold exactly in IEEE arithmetic).
+    static constexpr int coop_lane_of(int c) { return c < 3 ? c : c + 1; }
+    static __device__ __forceinline__ double ode_coop(double, double ys, const double *p);
 #endif
 };
 struct RhsLorenz {   // benches/benchmark.py:30-37
@@ -349,6 +381,12 @@ struct NormOps {
         for (int i = 0; i < N; ++i) s += t[i];
         return s;
     }
+    // the step controller's two powers (dopri5.rs:351-352, dop853.rs:432-433); rk_coop.h evaluates them side by side
+    static IVP_HD void pow2(double x1, double e1, double x2, double e2, double &r1, double &r2, uint64_t kz)
+    {
+        r1 = ivp_pow(x1, e1, kz);
+        r2 = ivp_pow(x2, e2, kz);
+    }
 };
 // state-array access through the map (component-major SoA: a[gi(c) * B + j])
 template <class MAP>
@@ -369,6 +407,7 @@ struct Lane {
     uint32_t budget;      // attempts left before `steps.total > nmax` (saturating)
     uint32_t acc_small;   // min(naccpt, 2): `steps.accepted > 1` test (dopri5.rs:455)
     bool over;            // nmax already exceeded on entry
+    uint64_t kz;          // opaque zero for KC() in the pinned-coefficient variant (IVP_HOIST = 2), else unused
     // DefaultSolOut registers (FULL kernels)
     int32_t next_idx, n_filled;
     uint32_t n_log, n_seg;
@@ -975,7 +1014,7 @@ IVP_HD bool stiff_tick(const IvpKArgs &a, uint32_t j, uint32_t &flags, uint32_t 
 template <class R, bool FULL, bool CTL = false>
 IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
-    KC_SCOPE
+    KC_SCOPE_KZ(L.kz)
     constexpr int N = R::N;
     // tableau, dopri5.rs:482-520
     constexpr double C2 = 0.2, C3 = 0.3, C4 = 0.8, C5 = 8.0 / 9.0;
@@ -1057,8 +1096,9 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     double err = NormOps<R>::sum(t_err);
     err = sqrt(err / (double)NormOps<R>::NT);
 
-    const double fac11 = ivp_pow(err, IVP_CTL(ctl_expo1, d_expo1));
-    double fac = fac11 / ivp_pow(L.facold, CTL ? a.ctl_beta : d_beta);
+    double fac11, facb;
+    NormOps<R>::pow2(err, IVP_CTL(ctl_expo1, d_expo1), L.facold, CTL ? a.ctl_beta : d_beta, fac11, facb, IVP_KZ_ARG);
+    double fac = fac11 / facb;
     fac = fmax(IVP_CTL(ctl_facc2, d_facc2), fmin(IVP_CTL(ctl_facc1, d_facc1), fac / IVP_CTL(ctl_safety, d_safety)));
     double hnew = h / fac;
 
@@ -1120,7 +1160,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 template <class R, bool FULL, bool CTL = false>
 IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
-    KC_SCOPE
+    KC_SCOPE_KZ(L.kz)
     constexpr int N = R::N, P = R::P;
     // Hairer's DOP853 coefficients, dop853.rs:674-848
     constexpr double C2 = 0.526001519587677318785587544488e-01, C3 = 0.789002279381515978178381316732e-01,
@@ -1283,8 +1323,9 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     if (deno <= 0.0) deno = 1.0;
     err = fabs(h) * err * sqrt(1.0 / ((double)NormOps<R>::NT * deno));
 
-    const double fac11 = ivp_pow(err, IVP_CTL(ctl_expo1, d_expo1));
-    double fac = fac11 / ivp_pow(L.facold, CTL ? a.ctl_beta : d_beta);
+    double fac11, facb;
+    NormOps<R>::pow2(err, IVP_CTL(ctl_expo1, d_expo1), L.facold, CTL ? a.ctl_beta : d_beta, fac11, facb, IVP_KZ_ARG);
+    double fac = fac11 / facb;
     fac = fmax(IVP_CTL(ctl_facc2, d_facc2), fmin(IVP_CTL(ctl_facc1, d_facc1), fac / IVP_CTL(ctl_safety, d_safety)));
     double hnew = h / fac;
 
@@ -1388,7 +1429,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 template <class R, bool FULL, bool CTL = false>
 IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
-    KC_SCOPE
+    KC_SCOPE_KZ(L.kz)
     constexpr int N = R::N;
     // tableau, rk23.rs:325-347
     constexpr double C2 = 0.5, C3 = 0.75, A21 = 0.5, A32 = 0.75;
@@ -1462,13 +1503,13 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) L.k1[i] = k4[i];
-        h *= fmax(fmin(IVP_CTL(ctl_safety, d_safety) * ivp_pow(err, KC(error_exponent)), IVP_CTL(ctl_scale_max, d_scale_max)), IVP_CTL(ctl_scale_min, d_scale_min));
+        h *= fmax(fmin(IVP_CTL(ctl_safety, d_safety) * ivp_pow(err, KC(error_exponent), IVP_KZ_ARG), IVP_CTL(ctl_scale_max, d_scale_max)), IVP_CTL(ctl_scale_min, d_scale_min));
         if (fabs(h) > L.hmax) h = L.hmax * L.posneg;
         L.h = h;
         if (xnew == L.xend) { L.status = 0; return false; }
     } else {
         L.d_nrejct += 1;
-        h *= fmax(fmin(IVP_CTL(ctl_safety, d_safety) * ivp_pow(err, KC(error_exponent)), 1.0), IVP_CTL(ctl_scale_min, d_scale_min));
+        h *= fmax(fmin(IVP_CTL(ctl_safety, d_safety) * ivp_pow(err, KC(error_exponent), IVP_KZ_ARG), 1.0), IVP_CTL(ctl_scale_min, d_scale_min));
         L.h = h;
         // The reference never terminates from here when err is NaN (h *= 1.0 forever) or once h has
         // collapsed to 0 (rk23.rs:300-306 has no underflow test).  A GPU lane must retire: report
@@ -1486,7 +1527,7 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 template <class R, bool FULL>
 IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
-    KC_SCOPE
+    KC_SCOPE_KZ(L.kz)
     constexpr int N = R::N;
     constexpr double C2 = 0.5, C3 = 0.5, A21 = 0.5, A32 = 0.5;   // rk4.rs:247-257 (C4 = A43 = 1)
     constexpr double B1 = 1.0 / 6.0, B2 = 1.0 / 3.0, B3 = 1.0 / 3.0, B4 = 1.0 / 6.0;
@@ -1541,6 +1582,11 @@ IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     Lane<R::N, R::P> L;
     lane_load<R>(a, j, L, M == M_RK23 || M == M_RK4, FULL);
+#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 2
+    L.kz = ivp_opaque_zero_v();
+#else
+    L.kz = 0;
+#endif
     if (a.has_max_step) L.hmax = (M == M_DOPRI5) ? a.max_step : fabs(a.max_step);
     else L.hmax = fabs(L.xend - L.x0);
     uint32_t it = 0;

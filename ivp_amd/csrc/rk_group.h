@@ -106,6 +106,11 @@ struct NormOps<GroupRhs<R, G>, void> {
         const int i = GroupRhs<R, G>::gl() + G * c;
         return (a.atol_dev && i < NT) ? a.atol_dev[i] : a.atol[0];
     }
+    static __device__ __forceinline__ void pow2(double x1, double e1, double x2, double e2, double &r1, double &r2, uint64_t kz)
+    {
+        r1 = ivp_pow(x1, e1, kz);
+        r2 = ivp_pow(x2, e2, kz);
+    }
     template <int C>
     static __device__ __forceinline__ double sum(const double (&term)[C])
     {

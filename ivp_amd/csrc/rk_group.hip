@@ -1,12 +1,12 @@
 // rk_group.hip -- the kernels in which several lanes share one trajectory, and their launch tables:
 //   * rk_group.h: wave-per-trajectory RK23 / DOPRI5 / DOP853 / RK4 for large state dimensions (8 < n <= 512);
 //   * rk_coop.h:  eight lanes per trajectory (n <= 8) for the latency-bound tail of a batch.  Compiled twice like rk_kernels.hip: strict (-ffp-contract=off, index-order error-norm sum) and
-// fast (-ffp-contract=fast, __shfl_xor butterfly).  Coefficients stay resident in registers (IVP_HOIST): a lone
-// wave per trajectory is latency-bound and has VGPRs to spare.
+// fast (-ffp-contract=fast, __shfl_xor butterfly).  Coefficients are pinned in vector registers (IVP_HOIST = 2, see
+// KC() in rk_core.h): a lone wave per SIMD pays an issue slot for every re-materialised constant and has VGPRs to spare.
 #include <hip/hip_runtime.h>
 
 #define IVP_HD __host__ __device__ __forceinline__
-#define IVP_HOIST 1
+#define IVP_HOIST 2
 #if IVP_FAST
 #define IVP_NS ivp_group_fast
 #define IVP_LAUNCH_NAME ivp_launch_group_fast
