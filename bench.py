@@ -10,9 +10,14 @@ over all ranks.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank integrates its own 100k-trajectory shard of a parameter sweep
-(weak scaling; trajectories are independent so there is no data-path collective) and the end states
-are gathered with one RCCL all-gather per step inside the timed region (BASELINE config C4).
+N > 1 (BASELINE config C4 as written): one process per GPU; the SAME batch of 100 000 trajectories is cut into N
+contiguous shards after a fixed permutation (trajectories are independent, so there is no data-path collective) and the
+end-state arenas are gathered with ONE RCCL all-gather per step inside the timed region: "scaling": "strong".  A weak-
+scaling figure (100 000 trajectories PER GPU) is measured in the same run and reported as the "weak" object.
+
+Timing: the headline steps run with options.profile = 0; the per-launch HIP-event durations that feed the roofline
+objects come from a separate instrumented pass of the same K steps; "wall_ms_with_d2h" repeats the steps with a D2H
+copy of the results into pinned host memory after every solve.
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (HBM view, as the contract asks),
 "roofline_fp64" (the resource that actually binds this kernel: FP64 VALU issue) and "cpu_baseline"
@@ -75,13 +80,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=100_000, help="trajectories per GPU (BASELINE C2: 100000)")
+    ap.add_argument("--batch", type=int, default=100_000, help="trajectories in the whole batch (BASELINE C2 / C4: 100000)")
     ap.add_argument("--fp", choices=["strict", "fast"], default="strict")
     ap.add_argument("--chunk", type=int, default=0, help="step attempts per launch (0 = library default)")
     ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
-                    help="c2 = BASELINE headline (default); c3 = 1M Van der Pol DOP853 rtol 1e-8; c5 = 10k stiff Van der Pol BDF")
+                    help="c2 = BASELINE headline (default; with --gpus N > 1 it is C4: the same batch sharded); "
+                         "c3 = 1M Van der Pol DOP853 rtol 1e-8; c5 = 10k stiff Van der Pol BDF")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast", action="store_true", help="skip the secondary fast-FP-mode measurement")
+    ap.add_argument("--no-fast", action="store_true", help="skip the secondary fast-FP-mode / pipelined measurements")
     args = ap.parse_args()
 
     # RCCL prints a version banner on stdout while the process group comes up; keep stdout clean for the ONE JSON
@@ -107,90 +114,110 @@ def main():
 
     import ivp_amd
     from ivp_amd import workloads as W
+    from ivp_amd.distributed import ResultArena, run_steps, shard_bounds
 
-    B = args.batch
     fp = ivp_amd.FpMode.FAST if args.fp == "fast" else ivp_amd.FpMode.STRICT
     wl = WORKLOADS[args.workload]
-    if args.workload != "c2" and args.batch == 100_000:
-        B = wl["B"]
-    # parameter sweep: rank r integrates its own B trajectories (seed offset => distinct shards)
-    y0, p, t0, t1 = getattr(W, wl["gen"])(B, seed=wl["seed"] + rank)
-    y0d = torch.as_tensor(y0, device=dev)
-    pd = torch.as_tensor(p, device=dev)
-    t1 = torch.as_tensor(t1, device=dev) if np.ndim(t1) else t1
-    opts = ivp_amd.Options(method=wl["method"], rtol=wl["rtol"], atol=wl["atol"], fp_mode=fp, chunk_attempts=args.chunk, profile=1)
+    B = args.batch if args.workload == "c2" or args.batch != 100_000 else wl["B"]
     prob = getattr(ivp_amd, wl["problem"])()
     n_state = prob.n
     ctx = ivp_amd.Context(local_rank)
-    # Two result buffers: with N > 1 the RCCL all-gather of step i (C4: gather of sol.y over xGMI) is asynchronous and
-    # overlaps the integration of step i+1, which writes into the other buffer (ivp_amd.distributed.OverlappedGather).
-    from ivp_amd.distributed import OverlappedGather
-    outs = [None, None]
-    og = OverlappedGather((n_state, B), torch.float64, dev) if dist is not None else None
-    step_no = [0]
-    out = None
+    mk_opts = lambda profile: ivp_amd.Options(method=wl["method"], rtol=wl["rtol"], atol=wl["atol"], fp_mode=fp,
+                                              chunk_attempts=args.chunk, profile=profile)
 
-    def step():
-        nonlocal out
-        if og is not None:
-            k = og.slot()
-        else:
-            k = step_no[0] & 1
-            step_no[0] += 1
-        outs[k] = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, ctx, outs[k])
-        out = outs[k]
-        if og is not None:
-            og.launch(k, out.y_end)
-
-    def sync_all():
-        if og is not None:
-            og.drain()
+    def barrier_sync():
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    kern_ms = launches = attempts = slots = lane_launches = coop_ms = coop_launches = 0.0
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        st = out.stats
-        kern_ms += st["step_kernel_ms"]
-        launches += st["launches"]
-        slots += st["lane_attempt_slots"]
-        lane_launches += st["lane_launches"]
-        coop_ms += st["coop_kernel_ms"]
-        coop_launches += st["coop_launches"]
-    sync_all()
-    elapsed = time.perf_counter() - t_begin
+    def run_case(y0, p, t1, profile, with_gather, with_d2h=False):
+        """W warm-up + K timed steps of one shard on this rank (ivp_amd.distributed.run_steps: one step = one complete
+        solve of the shard, + the all-gather of its end-state arena when `with_gather`, overlapped with the next
+        step's integration and waited for inside the timed region).  Returns elapsed seconds (this rank), the last
+        result, with profile the accumulated launch statistics, and the gather object."""
+        m = y0.shape[1]
+        y0d, pd = torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev)
+        t1d = torch.as_tensor(t1, device=dev) if np.ndim(t1) else t1
+        opts = mk_opts(profile)
+        acc = dict(kern_ms=0.0, launches=0.0, slots=0.0, lane_launches=0.0, coop_ms=0.0, coop_launches=0.0)
 
-    acc = int(out.naccpt.sum().item())
-    attempts = float(out.nstep.sum().item()) * args.steps  # DOPRI5/DOP853/BDF: nstep counts every attempt (dopri5.rs:285)
+        def on_step(out):
+            if profile:
+                st = out.stats
+                acc["kern_ms"] += st["step_kernel_ms"]; acc["launches"] += st["launches"]; acc["slots"] += st["lane_attempt_slots"]
+                acc["lane_launches"] += st["lane_launches"]; acc["coop_ms"] += st["coop_kernel_ms"]; acc["coop_launches"] += st["coop_launches"]
+
+        el, out, og, _ = run_steps(lambda sol: ivp_amd.solve_ivp_batch(prob, 0.0, t1d, y0d, pd, opts, ctx, sol), n_state, m, dev,
+                                   args.steps, args.warmup, gather=with_gather, d2h=with_d2h, on_step=on_step)
+        return el, out, acc, og
+
+    def reduce_max_sum(elapsed, accepted):
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t_acc = torch.tensor([float(accepted)], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t_acc, op=dist.ReduceOp.SUM)
+        return float(t_el.item()), float(t_acc.item())
+
+    # ---- STRONG scaling (headline; BASELINE C4 as written): ONE batch of B trajectories, fixed permutation for
+    # N > 1, contiguous shards of B/N, one RCCL all-gather of the end-state arena per step inside the timed region ----
+    if B % world:
+        raise SystemExit(f"--batch {B} must be a multiple of --gpus {world} (equal shards: one all-gather of equal-sized arenas)")
+    y0, p, t0, t1 = getattr(W, wl["gen"])(B, seed=wl["seed"])
+    assert t0 == 0.0
+    lo, hi = shard_bounds(B, world, rank)
+    if world > 1:
+        idx = W.shard_permutation(B)[lo:hi]
+        sh = (np.ascontiguousarray(y0[:, idx]), np.ascontiguousarray(p[:, idx]), t1[idx] if np.ndim(t1) else t1)
+    else:
+        sh = (y0, p, t1)
+    el, out, _, og = run_case(*sh, profile=0, with_gather=dist is not None)
+    acc_rank = int(out.naccpt.sum().item())
     ok = bool((out.status == 0).all().item())
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    t_acc = torch.tensor([float(acc)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_acc, op=dist.ReduceOp.SUM)
-    elapsed = float(t_el.item())
-    total_acc_per_step = float(t_acc.item())
+    nstep_rank = float(out.nstep.sum().item())
+    nrej_rank = float(out.nrejct.sum().item())
+    elapsed, total_acc = reduce_max_sum(el, acc_rank)
+    gathered_ok = None
+    if og is not None:   # every rank now holds every shard's end state: check the gathered status words and counters
+        g = ResultArena(n_state, hi - lo, dev).split(og.gathered[(og.steps - 1) & 1], [hi - lo] * world)
+        gathered_ok = bool((g["status"] == 0).all().item()) and int(g["naccpt"].sum().item()) == int(total_acc)
+
+    # ---- instrumented pass (NOT the headline): per-launch HIP-event durations for the roofline objects ----
+    el_p, out_p, acc, _ = run_case(*sh, profile=1, with_gather=False)
+    # ---- results on the host: the same steps followed by a D2H copy of the end-state arena into pinned memory ----
+    el_h, _, _, _ = run_case(*sh, profile=0, with_gather=False, with_d2h=True)
+    el_h, _ = reduce_max_sum(el_h, 0)
+
+    # ---- WEAK scaling (secondary figure, N > 1): B trajectories PER RANK (a parameter sweep: rank r takes seed + r) ----
+    weak = None
+    if world > 1 and not args.no_weak:
+        yw, pw, _, t1w = getattr(W, wl["gen"])(B, seed=wl["seed"] + rank)
+        el_w, out_w, _, _ = run_case(yw, pw, t1w, profile=0, with_gather=True)
+        el_w, acc_w = reduce_max_sum(el_w, int(out_w.naccpt.sum().item()))
+        weak = {"scaling": "weak", "trajectories_per_gpu": B, "value": acc_w * args.steps / el_w, "unit": "steps/s",
+                "ms_per_step": el_w / args.steps * 1e3,
+                "note": "every rank integrates its own batch of the full size (seed + rank) and all-gathers its end-state arena"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = total_acc_per_step * args.steps / elapsed
+        value = total_acc * args.steps / elapsed
+        launches, kern_ms, coop_ms, coop_launches = acc["launches"], acc["kern_ms"], acc["coop_ms"], acc["coop_launches"]
+        attempts = nstep_rank * args.steps   # DOPRI5/DOP853/BDF: nstep counts every attempt (dopri5.rs:285)
         avg_launch_ms = kern_ms / max(launches, 1)
         attempts_per_launch = attempts / max(launches, 1)
-        lanes_per_launch = lane_launches / max(launches, 1)  # trajectories that load + store their state
+        lanes_per_launch = acc["lane_launches"] / max(launches, 1)  # trajectories that load + store their state
         flop_per_attempt = wl["flop_per_attempt"]
         bytes_per_launch = lanes_per_launch * bytes_per_lane_launch(n_state, prob.n_params, args.workload)
         gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         tflops = (attempts_per_launch * flop_per_attempt / (avg_launch_ms * 1e-3) / 1e12) if (avg_launch_ms > 0 and flop_per_attempt) else None
-        traffic = None
+        traffic = traffic_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes_per_launch.json")
-        if os.path.exists(pmc) and args.workload == "c2":
+        if os.path.exists(pmc) and args.workload == "c2" and world == 1 and B == 100_000:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                traffic = j.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_hbm_bytes_per_launch.json (" + str(j.get("run", "rocprofv3 --pmc passes of tools/profile_c2.sh")) + \
+                              "): PMC counters of a separate profiled run of this command, not of this process"
             except Exception:
                 traffic = None
         res = {
@@ -202,25 +229,32 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": wl["desc"],
-                "trajectories_per_gpu": B,
+                "workload": wl["desc"] + (f"; C4: sharded over {world} GPUs after the fixed permutation (seed 20260104), "
+                                           "RCCL all-gather of the end-state arena per step" if world > 1 else ""),
+                "trajectories_total": B,
+                "trajectories_per_gpu": hi - lo,
                 "fp_mode": args.fp,
-                "chunk_attempts": opts.chunk_attempts or 64,
-                "parallelism": f"dp{world} (independent shards" + (", RCCL all-gather of y_end per step)" if world > 1 else ")"),
+                "chunk_attempts": args.chunk or 64,
+                "parallelism": f"dp{world} (independent shards" + (", one RCCL all-gather of the end states per step)" if world > 1 else ")"),
             },
             "wall_ms_to_t_end": ms_per_step,
-            "accepted_steps_per_batch": total_acc_per_step,
+            "wall_ms_with_d2h": el_h / args.steps * 1e3,
+            "instrumented_ms_per_step": el_p / args.steps * 1e3,
+            "timing_note": "value / ms_per_step: options.profile = 0 (no per-launch events); roofline launch durations come "
+                           "from a separate instrumented pass of the same K steps (instrumented_ms_per_step, this rank)",
+            "accepted_steps_per_batch": total_acc,
             "all_success": ok,
-            "wave_lane_utilisation": attempts / slots if slots else None,
-            "attempts_per_s": attempts / elapsed * world, "rejection_ratio": float(out.nrejct.sum().item()) / max(float(out.nstep.sum().item()), 1.0),
+            "gathered_ok": gathered_ok,
+            "wave_lane_utilisation": attempts / acc["slots"] if acc["slots"] else None,
+            "attempts_per_s": attempts / el * 1.0, "rejection_ratio": nrej_rank / max(nstep_rank, 1.0),
             "roofline": {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": wl["kernel"], "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": launches / args.steps,
                 # per kernel name, for a one-to-one check against the rocprofv3 --kernel-trace --stats rows
@@ -239,13 +273,21 @@ def main():
                 "attempts_per_launch": attempts_per_launch,
             },
         }
-        if args.fp == "strict" and not args.no_fast and dist is None and args.workload == "c2":   # single process only (it synchronises)
-            res["fast_fp_mode"] = fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all)
-        if not args.no_fast and dist is None and args.workload == "c2":
-            res["pipelined"] = pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, opts.fp_mode, args)
+        if weak is not None:
+            res["weak"] = weak
+        if world > 1:
+            res["latency_floor_note"] = ("strong scaling of one C2 batch is bounded by its slowest trajectory: 702 sequential "
+                                         "step attempts (192 in the bulk kernel + 510 in the lane-cooperative tail kernel) "
+                                         "do not shrink with the shard -- see DESIGN.md section 7")
+        single = dist is None
+        y0d, pd = torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev)
+        if args.fp == "strict" and not args.no_fast and single and args.workload == "c2":   # single process only (it synchronises)
+            res["fast_fp_mode"] = fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, barrier_sync)
+        if not args.no_fast and single and args.workload == "c2":
+            res["pipelined"] = pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp, args)
         if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
-            res["accuracy"] = accuracy_vs_truth(ivp_amd, prob, opts, ctx, dev)
+            res["accuracy"] = accuracy_vs_truth(ivp_amd, prob, mk_opts(0), ctx, dev)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)
@@ -294,29 +336,59 @@ def pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp_mode, args, streams=4):
                     "ivp_batch_submit_device / ivp_batch_poll; every solve is complete and unshared"}
 
 
+def _time_oracle(O, y0, p, t0, t1, threads):
+    walls, r = [], None
+    for rep in range(6):   # one warm-up + five timed runs, median (the protocol of benches/benchmark.py:56-78)
+        t = time.perf_counter()
+        r = O.solve_batch("cr3bp", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=threads)
+        if rep:
+            walls.append(time.perf_counter() - t)
+    return float(np.median(walls)), r
+
+
+def reference_crate_timing():
+    """if the GPU node has a Rust toolchain, time the genuine `ivp` 0.5.1 crate.  The crate is
+    not vendored here (and /root/reference does not exist on the GPU box), so this needs cargo AND a local checkout
+    named by IVP_REFERENCE_CRATE; otherwise the branch reports why it was skipped."""
+    import shutil
+    cargo = shutil.which("cargo")
+    crate = os.environ.get("IVP_REFERENCE_CRATE")
+    if not cargo:
+        return {"available": False, "why": "cargo not found on this host (no Rust toolchain in the image)"}
+    if not crate or not os.path.isfile(os.path.join(crate, "Cargo.toml")):
+        return {"available": False, "why": "cargo present but IVP_REFERENCE_CRATE does not name a checkout of Ryan-D-Gast/ivp"}
+    import subprocess
+    try:
+        t = time.perf_counter()
+        subprocess.check_call([cargo, "run", "--release", "--example", "cr3bp"], cwd=crate, stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=600)
+        return {"available": True, "what": "cargo run --release --example cr3bp (one Arenstorf orbit incl. process start)",
+                "wall_s": time.perf_counter() - t}
+    except Exception as e:   # noqa: BLE001
+        return {"available": False, "why": f"cargo run failed: {e}"}
+
+
 def cpu_baseline(y0, p, t0, t1):
     """The CPU oracle (C restatement of the reference algorithm, libm pow, -ffp-contract=off) on this host's
-    cores: B back-to-back solve_ivp calls, OpenMP over trajectories.  Bounded to ~10-30 s of CPU work."""
+    cores: B back-to-back solve_ivp calls, OpenMP over trajectories.  Bounded to ~10-30 s of CPU work.
+    Headline: every core of this process's affinity mask (SURVEY.md section 8d "all host cores"; count stated);
+    the 16-thread figure (the GPU box's CPU share for one GPU) and the single-thread figure are reported beside it."""
     from oracle import oracle as O
     O.build()
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU
+    cores = max(1, cores)
     n1 = 4096
     t = time.perf_counter()
     r1 = O.solve_batch("cr3bp", y0[:, :n1], p[:, :n1], t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=1)
     dt1 = time.perf_counter() - t
     single = r1["total_accepted"] / dt1
     nall = y0.shape[1]
-    walls = []
-    for rep in range(6):   # one warm-up + five timed runs, median (the protocol of benches/benchmark.py:56-78)
-        t = time.perf_counter()
-        r = O.solve_batch("cr3bp", y0[:, :nall], p[:, :nall], t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=cores)
-        if rep:
-            walls.append(time.perf_counter() - t)
-    dt = float(np.median(walls))
+    dt, r = _time_oracle(O, y0, p, t0, t1, cores)
+    t16 = min(16, cores)
+    dt16 = dt if t16 == cores else _time_oracle(O, y0, p, t0, t1, t16)[0]
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -329,10 +401,13 @@ def cpu_baseline(y0, p, t0, t1):
     return {
         "value": r["total_accepted"] / dt, "unit": "steps/s", "cores": cores, "kind": "port",
         "sample": f"the same {nall} CR3BP trajectories, one solve_ivp call each, OpenMP over trajectories "
-                  f"({cores} threads, median of 5 runs after a warm-up: {dt:.2f} s wall); single thread on the first {n1}: {single:.3e} steps/s",
+                  f"({cores} threads = every core of the affinity mask, median of 5 runs after a warm-up: {dt:.2f} s wall); "
+                  f"{t16} threads: {r['total_accepted'] / dt16:.3e} steps/s; single thread on the first {n1}: {single:.3e} steps/s",
+        "threads16_value": r["total_accepted"] / dt16, "threads16": t16,
         "single_core_value": single, "cpu_model": model, "wall_s": dt,
         "attempts_per_s": float(r["nstep"].sum()) / dt, "rejection_ratio": rej,
         "what": "oracle/ivp_oracle.c: C restatement of the reference (Rust) algorithm; the crate cannot be built here",
+        "reference_crate": reference_crate_timing(),
     }
 
 

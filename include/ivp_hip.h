@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IVP_HIP_ABI_VERSION 2
+#define IVP_HIP_ABI_VERSION 3
 
 /* Method: same order as `enum Method`, src/solve/options.rs:14-27. The explicit RK methods (RK23, DOPRI5,
  * DOP853, the fixed-step RK4) and the variable-order implicit BDF are on the accelerated path; RADAU returns
@@ -148,8 +148,9 @@ typedef struct {
     uint32_t max_log;       /* capacity (per trajectory) of the accepted-step log t_log/y_log and of the
                                dense-segment log; 0 = do not record (end state only) */
     int32_t variant;        /* stepping-kernel variant: 0 = auto, 1 = lean registers, 2 = coefficients resident,
-                               3 = lane-cooperative (eight lanes per trajectory; DOPRI5 end-state runs of built-in
-                               problems, otherwise as 0).  Strict-mode results do not depend on the variant. */
+                               3 = lane-cooperative (eight lanes per trajectory: DOPRI5 / DOP853, every output mode,
+                               problems with events, built-in and hiprtc systems with n <= 8; otherwise as 0).
+                               Strict-mode results do not depend on the variant. */
     int32_t profile;        /* 1: time every kernel launch with HIP events (see ivp_run_stats_t);
                                2: additionally sum naccpt / attempts over the batch on the host */
     /* ---- direct per-method call: `DOPRI5 {..}.solve()`, `DOP853 {..}.solve()`, `RK23 {..}.solve()` ----
@@ -282,6 +283,45 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
                             void *hip_stream);
 int ivp_batch_poll(ivp_ctx_t *ctx, int *done);
 int ivp_batch_wait(ivp_ctx_t *ctx);
+
+/*
+ * One batch over several devices.  The reference has no parallelism (a batch is B back-to-back solve_ivp() calls,
+ * src/solve/solve_ivp.rs:99-313, with no coupling between them), so the batch shards by trajectory range: shard k is
+ * integrated by its own context on its own device with no communication, and the only data movement is the final
+ * gather of the result arrays.  ONE host thread drives all contexts through ivp_batch_submit_device / ivp_batch_poll.
+ *
+ * ivp_shard_t: trajectories [first, first + count) of a batch of B; every pointer is device memory on
+ * ctx's device with SoA stride `count` (component c of the shard's i-th trajectory at a[c*count + i]); `out` members
+ * may be NULL like in ivp_batch_solve_device.  count == 0 is allowed (the shard is skipped).
+ *
+ * ivp_batch_solve_multi: integrates all shards concurrently; when `gathered` is not NULL every member that is
+ * non-NULL both in `gathered` and in a shard's `out` is copied into `gathered` (device memory on `gather_device`,
+ * stride B) at column offset `first` -- same-device copies for shards that live on gather_device,
+ * hipMemcpyPeerAsync / peer-enabled 2-D copies (xGMI) otherwise -- and the call returns when everything has landed.
+ * Two contexts on ONE device are legal (the degenerate case the single-GPU tests run).
+ *
+ * ivp_batch_solve_multi_host: host-pointer convenience form (arguments as ivp_batch_solve): splits the batch into
+ * n_ctx contiguous balanced shards (the first B % n_ctx shards get one more), stages each to its context's device,
+ * integrates concurrently and writes the results back into the caller's host arrays.
+ */
+typedef struct {
+    ivp_ctx_t *ctx;
+    size_t first, count;
+    const double *y0;         /* [n][count]        */
+    const double *params;     /* [n_params][count] */
+    const double *t0;         /* [count] or [1]    */
+    size_t t0_len;
+    const double *t1;
+    size_t t1_len;
+    ivp_batch_result_t out;   /* stride count      */
+    void *hip_stream;         /* stream on ctx's device, NULL = its default stream */
+} ivp_shard_t;
+
+int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_problem_t *prob, size_t B,
+                          const ivp_options_t *opt, int32_t gather_device, ivp_batch_result_t *gathered);
+int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_problem_t *prob, size_t B,
+                               const double *y0, const double *params, const double *t0, size_t t0_len,
+                               const double *t1, size_t t1_len, const ivp_options_t *opt, ivp_batch_result_t *out);
 
 /*
  * User-defined right-hand side: the device-side `impl IVP for T { fn ode(..) }` (src/ivp.rs:29).

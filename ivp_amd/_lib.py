@@ -47,6 +47,13 @@ class BatchResultT(C.Structure):
         "seg_cont", "seg_xold", "seg_h", "n_seg", "t_events", "y_events", "n_event_hits", "t_term", "njev", "nlu")]
 
 
+class ShardT(C.Structure):
+    """ivp_shard_t: trajectories [first, first + count) of a batch, resident on ctx's device (SoA stride count)."""
+    _fields_ = [("ctx", C.c_void_p), ("first", C.c_size_t), ("count", C.c_size_t),
+                ("y0", C.c_void_p), ("params", C.c_void_p), ("t0", C.c_void_p), ("t0_len", C.c_size_t),
+                ("t1", C.c_void_p), ("t1_len", C.c_size_t), ("out", BatchResultT), ("hip_stream", C.c_void_p)]
+
+
 class RunStatsT(C.Structure):
     _fields_ = [
         ("launches", C.c_uint32), ("init_launches", C.c_uint32),
@@ -60,7 +67,8 @@ class RunStatsT(C.Structure):
 EXPORTS = (
     "ivp_abi_version", "ivp_device_count", "ivp_ctx_create", "ivp_ctx_destroy", "ivp_last_error_string",
     "ivp_ctx_get_stats", "ivp_options_default", "ivp_options_method_defaults", "ivp_rhs_dims", "ivp_rhs_n_events", "ivp_batch_solve",
-    "ivp_batch_solve_device", "ivp_batch_submit_device", "ivp_batch_poll", "ivp_batch_wait", "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_free",
+    "ivp_batch_solve_device", "ivp_batch_submit_device", "ivp_batch_poll", "ivp_batch_wait", "ivp_batch_solve_multi", "ivp_batch_solve_multi_host",
+    "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_free",
 )
 
 ERRORS = {
@@ -127,6 +135,11 @@ def load():
     L.ivp_batch_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.ivp_batch_wait.restype = C.c_int
     L.ivp_batch_wait.argtypes = [C.c_void_p]
+    L.ivp_batch_solve_multi.restype = C.c_int
+    L.ivp_batch_solve_multi.argtypes = [C.POINTER(ShardT), C.c_int32, C.POINTER(ProblemT), C.c_size_t, C.POINTER(OptionsT),
+                                        C.c_int32, C.POINTER(BatchResultT)]
+    L.ivp_batch_solve_multi_host.restype = C.c_int
+    L.ivp_batch_solve_multi_host.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + solve_args[1:]
     L.ivp_rhs_compile.restype = C.c_int
     L.ivp_rhs_compile.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.ivp_rhs_compile_events.restype = C.c_int

@@ -373,8 +373,11 @@ class Options:
         if self.t_eval is not None:
             te = np.ascontiguousarray(self.t_eval, dtype=np.float64)
             keep.append(te)
-            o.t_eval = te.ctypes.data_as(_lib.c_double_p) if te.size else C.cast(C.pointer(C.c_double(0.0)), _lib.c_double_p)
-            o.n_eval = te.size
+            if not te.size:   # Some(vec![]): a non-NULL pointer to a buffer that stays alive as long as the options struct
+                te = np.zeros(1)
+                keep.append(te)
+            o.t_eval = te.ctypes.data_as(_lib.c_double_p)
+            o.n_eval = len(self.t_eval)
         if self.first_step is not None:
             o.has_first_step, o.first_step = 1, float(self.first_step)
         if self.max_step is not None:
@@ -756,6 +759,30 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         y_end=xp_zeros((n, B), f64), t_end=xp_zeros((B,), f64), status=xp_zeros((B,), i32),
         nfev=xp_zeros((B,), u64), nstep=xp_zeros((B,), u64), naccpt=xp_zeros((B,), u64),
         nrejct=xp_zeros((B,), u64), h_next=xp_zeros((B,), f64))
+    if out is not None:
+        # a reused result set goes to the kernels as raw pointers: every buffer it carries must have the shape, dtype
+        # and placement this call needs (a BatchSolution from another batch size / option set would be written out of bounds)
+        nev_ = f.n_events()
+        rows_e = max(ne + (1 if nev_ else 0), 1)
+        mev_ = max(int(options.max_events), 1)
+        want = dict(y_end=((n, B), f64), t_end=((B,), f64), status=((B,), i32), nfev=((B,), u64), nstep=((B,), u64),
+                    naccpt=((B,), u64), nrejct=((B,), u64), h_next=((B,), f64), njev=((B,), u64), nlu=((B,), u64),
+                    y_eval=((rows_e, n, B), f64), eval_idx=((rows_e, B), i32), n_filled=((B,), i32),
+                    t_log=((ml, B), f64), y_log=((ml, n, B), f64), n_log=((B,), u32),
+                    seg_cont=((ml, nc, B), f64), seg_xold=((ml, B), f64), seg_h=((ml, B), f64), n_seg=((B,), u32),
+                    t_events=((nev_, mev_, B), f64), y_events=((nev_, mev_, n, B), f64), n_event_hits=((nev_, B), u32), t_term=((B,), f64))
+        for name, (shape, dt) in want.items():
+            v = getattr(out, name)
+            if v is None:
+                continue
+            if _is_torch(v) != on_device:
+                raise ValueError(f"out.{name}: {'device' if on_device else 'host'} array expected")
+            if tuple(v.shape) != tuple(shape) or v.dtype != dt:
+                raise ValueError(f"out.{name}: expected shape {tuple(shape)} dtype {dt}, got {tuple(v.shape)} {v.dtype}")
+            if on_device and (v.device != y0.device or not v.is_contiguous()):
+                raise ValueError(f"out.{name}: must be a contiguous tensor on {y0.device}")
+            if not on_device and not v.flags["C_CONTIGUOUS"]:
+                raise ValueError(f"out.{name}: must be C-contiguous")
     if res.njev is None:
         res.njev = xp_zeros((B,), u64)
         res.nlu = xp_zeros((B,), u64)

@@ -200,7 +200,23 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
 }
 
 // lanes (8 per trajectory) up to which the lane-cooperative kernels take over: two waves per SIMD
-constexpr size_t kCoopCapLanes = 2u * 256u * 4u * 64u;
+constexpr size_t kCoopCapLanesDefault = 2u * 256u * 4u * 64u;
+
+// Launch-policy knobs.  The defaults are the measured optimum for the BASELINE configs on MI355X; the environment
+// overrides exist for tuning runs (tools/tune_policy.py) and are read once per process.
+struct Tune {
+    size_t coop_cap_lanes = kCoopCapLanesDefault;
+    uint32_t bulk_chunk = 64;        // attempts per bulk launch
+    int launches_per_poll = 3;       // bulk launches between two host polls
+    Tune()
+    {
+        if (const char *e = getenv("IVP_TUNE_COOP_CAP_LANES")) coop_cap_lanes = (size_t)strtoull(e, nullptr, 10);
+        if (const char *e = getenv("IVP_TUNE_BULK_CHUNK")) bulk_chunk = (uint32_t)std::max(1l, strtol(e, nullptr, 10));
+        if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10)));
+    }
+};
+const Tune &tune() { static const Tune t; return t; }
+#define kCoopCapLanes (tune().coop_cap_lanes)
 
 hipEvent_t pend_event(ivp_ctx *ctx)
 {
@@ -240,7 +256,9 @@ int enqueue_round(ivp_ctx *ctx)
     uint32_t *counts = (uint32_t *)ctx->counts.p;
     const uint32_t lanes = P.lanes;
     const bool profile = P.profile != 0;
-    const bool tail = P.adaptive && (size_t)lanes * (P.group ? (P.jit ? (uint32_t)ivp_group_width(P.n) : (uint32_t)IVP_WAVE) : 1u) <= kOneWavePerSimd;
+    const bool fits_one_wave = (size_t)lanes * (P.group ? (P.jit ? (uint32_t)ivp_group_width(P.n) : (uint32_t)IVP_WAVE) : 1u) <= kOneWavePerSimd;
+    // problems whose stragglers may be handed to the lane-cooperative kernels by a speculative launch (see below)
+    const bool spec_ok = P.coop_ok && P.variant == 0 && P.adaptive && P.n >= 4 && P.fp_mode == IVP_FP_STRICT && !P.jit;
     // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
     // registers; auto = resident once at most two waves per SIMD are left to run
     // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;
@@ -256,9 +274,15 @@ int enqueue_round(ivp_ctx *ctx)
     const bool use_coop = P.coop_ok && (P.variant == 3 ||
                                         (P.variant == 0 && P.adaptive && P.n >= 4 &&
                                          (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) * 8u <= coop_cap));
+    // Long chunks (one launch per poll) once compaction cannot help any more: in the cooperative kernels, and for
+    // problems without a cooperative kernel when the active set fits one wave per SIMD.  A set that will still be
+    // handed to the cooperative kernels keeps short chunks + the speculative hand-over whatever its size: an attempt
+    // of a lone thread-per-trajectory wave costs 4.2 us against 1.9 us in the cooperative kernel, so every attempt a
+    // straggler spends in a 1024-attempt bulk launch is paid twice.
     // three short launches per poll: measured on C2 (attempts per trajectory peak at 160-200) the hand-over to the
     // cooperative kernel then happens after 192 instead of 256 attempts (3.33 -> 3.25 ms); more polls cost ~40 us each
-    const int launches_per_sync = tail ? 1 : 3;
+    const bool tail = P.adaptive && (use_coop || (fits_one_wave && !spec_ok));
+    const int launches_per_sync = tail ? 1 : tune().launches_per_poll;
     const uint32_t this_chunk = tail ? 1024u : P.chunk;
     for (int r = 0; r < launches_per_sync; ++r, ++P.c) {
         const uint64_t c = P.c;
@@ -287,7 +311,7 @@ int enqueue_round(ivp_ctx *ctx)
     // the largest set it may take; it does nothing unless the active count turned out small enough.  When it runs, the
     // poll between the bulk and the tail of a batch (~40 us of host round trip) disappears.
     P.spec = false;
-    if (!tail && !use_coop && P.coop_ok && P.variant == 0 && P.adaptive && P.n >= 4 && P.fp_mode == IVP_FP_STRICT && !P.jit) {
+    if (!tail && !use_coop && spec_ok) {
         const uint64_t c = P.c;
         IvpKArgs ka = P.a;
         ka.chunk = 1024u;
@@ -665,7 +689,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     // the loop switches to them for the latency-bound tail; fast mode only on request (variant 3).
     P.coop_ok = !group && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
     P.variant = (opt->variant == 3 && !P.coop_ok) ? 0 : opt->variant;
-    P.chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : 64u;
+    P.chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : tune().bulk_chunk;
     P.adaptive = opt->chunk_attempts == 0;
     P.B = B;
     P.lanes = (uint32_t)B;
@@ -735,75 +759,239 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
                     const double *t0, size_t t0_len, const double *t1, size_t t1_len, const ivp_options_t *opt,
                     ivp_batch_result_t *out)
 {
-    if (!ctx) return IVP_ERR_BAD_ARGUMENT;
-    ctx->err.clear();
-    int n = 0, np = 0;
-    int rc = validate(ctx, prob, B, opt, &n, &np);
-    if (rc != IVP_OK) return rc;
-    if (!y0 || !t0 || !t1 || !out) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "null y0/t0/t1/out");
-    if (np > 0 && !params) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
-    if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ivp_ctx_t *one[1] = {ctx};
+    return ivp_batch_solve_multi_host(one, 1, prob, B, y0, params, t0, t0_len, t1, t1_len, opt, out);
+}
 
+}  // extern "C"
+
+namespace {
+
+// Every member of ivp_batch_result_t as (offset, element size, rows): a member is `rows` SoA rows of B elements.
+struct MemberDesc { size_t off, elem, rows; };
+struct ResultShape { size_t n, ne_rows, ml, nc, nev, mev; };
+ResultShape result_shape(const ivp_problem_t *prob, const ivp_options_t *opt, int n)
+{
+    ResultShape r;
+    r.n = (size_t)n;
+    r.nev = prob->rhs_id == IVP_RHS_JIT ? (size_t)ivp_jit_n_events(prob->jit) : n > IVP_MAX_N ? 0 : (size_t)kRhsEvents[prob->rhs_id];
     const size_t ne = opt->t_eval ? (size_t)opt->n_eval : 0;
-    const size_t ml = opt->max_log;
-    const size_t nc = (size_t)ncoef_of(opt->method) * n;
-
-    HIP_TRY(ctx, ctx->st_y0.reserve(sizeof(double) * n * B));
-    HIP_TRY(ctx, ctx->st_params.reserve(sizeof(double) * std::max(np, 1) * B));
-    HIP_TRY(ctx, ctx->st_t0.reserve(sizeof(double) * t0_len));
-    HIP_TRY(ctx, ctx->st_t1.reserve(sizeof(double) * t1_len));
-    HIP_TRY(ctx, hipMemcpy(ctx->st_y0.p, y0, sizeof(double) * n * B, hipMemcpyHostToDevice));
-    if (np > 0) HIP_TRY(ctx, hipMemcpy(ctx->st_params.p, params, sizeof(double) * np * B, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->st_t0.p, t0, sizeof(double) * t0_len, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->st_t1.p, t1, sizeof(double) * t1_len, hipMemcpyHostToDevice));
-
-    // device mirrors of every requested output
-    struct Slot { void *host; size_t bytes; void **dev; };
-    ivp_batch_result_t d;
-    std::memset(&d, 0, sizeof d);
-    const size_t nev = prob->rhs_id == IVP_RHS_JIT ? (size_t)ivp_jit_n_events(prob->jit)
-                     : n > IVP_MAX_N ? 0 : (size_t)kRhsEvents[prob->rhs_id];
-    const size_t mev = opt->max_events;
-    const size_t ne_rows = opt->t_eval ? ne + (nev > 0 ? 1 : 0) : 0;   // a terminal event appends one more sample
-    Slot slots[24] = {
-        {out->y_end, sizeof(double) * n * B, (void **)&d.y_end},
-        {out->t_end, sizeof(double) * B, (void **)&d.t_end},
-        {out->status, sizeof(int32_t) * B, (void **)&d.status},
-        {out->nfev, sizeof(uint64_t) * B, (void **)&d.nfev},
-        {out->nstep, sizeof(uint64_t) * B, (void **)&d.nstep},
-        {out->naccpt, sizeof(uint64_t) * B, (void **)&d.naccpt},
-        {out->nrejct, sizeof(uint64_t) * B, (void **)&d.nrejct},
-        {out->h_next, sizeof(double) * B, (void **)&d.h_next},
-        {out->y_eval, sizeof(double) * ne_rows * n * B, (void **)&d.y_eval},
-        {out->eval_idx, sizeof(int32_t) * ne_rows * B, (void **)&d.eval_idx},
-        {out->n_filled, sizeof(int32_t) * B, (void **)&d.n_filled},
-        {out->t_log, sizeof(double) * ml * B, (void **)&d.t_log},
-        {out->y_log, sizeof(double) * ml * n * B, (void **)&d.y_log},
-        {out->n_log, sizeof(uint32_t) * B, (void **)&d.n_log},
-        {out->seg_cont, sizeof(double) * ml * nc * B, (void **)&d.seg_cont},
-        {out->seg_xold, sizeof(double) * ml * B, (void **)&d.seg_xold},
-        {out->seg_h, sizeof(double) * ml * B, (void **)&d.seg_h},
-        {out->n_seg, sizeof(uint32_t) * B, (void **)&d.n_seg},
-        {out->njev, sizeof(uint64_t) * B, (void **)&d.njev},
-        {out->nlu, sizeof(uint64_t) * B, (void **)&d.nlu},
-        {out->t_events, sizeof(double) * nev * mev * B, (void **)&d.t_events},
-        {out->y_events, sizeof(double) * nev * mev * n * B, (void **)&d.y_events},
-        {out->n_event_hits, sizeof(uint32_t) * nev * B, (void **)&d.n_event_hits},
-        {out->t_term, sizeof(double) * B, (void **)&d.t_term},
+    r.ne_rows = opt->t_eval ? ne + (r.nev > 0 ? 1 : 0) : 0;   // a terminal event appends one more sample
+    r.ml = opt->max_log;
+    r.nc = (size_t)ncoef_of(opt->method) * n;
+    r.mev = opt->max_events;
+    return r;
+}
+constexpr int kMembers = 24;
+void member_table(const ResultShape &r, MemberDesc (&m)[kMembers])
+{
+#define M(field, elem, rows) MemberDesc{offsetof(ivp_batch_result_t, field), (size_t)(elem), (size_t)(rows)}
+    const MemberDesc t[kMembers] = {
+        M(y_end, 8, r.n), M(t_end, 8, 1), M(status, 4, 1), M(nfev, 8, 1), M(nstep, 8, 1), M(naccpt, 8, 1), M(nrejct, 8, 1), M(h_next, 8, 1),
+        M(y_eval, 8, r.ne_rows * r.n), M(eval_idx, 4, r.ne_rows), M(n_filled, 4, 1),
+        M(t_log, 8, r.ml), M(y_log, 8, r.ml * r.n), M(n_log, 4, 1),
+        M(seg_cont, 8, r.ml * r.nc), M(seg_xold, 8, r.ml), M(seg_h, 8, r.ml), M(n_seg, 4, 1),
+        M(njev, 8, 1), M(nlu, 8, 1),
+        M(t_events, 8, r.nev * r.mev), M(y_events, 8, r.nev * r.mev * r.n), M(n_event_hits, 4, r.nev), M(t_term, 8, 1),
     };
-    for (int i = 0; i < 24; ++i) {
-        if (slots[i].host && slots[i].bytes) {
-            HIP_TRY(ctx, ctx->st_out[i].reserve(slots[i].bytes));
-            *slots[i].dev = ctx->st_out[i].p;
+#undef M
+    for (int i = 0; i < kMembers; ++i) m[i] = t[i];
+}
+inline void *&member(ivp_batch_result_t *r, const MemberDesc &d) { return *(void **)((char *)r + d.off); }
+inline void *member(const ivp_batch_result_t *r, const MemberDesc &d) { return *(void *const *)((const char *)r + d.off); }
+
+// rows x (count elements) between two SoA arrays of different stride
+hipError_t copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t elem, size_t count, size_t rows,
+                     hipMemcpyKind kind, hipStream_t s)
+{
+    if (!rows || !count) return hipSuccess;
+    if (dst_stride == count && src_stride == count) return hipMemcpyAsync(dst, src, elem * count * rows, kind, s);
+    return hipMemcpy2DAsync(dst, dst_stride * elem, src, src_stride * elem, count * elem, rows, kind, s);
+}
+
+// device -> device, possibly across devices: peer-enabled 2-D copy (xGMI) when the runtime allows it, else one
+// hipMemcpyPeerAsync per row
+hipError_t copy_rows_peer(void *dst, int dst_dev, size_t dst_stride, const void *src, int src_dev, size_t src_stride, size_t elem,
+                          size_t count, size_t rows, hipStream_t s)
+{
+    if (!rows || !count) return hipSuccess;
+    if (dst_dev == src_dev) return copy_rows(dst, dst_stride, src, src_stride, elem, count, rows, hipMemcpyDeviceToDevice, s);
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, src_dev, dst_dev) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(dst_dev, 0);   // current device = src_dev (the caller set it)
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) {
+            (void)hipGetLastError();
+            return copy_rows(dst, dst_stride, src, src_stride, elem, count, rows, hipMemcpyDeviceToDevice, s);
+        }
+        (void)hipGetLastError();
+    }
+    for (size_t r = 0; r < rows; ++r) {
+        const hipError_t e = hipMemcpyPeerAsync((char *)dst + r * dst_stride * elem, dst_dev, (const char *)src + r * src_stride * elem, src_dev,
+                                                count * elem, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// drive every submitted shard to completion from this thread; on an error the other solves are still drained
+int drive_all(ivp_ctx_t *const *ctxs, const char *live, int n)
+{
+    std::vector<char> done(n, 0);
+    int rc_first = IVP_OK, pending = 0;
+    for (int i = 0; i < n; ++i) { done[i] = live[i] ? 0 : 1; pending += live[i] ? 1 : 0; }
+    while (pending) {
+        for (int i = 0; i < n; ++i) {
+            if (done[i]) continue;
+            int d = 0;
+            const int rc = ivp_batch_poll(ctxs[i], &d);
+            if (rc != IVP_OK) { if (rc_first == IVP_OK) rc_first = rc; d = 1; }
+            if (d) { done[i] = 1; --pending; }
         }
     }
-    rc = ivp_batch_solve_device(ctx, prob, B, (const double *)ctx->st_y0.p, np > 0 ? (const double *)ctx->st_params.p : nullptr,
-                                (const double *)ctx->st_t0.p, t0_len, (const double *)ctx->st_t1.p, t1_len, opt, &d, nullptr);
+    return rc_first;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_problem_t *prob, size_t B, const ivp_options_t *opt,
+                          int32_t gather_device, ivp_batch_result_t *gathered)
+{
+    if (!shards || n_shards <= 0 || n_shards > 64) return IVP_ERR_BAD_ARGUMENT;
+    ivp_ctx_t *c0 = nullptr;
+    for (int i = 0; i < n_shards; ++i) {
+        if (!shards[i].ctx) return IVP_ERR_BAD_ARGUMENT;
+        if (!c0) c0 = shards[i].ctx;
+        for (int k = 0; k < i; ++k)
+            if (shards[k].ctx == shards[i].ctx) return fail(c0, IVP_ERR_BAD_ARGUMENT, "shards %d and %d share one context", k, i);
+        if (shards[i].first > B || shards[i].count > B - shards[i].first)
+            return fail(c0, IVP_ERR_BAD_ARGUMENT, "shard %d: [%zu, %zu) is outside the batch of %zu", i, shards[i].first, shards[i].first + shards[i].count, B);
+    }
+    if (gathered) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || gather_device < 0 || gather_device >= ndev)
+            return fail(c0, IVP_ERR_BAD_ARGUMENT, "gather_device %d", gather_device);
+    }
+    std::vector<ivp_ctx_t *> ctxs(n_shards);
+    std::vector<char> live(n_shards, 0);
+    int rc = IVP_OK;
+    for (int i = 0; i < n_shards && rc == IVP_OK; ++i) {
+        ivp_shard_t &sh = shards[i];
+        ctxs[i] = sh.ctx;
+        if (sh.count == 0) continue;
+        rc = ivp_batch_submit_device(sh.ctx, prob, sh.count, sh.y0, sh.params, sh.t0, sh.t0_len, sh.t1, sh.t1_len, opt, &sh.out, sh.hip_stream);
+        if (rc == IVP_OK) live[i] = 1;
+        else if (sh.ctx != c0) c0->err = sh.ctx->err;   // the caller reads the first context's message
+    }
+    const int rc_drive = drive_all(ctxs.data(), live.data(), n_shards);
+    if (rc == IVP_OK && rc_drive != IVP_OK) {
+        rc = rc_drive;
+        for (int i = 0; i < n_shards; ++i) if (live[i] && !shards[i].ctx->err.empty() && shards[i].ctx != c0) { c0->err = shards[i].ctx->err; break; }
+    }
+    if (rc != IVP_OK || !gathered) return rc;
+
+    // ---- gather: shard columns into the batch-wide arrays on gather_device ----
+    int n = 0, np = 0;
+    rc = validate(c0, prob, B ? B : 1, opt, &n, &np);
     if (rc != IVP_OK) return rc;
-    for (int i = 0; i < 24; ++i)
-        if (slots[i].host && slots[i].bytes)
-            HIP_TRY(ctx, hipMemcpy(slots[i].host, *slots[i].dev, slots[i].bytes, hipMemcpyDeviceToHost));
+    MemberDesc md[kMembers];
+    member_table(result_shape(prob, opt, n), md);
+    for (int i = 0; i < n_shards; ++i) {
+        ivp_shard_t &sh = shards[i];
+        if (sh.count == 0) continue;
+        HIP_TRY(c0, hipSetDevice(sh.ctx->device));
+        hipStream_t s = (hipStream_t)sh.hip_stream;
+        for (int k = 0; k < kMembers; ++k) {
+            void *dst = member(gathered, md[k]);
+            const void *src = member(&sh.out, md[k]);
+            if (!dst || !src) continue;
+            HIP_TRY(c0, copy_rows_peer((char *)dst + sh.first * md[k].elem, gather_device, B, src, sh.ctx->device, sh.count, md[k].elem, sh.count, md[k].rows, s));
+        }
+    }
+    for (int i = 0; i < n_shards; ++i) {
+        if (shards[i].count == 0) continue;
+        HIP_TRY(c0, hipSetDevice(shards[i].ctx->device));
+        HIP_TRY(c0, hipStreamSynchronize((hipStream_t)shards[i].hip_stream));
+    }
+    return IVP_OK;
+}
+
+int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_problem_t *prob, size_t B, const double *y0,
+                               const double *params, const double *t0, size_t t0_len, const double *t1, size_t t1_len,
+                               const ivp_options_t *opt, ivp_batch_result_t *out)
+{
+    if (!ctxs || n_ctx <= 0 || n_ctx > 64 || !ctxs[0]) return IVP_ERR_BAD_ARGUMENT;
+    ivp_ctx_t *c0 = ctxs[0];
+    for (int i = 0; i < n_ctx; ++i) {
+        if (!ctxs[i]) return IVP_ERR_BAD_ARGUMENT;
+        for (int k = 0; k < i; ++k) if (ctxs[k] == ctxs[i]) return fail(c0, IVP_ERR_BAD_ARGUMENT, "contexts %d and %d are the same", k, i);
+    }
+    c0->err.clear();
+    int n = 0, np = 0;
+    int rc = validate(c0, prob, B, opt, &n, &np);
+    if (rc != IVP_OK) return rc;
+    if (!y0 || !t0 || !t1 || !out) return fail(c0, IVP_ERR_BAD_ARGUMENT, "null y0/t0/t1/out");
+    if (np > 0 && !params) return fail(c0, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
+    if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
+    MemberDesc md[kMembers];
+    member_table(result_shape(prob, opt, n), md);
+
+    // contiguous balanced shards: the first B % n_ctx get one more trajectory
+    std::vector<ivp_shard_t> sh(n_ctx);
+    const size_t base = B / (size_t)n_ctx, extra = B % (size_t)n_ctx;
+    size_t first = 0;
+    for (int i = 0; i < n_ctx; ++i) {
+        ivp_ctx *ctx = ctxs[i];
+        ivp_shard_t &S = sh[i];
+        std::memset(&S, 0, sizeof S);
+        S.ctx = ctx;
+        S.first = first;
+        S.count = base + ((size_t)i < extra ? 1 : 0);
+        first += S.count;
+        if (S.count == 0) continue;
+        HIP_TRY(c0, hipSetDevice(ctx->device));
+        const size_t m = S.count;
+        const size_t l0 = t0_len == 1 ? 1 : m, l1 = t1_len == 1 ? 1 : m;
+        HIP_TRY(c0, ctx->st_y0.reserve(sizeof(double) * n * m));
+        HIP_TRY(c0, ctx->st_params.reserve(sizeof(double) * std::max(np, 1) * m));
+        HIP_TRY(c0, ctx->st_t0.reserve(sizeof(double) * l0));
+        HIP_TRY(c0, ctx->st_t1.reserve(sizeof(double) * l1));
+        // pageable host memory: these copies are staged by the runtime and return once the source has been read
+        HIP_TRY(c0, copy_rows(ctx->st_y0.p, m, y0 + S.first, B, 8, m, (size_t)n, hipMemcpyHostToDevice, nullptr));
+        if (np > 0) HIP_TRY(c0, copy_rows(ctx->st_params.p, m, params + S.first, B, 8, m, (size_t)np, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(c0, hipMemcpyAsync(ctx->st_t0.p, t0 + (t0_len == 1 ? 0 : S.first), sizeof(double) * l0, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(c0, hipMemcpyAsync(ctx->st_t1.p, t1 + (t1_len == 1 ? 0 : S.first), sizeof(double) * l1, hipMemcpyHostToDevice, nullptr));
+        S.y0 = (const double *)ctx->st_y0.p;
+        S.params = np > 0 ? (const double *)ctx->st_params.p : nullptr;
+        S.t0 = (const double *)ctx->st_t0.p; S.t0_len = l0;
+        S.t1 = (const double *)ctx->st_t1.p; S.t1_len = l1;
+        for (int k = 0; k < kMembers; ++k) {   // device mirrors of every requested output
+            const size_t bytes = md[k].elem * md[k].rows * m;
+            if (member(out, md[k]) && bytes) {
+                HIP_TRY(c0, ctx->st_out[k].reserve(bytes));
+                member(&S.out, md[k]) = ctx->st_out[k].p;
+            }
+        }
+    }
+    rc = ivp_batch_solve_multi(sh.data(), n_ctx, prob, B, opt, 0, nullptr);
+    if (rc != IVP_OK) return rc;
+    for (int i = 0; i < n_ctx; ++i) {
+        ivp_shard_t &S = sh[i];
+        if (S.count == 0) continue;
+        HIP_TRY(c0, hipSetDevice(S.ctx->device));
+        for (int k = 0; k < kMembers; ++k) {
+            void *host = member(out, md[k]);
+            const void *dev = member(&S.out, md[k]);
+            if (host && dev)
+                HIP_TRY(c0, copy_rows((char *)host + S.first * md[k].elem, B, dev, S.count, md[k].elem, S.count, md[k].rows, hipMemcpyDeviceToHost, nullptr));
+        }
+    }
+    for (int i = 0; i < n_ctx; ++i) {
+        if (sh[i].count == 0) continue;
+        HIP_TRY(c0, hipSetDevice(sh[i].ctx->device));
+        HIP_TRY(c0, hipStreamSynchronize(nullptr));
+    }
     return IVP_OK;
 }
 

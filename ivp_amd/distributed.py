@@ -1,25 +1,39 @@
-"""Multi-GPU driver: one process per GPU, trajectories sharded across ranks, ONE gather at the end.
+"""Multi-GPU drivers: trajectories sharded across GPUs, ONE gather at the end.
 
 The reference has no parallelism of any kind; a "batch" there is B back-to-back solve_ivp()
-calls.  Trajectories are independent, so the batch shards trivially: after a fixed permutation (which
-equalises step-count skew, BASELINE config C4) rank r owns the contiguous slice [lo_r, hi_r) and runs the
-stepping kernels on its own GPU with no communication at all.  The only collective is the final
-all-gather of the end states / statistics (RCCL over xGMI when the backend is "nccl"; at C4 sizes it is a
-600 kB-per-rank, latency-bound message, so one fused all-gather of a packed buffer beats several small ones).
+calls (src/solve/solve_ivp.rs:99-313) with no coupling between them.  The batch therefore shards trivially: after a
+fixed permutation (which equalises step-count skew, BASELINE config C4) shard r is the contiguous slice
+[lo_r, hi_r) and is integrated by its own GPU with no communication at all.  The only data movement is the final
+gather of the end states / statistics.
 
-`solve_fn` is the per-shard integrator; it defaults to the HIP path (`ivp_amd.solve_ivp_batch`).  The CPU
+Two drivers, the same partitioning:
+
+* ``solve_ivp_sharded``  one PROCESS per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI, "gloo" in the
+  CPU tests).  Every rank's result arrays are views into ONE contiguous byte arena (``ResultArena``): the kernels write
+  their results straight into it and the gather is a single ``all_gather_into_tensor`` of raw bytes -- no packing
+  kernels, no dtype punning, no host bounce.  At C4 sizes (100k trajectories over 8 GPUs) the arena is 1.2 MB per
+  rank, i.e. a latency-bound message, which is why it is ONE collective.
+* ``solve_ivp_batch_multi``  one process, one host THREAD, N contexts (``ivp_batch_solve_multi`` in the C ABI): the
+  shards are driven through the resumable submit/poll entry points and gathered with peer copies
+  (``hipMemcpyPeerAsync`` / peer-enabled 2-D copies over xGMI).  Both gathers move the same bytes
+  (tests/test_gpu_multi.py compares them).
+
+``solve_fn`` is the per-shard integrator; it defaults to the HIP path (``ivp_amd.solve_ivp_batch``).  The CPU
 test-suite injects the oracle there to exercise the sharding + gather logic under gloo without a GPU.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+import ctypes as C
+from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
-from . import api
+from . import _lib, api
 
-FIELDS_F64 = ("t_end", "h_next")
-FIELDS_INT = ("status", "nfev", "nstep", "naccpt", "nrejct")
+# end-state members of a shard's result, in arena order: (name, numpy dtype, rows per trajectory or None = n)
+ARENA_FIELDS = (("y_end", np.float64, None), ("t_end", np.float64, 1), ("h_next", np.float64, 1),
+                ("nfev", np.int64, 1), ("nstep", np.int64, 1), ("naccpt", np.int64, 1), ("nrejct", np.int64, 1),
+                ("status", np.int32, 1))
 
 
 def shard_bounds(B: int, world: int, rank: int):
@@ -30,12 +44,98 @@ def shard_bounds(B: int, world: int, rank: int):
     return lo, hi
 
 
+class ResultArena:
+    """End-state result arrays of ONE shard (capacity ``m`` trajectories, state dimension ``n``) as views into one
+    contiguous byte buffer.  ``solution()`` hands the views to ``solve_ivp_batch(out=...)`` so the kernels write into
+    the arena; ``split(gathered, counts)`` turns the gathered ``[world, nbytes]`` buffer back into arrays."""
+
+    def __init__(self, n: int, m: int, device):
+        import torch
+        self.n, self.m = int(n), int(m)
+        self.layout = []   # (name, torch dtype, rows, byte offset)
+        off = 0
+        tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}
+        for name, dt, rows in ARENA_FIELDS:
+            rows = self.n if rows is None else rows
+            self.layout.append((name, tdt[dt], rows, off))
+            off += np.dtype(dt).itemsize * rows * self.m
+            off = (off + 255) & ~255       # every member starts on a 256-byte boundary
+        self.nbytes = off
+        self.buf = torch.zeros(max(self.nbytes, 256), dtype=torch.uint8, device=device)
+        self.views = self.views_of(self.buf)
+
+    def views_of(self, buf) -> dict:
+        """Typed views of a byte buffer with this arena's layout (``buf``: 1-D uint8, at least ``nbytes`` long)."""
+        out = {}
+        for name, tdt, rows, off in self.layout:
+            nb = tdt.itemsize * rows * self.m
+            v = buf[off:off + nb].view(tdt)
+            out[name] = v.view(rows, self.m) if rows > 1 or name == "y_end" else v
+        return out
+
+    def solution(self, count: Optional[int] = None) -> api.BatchSolution:
+        """A BatchSolution whose members are the arena's views.  Only a full arena (count == m) can be written in
+        place: a shard with fewer trajectories has a different SoA stride and goes through ``store``."""
+        assert count is None or count == self.m
+        v = self.views
+        return api.BatchSolution(y_end=v["y_end"], t_end=v["t_end"], status=v["status"], nfev=v["nfev"], nstep=v["nstep"],
+                                 naccpt=v["naccpt"], nrejct=v["nrejct"], h_next=v["h_next"])
+
+    def store(self, shard: dict, count: int) -> None:
+        """Copy a shard result (``count`` <= m trajectories; tensors or numpy arrays) into the arena's first columns."""
+        import torch
+        for name, tdt, rows, _ in self.layout:
+            src = shard[name]
+            t = src if api._is_torch(src) else torch.as_tensor(np.ascontiguousarray(src))
+            t = t.to(device=self.buf.device, dtype=tdt)
+            self.views[name][..., :count] = t.reshape(self.views[name][..., :count].shape)
+
+    def split(self, gathered, counts: Sequence[int]) -> dict:
+        """``gathered``: ``[world, nbytes]`` uint8.  Returns name -> array with the shards' columns concatenated in
+        rank order (``sum(counts)`` columns)."""
+        import torch
+        parts = {name: [] for name, *_ in self.layout}
+        for r, cnt in enumerate(counts):
+            v = self.views_of(gathered[r])
+            for name in parts:
+                parts[name].append(v[name][..., :cnt])
+        return {name: torch.cat(p, dim=-1) for name, p in parts.items()}
+
+
+def _as_numpy(d: dict) -> dict:
+    out = {}
+    for k, v in d.items():
+        a = v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+        if k in ("nfev", "nstep", "naccpt", "nrejct"):
+            a = a.astype(np.uint64)
+        out[k] = a
+    return out
+
+
+def _unpermute(out: dict, perm, B: int) -> dict:
+    """Shard position q holds trajectory perm[q]; scatter back to original order (numpy or torch arrays)."""
+    res = {}
+    for k, v in out.items():
+        if api._is_torch(v):
+            import torch
+            r = torch.empty_like(v)
+            r.index_copy_(v.dim() - 1, torch.as_tensor(np.asarray(perm), device=v.device, dtype=torch.int64), v)
+        else:
+            v = np.asarray(v)
+            r = np.empty_like(v)
+            r[..., np.asarray(perm)] = v
+        res[k] = r
+    return res
+
+
 def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.ndarray], options: api.Options,
                       *, permutation: Optional[np.ndarray] = None, group=None, device=None,
-                      solve_fn: Optional[Callable] = None, gather: bool = True) -> dict:
+                      solve_fn: Optional[Callable] = None, gather: bool = True, as_numpy: bool = True) -> dict:
     """Integrate a batch held (replicated) as host arrays on every rank; returns the gathered result on every
-    rank as numpy arrays in the ORIGINAL trajectory order: y_end[n,B], t_end, h_next, status, nfev, nstep,
-    naccpt, nrejct.  With ``gather=False`` only this rank's shard is returned (plus its index list)."""
+    rank in the ORIGINAL trajectory order: y_end[n,B], t_end, h_next, status, nfev, nstep, naccpt, nrejct
+    (numpy arrays, or tensors on the gather device with ``as_numpy=False``).  With ``gather=False`` only this rank's
+    shard is returned (plus its index list).  A rank whose shard is empty (world > B) still takes part in the
+    collective."""
     import torch
     import torch.distributed as dist
 
@@ -45,6 +145,7 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
     n, B = y0.shape
     perm = np.arange(B) if permutation is None else np.asarray(permutation)
     lo, hi = shard_bounds(B, world, rank)
+    m = hi - lo
     idx = perm[lo:hi]
     t0a = np.atleast_1d(np.asarray(t0, dtype=np.float64))
     t1a = np.atleast_1d(np.asarray(t1, dtype=np.float64))
@@ -54,79 +155,130 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
     sh_p = None if params is None else np.ascontiguousarray(np.asarray(params, dtype=np.float64)[:, idx])
 
     backend = dist.get_backend(group) if dist.is_initialized() else None
-    use_cuda = backend == "nccl"   # the packed gather buffer follows the backend (RCCL: device memory; gloo: host memory)
+    use_cuda = backend == "nccl" or (solve_fn is None and backend is None)   # arena follows the backend (RCCL: device; gloo: host)
     if solve_fn is None:
         dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        r = api.solve_ivp_batch(f, torch.as_tensor(sh_t0, device=dev) if sh_t0.size > 1 else float(sh_t0[0]),
-                                torch.as_tensor(sh_t1, device=dev) if sh_t1.size > 1 else float(sh_t1[0]),
-                                torch.as_tensor(sh_y0, device=dev),
-                                None if sh_p is None else torch.as_tensor(sh_p, device=dev), options)
-        shard = {k: getattr(r, k) for k in ("y_end",) + FIELDS_F64 + FIELDS_INT}
     else:
-        shard = solve_fn(f, sh_t0, sh_t1, sh_y0, sh_p, options)
+        dev = torch.device("cpu")
+    tdev = dev if use_cuda else torch.device("cpu")
+    m_max = shard_bounds(B, world, 0)[1] - shard_bounds(B, world, 0)[0]
+    arena = ResultArena(n, m_max, tdev)
+
+    if m > 0:
+        if solve_fn is None:
+            in_place = m == m_max and use_cuda and tdev == dev   # the kernels write straight into the arena
+            r = api.solve_ivp_batch(f, torch.as_tensor(sh_t0, device=dev) if sh_t0.size > 1 else float(sh_t0[0]),
+                                    torch.as_tensor(sh_t1, device=dev) if sh_t1.size > 1 else float(sh_t1[0]),
+                                    torch.as_tensor(sh_y0, device=dev),
+                                    None if sh_p is None else torch.as_tensor(sh_p, device=dev), options,
+                                    out=arena.solution() if in_place else None)
+            if not in_place:
+                arena.store({k: getattr(r, k) for k, *_ in ARENA_FIELDS}, m)
+        else:
+            arena.store(solve_fn(f, sh_t0, sh_t1, sh_y0, sh_p, options), m)
     if not gather or world == 1:
-        out = {k: (v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)) for k, v in shard.items()}
+        out = {k: v[..., :m] for k, v in arena.views.items()}
         if world == 1:
-            return _unpermute(out, perm, n, B)
+            out = _unpermute(out, perm, B)
+            return _as_numpy(out) if as_numpy else out
+        out = _as_numpy(out) if as_numpy else out
         out["index"] = idx
         return out
 
-    # pack everything into one f64 buffer [n + 2 + 5, max_shard] so that a single collective moves it
-    max_sh = shard_bounds(B, world, 0)[1] - shard_bounds(B, world, 0)[0]
-    rows = n + len(FIELDS_F64) + len(FIELDS_INT)
-    tdev = torch.device(f"cuda:{torch.cuda.current_device()}") if use_cuda else torch.device("cpu")
-    pack = torch.zeros((rows, max_sh), dtype=torch.float64, device=tdev)
-    m = hi - lo
-
-    def as_t(v):
-        t = v if hasattr(v, "device") and not isinstance(v, np.ndarray) else torch.as_tensor(np.ascontiguousarray(v))
-        return t.to(tdev)
-
-    pack[:n, :m] = as_t(shard["y_end"])
-    row = n
-    for k in FIELDS_F64:
-        pack[row, :m] = as_t(shard[k])
-        row += 1
-    for k in FIELDS_INT:
-        # counters are exact in f64 up to 2^53 steps; status is a small enum
-        pack[row, :m] = as_t(shard[k]).to(torch.float64)
-        row += 1
-    parts = [torch.empty_like(pack) for _ in range(world)]
-    dist.all_gather(parts, pack, group=group)
-    allp = torch.stack(parts).cpu().numpy()
-
-    out = {"y_end": np.empty((n, B)), **{k: np.empty(B) for k in FIELDS_F64},
-           "status": np.empty(B, dtype=np.int32), **{k: np.empty(B, dtype=np.uint64) for k in FIELDS_INT[1:]}}
-    for r_ in range(world):
-        a, b = shard_bounds(B, world, r_)
-        mm = b - a
-        out["y_end"][:, a:b] = allp[r_, :n, :mm]
-        row = n
-        for k in FIELDS_F64:
-            out[k][a:b] = allp[r_, row, :mm]
-            row += 1
-        for k in FIELDS_INT:
-            out[k][a:b] = allp[r_, row, :mm].astype(out[k].dtype)
-            row += 1
-    return _unpermute(out, perm, n, B)
+    gathered = torch.empty((world, arena.buf.numel()), dtype=torch.uint8, device=tdev)
+    if backend == "gloo":   # gloo has no all_gather_into_tensor
+        dist.all_gather(list(gathered.unbind(0)), arena.buf, group=group)
+    else:
+        dist.all_gather_into_tensor(gathered, arena.buf, group=group)
+    counts = [shard_bounds(B, world, r_)[1] - shard_bounds(B, world, r_)[0] for r_ in range(world)]
+    out = _unpermute(arena.split(gathered, counts), perm, B)
+    return _as_numpy(out) if as_numpy else out
 
 
-def _unpermute(out: dict, perm: np.ndarray, n: int, B: int) -> dict:
-    """Shard position q holds trajectory perm[q]; scatter back to original order."""
-    res = {}
-    for k, v in out.items():
-        v = np.asarray(v)
-        r = np.empty_like(v)
-        r[..., perm] = v
-        res[k] = r
-    return res
+def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Options = None, *,
+                          devices: Optional[Sequence[int]] = None, contexts: Optional[Sequence[api.Context]] = None,
+                          permutation: Optional[np.ndarray] = None, gather_device: Optional[int] = None) -> api.BatchSolution:
+    """One process, one host thread, one context per entry of ``devices`` (``ivp_batch_solve_multi``): the batch is cut
+    into ``len(devices)`` contiguous balanced shards (after ``permutation``), each integrated on its device, and the
+    end states are gathered with peer copies onto ``gather_device`` (default: the first device).  ``devices`` may name
+    the same GPU more than once (the degenerate single-GPU case).  End-state results only (no t_eval / logs)."""
+    import torch
+    options = options or api.Options()
+    if options.t_eval is not None or options.max_log or options.dense_output:
+        raise ValueError("solve_ivp_batch_multi gathers end states only")
+    devices = list(devices) if devices is not None else list(range(torch.cuda.device_count()))
+    if not devices:
+        raise RuntimeError("no HIP device")
+    contexts = list(contexts) if contexts is not None else [api.Context(d) for d in devices]
+    gdev = devices[0] if gather_device is None else int(gather_device)
+    home = torch.device("cuda", gdev)
+    y0 = torch.as_tensor(y0, dtype=torch.float64).to(home)
+    n, B = int(y0.shape[0]), int(y0.shape[1])
+    if n != f.n:
+        raise ValueError(f"y0 must have shape [n={f.n}, B]")
+    if f.n_params:
+        if params is None:
+            params = np.repeat(np.asarray(f.params(), dtype=np.float64)[:, None], B, axis=1)
+        params = torch.as_tensor(params, dtype=torch.float64).to(home)
+    else:
+        params = None
+    perm_t = None if permutation is None else torch.as_tensor(np.asarray(permutation), device=home, dtype=torch.int64)
+
+    def vec(v):
+        if np.ndim(v) == 0 and not api._is_torch(v):
+            return float(v)
+        t = torch.as_tensor(v, dtype=torch.float64).to(home)
+        return float(t.reshape(-1)[0]) if t.numel() == 1 else t
+    t0v, t1v = vec(t0), vec(t1)
+
+    world = len(devices)
+    keep: list = []
+    copt = options._c(n, keep)
+    prob = api._problem_c(f)
+    shards = (_lib.ShardT * world)()
+    ptr = lambda a: None if a is None else C.c_void_p(a.data_ptr())
+    for k, d in enumerate(devices):
+        lo, hi = shard_bounds(B, world, k)
+        m = hi - lo
+        dev = torch.device("cuda", d)
+        S = shards[k]
+        S.ctx = contexts[k].handle
+        S.first, S.count = lo, m
+        if m == 0:
+            continue
+        sel = slice(lo, hi) if perm_t is None else perm_t[lo:hi]
+        cut = lambda a: (a[..., sel] if perm_t is None else a.index_select(a.dim() - 1, sel)).to(dev).contiguous()
+        ys, ps = cut(y0), None if params is None else cut(params)
+        a0 = cut(t0v) if api._is_torch(t0v) else torch.as_tensor([t0v], dtype=torch.float64, device=dev)
+        a1 = cut(t1v) if api._is_torch(t1v) else torch.as_tensor([t1v], dtype=torch.float64, device=dev)
+        res = {name: torch.zeros((n, m) if rows is None else (m,), dtype={np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}[dt], device=dev)
+               for name, dt, rows in ARENA_FIELDS}
+        keep += [ys, ps, a0, a1, res]
+        S.y0, S.params, S.t0, S.t0_len, S.t1, S.t1_len = ptr(ys), ptr(ps), ptr(a0), a0.numel(), ptr(a1), a1.numel()
+        for name in res:
+            setattr(S.out, name, ptr(res[name]))
+        S.hip_stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    g = {name: torch.zeros((n, B) if rows is None else (B,), dtype={np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}[dt], device=home)
+         for name, dt, rows in ARENA_FIELDS}
+    gathered = _lib.BatchResultT()
+    for name in g:
+        setattr(gathered, name, ptr(g[name]))
+    for d in set(devices) | {gdev}:
+        torch.cuda.synchronize(d)    # inputs were produced on torch streams; the shard streams may differ
+    rc = contexts[0].lib.ivp_batch_solve_multi(shards, world, C.byref(prob), B, C.byref(copt), gdev, C.byref(gathered))
+    if rc != 0:
+        raise api.ConfigError(rc, contexts[0].last_error())
+    if perm_t is not None:
+        g = _unpermute(g, permutation, B)
+    return api.BatchSolution(y_end=g["y_end"], t_end=g["t_end"], status=g["status"], nfev=g["nfev"], nstep=g["nstep"],
+                             naccpt=g["naccpt"], nrejct=g["nrejct"], h_next=g["h_next"])
 
 
 class OverlappedGather:
-    """Double-buffered, asynchronous all-gather of one result array per step, used by bench.py --gpus N.
+    """Double-buffered, asynchronous all-gather of one byte arena per step, used by bench.py --gpus N.
 
     Step i's gather (RCCL over xGMI under backend "nccl": the C4 "gather of sol.y") runs while step i+1 integrates
-    into the other buffer; ``slot()`` returns which of the two buffers the next step may write (after making sure the
+    into the other arena; ``slot()`` returns which of the two buffers the next step may write (after making sure the
     gather that last read it has completed), ``launch(k, tensor)`` starts the gather of that step's result, and
     ``drain()`` waits for everything outstanding.  Backend-agnostic (gloo on CPU tensors in the tests)."""
 
@@ -160,3 +312,62 @@ class OverlappedGather:
             if self.works[k] is not None:
                 self.works[k].wait()
                 self.works[k] = None
+
+
+def run_steps(solve_into: Callable, n: int, m: int, device, steps: int, warmup: int, *, gather: bool, d2h: bool = False,
+              on_step: Optional[Callable] = None):
+    """The step loop of bench.py (kept here so that the CPU suite can run the very same code under gloo).
+
+    ``solve_into(sol)`` integrates this rank's shard of ``m`` trajectories and leaves the end states in ``sol`` (a
+    BatchSolution whose members are views of a ResultArena); it returns the solution object to report (normally
+    ``sol``).  One step = one complete solve (+ the all-gather of the shard's byte arena when ``gather``: step i's
+    gather overlaps step i+1's integration through double buffering, and every gather is waited for inside the timed
+    region).  ``d2h``: every solve is followed by a copy of the arena into pinned host memory.
+    Returns (elapsed seconds on this rank, last solution, OverlappedGather or None, the two arenas)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    is_cuda = torch.device(device).type == "cuda"
+    arenas = [ResultArena(n, m, device) for _ in range(2)]
+    sols = [a.solution() for a in arenas]
+    og = OverlappedGather((arenas[0].buf.numel(),), torch.uint8, device) if gather else None
+    host = None
+    if d2h:
+        host = torch.empty(arenas[0].buf.numel(), dtype=torch.uint8)
+        host = host.pin_memory() if is_cuda else host
+    cnt = [0]
+
+    def step():
+        if og is not None:
+            k = og.slot()
+        else:
+            k = cnt[0] & 1
+            cnt[0] += 1
+        out = solve_into(sols[k])
+        if og is not None:
+            og.launch(k, arenas[k].buf)
+        if host is not None:
+            host.copy_(arenas[k].buf, non_blocking=True)
+            if is_cuda:
+                torch.cuda.current_stream().synchronize()     # the caller owns the results on the host now
+        return out
+
+    def drain():
+        if og is not None:
+            og.drain()
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        if is_cuda:
+            torch.cuda.synchronize()
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    drain()
+    t_begin = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+        if on_step is not None:
+            on_step(out)
+    drain()
+    return time.perf_counter() - t_begin, out, og, arenas

@@ -45,6 +45,29 @@ int main(void)
             return 11;
         }
     }
+    /* the same batch split over two contexts (here on one device; one per GPU in production): identical bits */
+    {
+        ivp_ctx_t *ctx2 = NULL;
+        if (ivp_ctx_create(&ctx2, ivp_device_count() > 1 ? 1 : 0) != IVP_OK) return 13;
+        ivp_ctx_t *both[2];
+        both[0] = ctx; both[1] = ctx2;
+        double y2[B], te2[B];
+        int32_t st2[B];
+        uint64_t na2[B];
+        ivp_batch_result_t out2;
+        memset(&out2, 0, sizeof out2);
+        out2.y_end = y2; out2.t_end = te2; out2.status = st2; out2.naccpt = na2;
+        rc = ivp_batch_solve_multi_host(both, 2, &prob, B, y0, k, &t0, 1, t1, B, &opt, &out2);
+        if (rc != IVP_OK) { printf("multi solve failed: %d %s\n", rc, ivp_last_error_string(ctx)); return 14; }
+        if (memcmp(y2, y_end, sizeof y2) || memcmp(te2, t_end, sizeof te2) || memcmp(st2, status, sizeof st2) || memcmp(na2, naccpt, sizeof na2)) {
+            printf("multi-context result differs from the single-context one\n");
+            return 15;
+        }
+        both[1] = ctx;
+        if (ivp_batch_solve_multi_host(both, 2, &prob, B, y0, k, &t0, 1, t1, B, &opt, &out2) != IVP_ERR_BAD_ARGUMENT) return 16;
+        ivp_ctx_destroy(ctx2);
+        printf("multi-context solve ok\n");
+    }
     opt.method = IVP_RADAU;
     if (ivp_batch_solve(ctx, &prob, B, y0, k, &t0, 1, t1, B, &opt, &out) != IVP_ERR_UNSUPPORTED_METHOD) return 12;
     ivp_ctx_destroy(ctx);

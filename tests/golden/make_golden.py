@@ -81,7 +81,7 @@ def one_step_cases():
     return cases
 
 
-def truth_cases(nsub=32):
+def truth_cases(nsub=256):   # the 256-trajectory accuracy subset
     out = {}
     y0, p, t0, t1 = workloads.cr3bp_batch(256)
     ys = []

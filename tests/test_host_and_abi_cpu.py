@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ivp_abi_version() == 2
+    assert lib.ivp_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(lib):
@@ -127,6 +127,9 @@ got = D.solve_ivp_sharded(ivp_amd.CR3BP(), t0, 2.0, y0, p, opt, permutation=perm
 ref = O.solve_batch("cr3bp", y0, p, t0, 2.0, method="DOPRI5", rtol=1e-6, atol=1e-9, detpow=True)
 for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct"):
     assert np.array_equal(np.asarray(got[k]).astype(ref[k].dtype), ref[k]), k
+# a batch smaller than the world: rank 1's shard is empty, it still takes part in the collective (no deadlock)
+got1 = D.solve_ivp_sharded(ivp_amd.CR3BP(), t0, 2.0, y0[:, :1], p[:, :1], opt, solve_fn=oracle_solve)
+assert np.array_equal(got1["y_end"], ref["y_end"][:, :1]) and got1["naccpt"][0] == ref["naccpt"][0]
 dist.barrier()
 dist.destroy_process_group()
 print("rank", sys.argv[1], "ok")
@@ -207,6 +210,60 @@ def test_overlapped_gather_double_buffering_under_gloo_world_size_2(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "worker_og.py"
     script.write_text(_WORKER_OG.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+_WORKER_BENCH = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from ivp_amd import workloads as W, distributed as D
+from oracle import oracle as O
+
+rank = int(sys.argv[1]); world = 2
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+B = 64                                           # bench.py requires B % world == 0 (equal arenas)
+y0, p, t0, t1 = W.cr3bp_batch(B)
+t1 = 2.0
+perm = W.shard_permutation(B)
+lo, hi = D.shard_bounds(B, world, rank)
+idx = perm[lo:hi]
+ys, ps = np.ascontiguousarray(y0[:, idx]), np.ascontiguousarray(p[:, idx])
+calls = [0]
+def solve_into(sol):                             # bench.py passes ivp_amd.solve_ivp_batch(..., out=sol) here
+    r = O.solve_batch("cr3bp", ys, ps, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, detpow=True)
+    for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct"):
+        getattr(sol, k).copy_(torch.as_tensor(r[k].astype(np.int64) if r[k].dtype == np.uint64 else r[k]))
+    calls[0] += 1
+    return sol
+el, out, og, arenas = D.run_steps(solve_into, 6, hi - lo, torch.device("cpu"), steps=3, warmup=1, gather=True, d2h=False)
+assert calls[0] == 4 and el > 0
+# the gather of the LAST step: every rank holds every shard; undo the permutation and compare with one whole-batch solve
+g = arenas[0].split(og.gathered[(og.steps - 1) & 1], [hi - lo] * world)
+full = D._unpermute(g, perm, B)
+ref = O.solve_batch("cr3bp", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, detpow=True)
+for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct"):
+    assert np.array_equal(full[k].numpy().astype(ref[k].dtype), ref[k]), k
+el2, _, og2, _ = D.run_steps(solve_into, 6, hi - lo, torch.device("cpu"), steps=2, warmup=0, gather=False, d2h=True)
+assert og2 is None
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_bench_step_loop_strong_scaling_under_gloo_world_size_2(tmp_path):
+    """The exact loop bench.py --gpus N times (ivp_amd.distributed.run_steps): shard after the fixed permutation,
+    integrate into a byte arena, overlapped all-gather of the arena per step, every rank ends up with the whole batch.
+    The per-shard integrator is the CPU oracle here; on the GPU box it is the HIP path and the backend is RCCL."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker_bench.py"
+    script.write_text(_WORKER_BENCH.format(root=ROOT, port=port))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
