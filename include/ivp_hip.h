@@ -167,6 +167,8 @@ typedef struct {
     double scale_max;       /* default 10  (DOPRI5, RK23), 6 (DOP853)            */
     double beta;            /* default 0.04 (DOPRI5), 0 (DOP853)                 */
     uint64_t stiff_test;    /* default 1000                                      */
+    int32_t count_log;      /* 1: run DefaultSolOut's accepted-step recording without storing anything: out->n_log
+                               receives the number of records per trajectory (first pass of the CSR log) */
 } ivp_options_t;
 
 /* Per-trajectory results: `struct Solution` (src/solve/solution.rs:7-20) + IntegrationResult.h
@@ -202,6 +204,13 @@ typedef struct {
     /* implicit methods (BDF): Solution.njev / Solution.nlu; zero for the explicit RK methods  */
     uint64_t *njev;     /* [B]                                                                  */
     uint64_t *nlu;      /* [B]                                                                  */
+    /* Unbounded accepted-step log in CSR form (the reference's Solution.t / Solution.y are Vecs that grow with every
+     * accepted step, src/solve/solout.rs:387-428): an INPUT.  When non-NULL (device path only) it holds B+1 record
+     * offsets; trajectory b's k-th record then lives at t_log[log_offsets[b] + k] and
+     * y_log[(log_offsets[b] + k) * n + c] (time-major like Vec<Vec<f64>>), so the log takes sum(n_log) records
+     * instead of max_log x B.  Two passes: a counting solve (options.count_log = 1, only n_log is written), an
+     * exclusive scan of n_log, then the filling solve with these offsets. */
+    const uint64_t *log_offsets;
 } ivp_batch_result_t;
 
 /* What the last solve on a context did (filled when options.profile == 1). */

@@ -37,6 +37,7 @@ class OptionsT(C.Structure):
         ("fp_mode", C.c_int32), ("chunk_attempts", C.c_int32), ("max_log", C.c_uint32), ("variant", C.c_int32), ("profile", C.c_int32),
         ("has_settings", C.c_int32), ("uround", C.c_double), ("safety_factor", C.c_double), ("scale_min", C.c_double),
         ("scale_max", C.c_double), ("beta", C.c_double), ("stiff_test", C.c_uint64),
+        ("count_log", C.c_int32),
     ]
 
 
@@ -44,7 +45,7 @@ class BatchResultT(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in (
         "y_end", "t_end", "status", "nfev", "nstep", "naccpt", "nrejct", "h_next",
         "y_eval", "eval_idx", "n_filled", "t_log", "y_log", "n_log",
-        "seg_cont", "seg_xold", "seg_h", "n_seg", "t_events", "y_events", "n_event_hits", "t_term", "njev", "nlu")]
+        "seg_cont", "seg_xold", "seg_h", "n_seg", "t_events", "y_events", "n_event_hits", "t_term", "njev", "nlu", "log_offsets")]
 
 
 class ShardT(C.Structure):

@@ -350,6 +350,7 @@ class Options:
     variant: int = 0                   # stepping-kernel variant: 0 auto, 1 lean registers, 2 coefficients resident,
                                        # 3 lane-cooperative (8 lanes per trajectory; DOPRI5 / DOP853) -- strict results never depend on it
     profile: int = 0                   # 1: HIP-event kernel timing, 2: + batch totals (see ivp_run_stats_t)
+    count_log: bool = False            # counting pass of the CSR step log: only n_log is produced (solve_ivp_batch_logged)
 
     def _c(self, n: int, keep: list) -> _lib.OptionsT:
         o = _lib.OptionsT()
@@ -404,6 +405,7 @@ class Options:
         o.max_events = int(self.max_events)
         o.variant = int(self.variant)
         o.profile = int(self.profile)
+        o.count_log = int(bool(self.count_log))
         return o
 
     @property
@@ -634,7 +636,14 @@ class BatchSolution:
     t_term: object = None
     njev: object = None
     nlu: object = None
+    log_offsets: object = None   # CSR step log (solve_ivp_batch_logged): [B+1] record offsets; t_log [total], y_log [total, n]
     stats: dict = field(default_factory=dict)
+    event_overflow: bool = False  # some trajectory detected more occurrences of an event than max_events could store
+
+    def log_of(self, b: int):
+        """(t, y) of trajectory b from a CSR step log: Solution.t / Solution.y of that solve_ivp() call."""
+        lo, hi = int(self.log_offsets[b]), int(self.log_offsets[b + 1])
+        return self.t_log[lo:hi], self.y_log[lo:hi]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -651,6 +660,21 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+def _flag_event_overflow(res: "BatchSolution") -> None:
+    """The reference's t_events / y_events are Vecs that grow with every hit (src/solve/solout.rs:158-331); the batch
+    buffers hold max_events per event and trajectory.  n_event_hits keeps counting past the capacity: report it."""
+    if res.n_event_hits is None or res.t_events is None:
+        return
+    cap = int(res.t_events.shape[1])
+    most = int(res.n_event_hits.max()) if res.n_event_hits.shape[0] and res.n_event_hits.shape[1] else 0
+    if most > cap:
+        import warnings
+        res.event_overflow = True
+        warnings.warn(f"event buffers overflowed: up to {most} occurrences of one event in a trajectory, capacity "
+                      f"max_events = {cap}; t_events / y_events hold the first {cap} -- rerun with Options(max_events >= {most})",
+                      RuntimeWarning, stacklevel=3)
+
+
 class PendingBatch:
     """A solve in flight (``solve_ivp_batch(..., wait=False)``): ``done()`` advances it without blocking,
     ``result()`` blocks until the results are final.  One per Context at a time."""
@@ -664,6 +688,7 @@ class PendingBatch:
         self._keep = None
         if self._profile:
             self._res.stats = self._ctx.stats()
+        _flag_event_overflow(self._res)
 
     def done(self) -> bool:
         if self._done:
@@ -771,6 +796,12 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
                     t_log=((ml, B), f64), y_log=((ml, n, B), f64), n_log=((B,), u32),
                     seg_cont=((ml, nc, B), f64), seg_xold=((ml, B), f64), seg_h=((ml, B), f64), n_seg=((B,), u32),
                     t_events=((nev_, mev_, B), f64), y_events=((nev_, mev_, n, B), f64), n_event_hits=((nev_, B), u32), t_term=((B,), f64))
+        if out.log_offsets is not None:   # CSR step log: t_log [total], y_log [total, n], offsets [B+1]
+            if out.t_log is None or out.y_log is None:
+                raise ValueError("out.log_offsets needs out.t_log and out.y_log")
+            total = int(out.t_log.shape[0])
+            want["t_log"], want["y_log"] = ((total,), f64), ((total, n), f64)
+            want["log_offsets"] = ((B + 1,), u64)
         for name, (shape, dt) in want.items():
             v = getattr(out, name)
             if v is None:
@@ -791,7 +822,9 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         res.y_eval = xp_zeros((rows, n, B), f64)
         res.eval_idx = xp_zeros((rows, B), i32)
         res.n_filled = xp_zeros((B,), i32)
-    if options.t_eval is None and ml > 0 and res.t_log is None:
+    if options.count_log and res.n_log is None:
+        res.n_log = xp_zeros((B,), u32)
+    if options.t_eval is None and ml > 0 and res.t_log is None and res.log_offsets is None:
         res.t_log = xp_zeros((ml, B), f64)
         res.y_log = xp_zeros((ml, n, B), f64)
         res.n_log = xp_zeros((B,), u32)
@@ -839,6 +872,44 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         raise ConfigError(rc, ctx.last_error())
     if options.profile:
         res.stats = ctx.stats()
+    _flag_event_overflow(res)
+    return res
+
+
+def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = None, ctx: Context = None) -> BatchSolution:
+    """``Solution.t`` / ``Solution.y`` of B independent solves -- every accepted step of every trajectory -- in CSR form.
+
+    The reference pushes one record per accepted step into growing Vecs (src/solve/solout.rs:387-428).  A dense
+    ``[max_log, n, B]`` buffer sized for the longest trajectory wastes memory on all others, so this runs two passes on
+    the device: a counting solve (``Options.count_log``: the device DefaultSolOut runs, nothing is stored), an
+    exclusive scan of the counts, and the filling solve that writes record k of trajectory b at ``offsets[b] + k``.
+    The integration is deterministic, so both passes take identical steps.  Memory: ``sum(n_log) * (n + 1) * 8`` bytes.
+
+    Returns a BatchSolution with ``log_offsets`` [B+1], ``t_log`` [total], ``y_log`` [total, n] (time-major like the
+    reference's ``Vec<Vec<f64>>``), ``n_log`` and the end-state members; ``log_of(b)`` slices one trajectory.
+    ``y0`` may be a numpy array (moved to the context's device) or a CUDA tensor."""
+    import torch
+    options = options or Options()
+    if options.t_eval is not None:
+        raise ValueError("the accepted-step log is what solve_ivp records when t_eval is None")
+    ctx = ctx or default_context(y0.device.index or 0 if _is_torch(y0) else 0)
+    dev = y0.device if _is_torch(y0) else torch.device("cuda", ctx.device)
+    to_dev = lambda a: None if a is None else (a if _is_torch(a) else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev))
+    y0d, pd = to_dev(y0), to_dev(params)
+    tt = lambda v: v if (np.ndim(v) == 0 and not _is_torch(v)) else to_dev(v)
+    t0d, t1d = tt(t0), tt(t1)
+    n, B = int(y0d.shape[0]), int(y0d.shape[1])
+    base = {k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log", "profile")}
+    cnt = solve_ivp_batch(f, t0d, t1d, y0d, pd, Options(**base, max_log=options.max_log if options.dense_output else 0, count_log=True), ctx)
+    offsets = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(cnt.n_log.to(torch.int64), 0, out=offsets[1:])
+    total = int(offsets[-1].item())
+    out = BatchSolution(y_end=cnt.y_end, t_end=cnt.t_end, status=cnt.status, nfev=cnt.nfev, nstep=cnt.nstep, naccpt=cnt.naccpt,
+                        nrejct=cnt.nrejct, h_next=cnt.h_next, njev=cnt.njev, nlu=cnt.nlu, n_log=cnt.n_log,
+                        t_log=torch.empty(max(total, 1), dtype=torch.float64, device=dev),
+                        y_log=torch.empty((max(total, 1), n), dtype=torch.float64, device=dev), log_offsets=offsets)
+    res = solve_ivp_batch(f, t0d, t1d, y0d, pd, Options(**base, max_log=options.max_log if options.dense_output else 0, profile=options.profile), ctx, out)
+    res.t_log, res.y_log = res.t_log[:total], res.y_log[:total]
     return res
 
 
@@ -869,18 +940,29 @@ def solve_ivp(f: IVP, x0: float, xend: float, y0: Sequence[float], options: Opti
         raise ValueError(f"y0 has {n} components, problem has {f.n}")
     need_log = options.t_eval is None or options.dense_output
     cap = options.max_log or (4096 if need_log else 0)
+    ev_cap = max(int(options.max_events), 1)
+    import warnings
     while True:
-        o = Options(**{**options.__dict__, "max_log": cap})
+        # Solution.t / .y / .t_events / .y_events are unbounded Vecs in the reference (solout.rs:158-331,387-428):
+        # a buffer that turned out too small means a rerun with room for everything, never a truncated result
+        o = Options(**{**options.__dict__, "max_log": cap, "max_events": ev_cap})
         pr = np.asarray(f.params(), dtype=np.float64).reshape(f.n_params, 1) if f.n_params else None
-        r = solve_ivp_batch(f, x0, xend, y0.reshape(n, 1), pr, o, ctx)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            r = solve_ivp_batch(f, x0, xend, y0.reshape(n, 1), pr, o, ctx)
         used = 0
         if r.n_log is not None:
             used = max(used, int(r.n_log[0]))
         if r.n_seg is not None:
             used = max(used, int(r.n_seg[0]))
-        if used <= cap or not need_log:
+        hits = int(np.asarray(r.n_event_hits).max()) if (n_events and r.n_event_hits is not None) else 0
+        log_ok = used <= cap or not need_log
+        if log_ok and hits <= ev_cap:
             break
-        cap = int(used * 1.25) + 16  # the log overflowed: rerun with room for every accepted step
+        if not log_ok:
+            cap = int(used * 1.25) + 16  # the log overflowed: rerun with room for every accepted step
+        if hits > ev_cap:
+            ev_cap = int(hits * 1.25) + 8
     if options.t_eval is not None:
         m = int(r.n_filled[0])
         te = np.asarray(options.t_eval, dtype=np.float64)

@@ -83,7 +83,7 @@ struct ivp_ctx {
     int device = 0;
     std::string err;
     // scratch (device)
-    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval, tolvec;
+    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval, tolvec, zero_off;
     DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
     DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
     DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu, prev_event, sc_n_ev;
@@ -437,7 +437,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval, &c->tolvec,
+    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval, &c->tolvec, &c->zero_off,
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
@@ -520,7 +520,10 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     hipStream_t s = (hipStream_t)hip_stream;
 
     const bool want_eval = opt->t_eval != nullptr;
-    const bool want_log = !want_eval && opt->max_log > 0 && out->t_log && out->y_log;
+    const bool csr_log = !want_eval && out->log_offsets && out->t_log && out->y_log;    // fill pass of the CSR step log
+    const bool count_log = !want_eval && opt->count_log != 0 && !csr_log;               // counting pass: n_log only
+    if (opt->count_log && !out->n_log) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "count_log needs out.n_log");
+    const bool want_log = csr_log || count_log || (!want_eval && opt->max_log > 0 && out->t_log && out->y_log);
     const bool want_dense = opt->dense_output && opt->max_log > 0 && out->seg_cont && out->seg_xold && out->seg_h;
     const bool group = n > IVP_MAX_N;
     const int n_events = prob->rhs_id == IVP_RHS_JIT ? ivp_jit_n_events(prob->jit) : group ? 0 : kRhsEvents[prob->rhs_id];
@@ -652,9 +655,18 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         a.next_idx = (int32_t *)ctx->sc_next_idx.p;
         a.t_last = (double *)ctx->sc_t_last.p;
         a.max_log = (want_log || want_dense) ? opt->max_log : 0;
-        if (want_log) {
+        if (count_log) {
+            // counting pass = a CSR log whose offsets are all zero: so_sample runs (t_log != NULL), every record finds
+            // capacity 0 and only n_log advances
+            HIP_TRY(ctx, ctx->zero_off.reserve(sizeof(unsigned long long) * (B + 1)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->zero_off.p, 0, sizeof(unsigned long long) * (B + 1), s));
+            a.t_log = (double *)ctx->counts.p;
+            a.y_log = (double *)ctx->counts.p;
+            a.log_off = (const unsigned long long *)ctx->zero_off.p;
+        } else if (want_log) {
             a.t_log = out->t_log;
             a.y_log = out->y_log;
+            a.log_off = csr_log ? (const unsigned long long *)out->log_offsets : nullptr;
         }
         a.collect_dense = want_dense ? 1 : 0;
         a.seg_cont = out->seg_cont;
@@ -934,6 +946,7 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
     if (!y0 || !t0 || !t1 || !out) return fail(c0, IVP_ERR_BAD_ARGUMENT, "null y0/t0/t1/out");
     if (np > 0 && !params) return fail(c0, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
     if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
+    if (out->log_offsets) return fail(c0, IVP_ERR_BAD_ARGUMENT, "the CSR step log (log_offsets) is available on the device-pointer entry points only");
     MemberDesc md[kMembers];
     member_table(result_shape(prob, opt, n), md);
 

@@ -78,6 +78,8 @@ struct IvpKArgs {
     double *y_log;            // [max_log][N][B]
     uint32_t *n_log;          // [B]
     double *t_last;           // [B] last recorded t (dedupe test, solout.rs:424)
+    const unsigned long long *log_off;  // CSR step log: [B+1] record offsets; then t_log is [total] and y_log [total][N]
+                                        // (time-major like the reference's Vec<Vec<f64>>); NULL = dense [max_log][..][B]
     int32_t collect_dense;
     double *seg_cont;         // [max_log][ncoef*N][B]
     double *seg_xold;         // [max_log][B]

@@ -578,7 +578,16 @@ template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, const double *yv)
 {
     const size_t B = a.B;
-    if (L.n_log < a.max_log) {
+    if (a.log_off != nullptr) {
+        // CSR log (two-pass count / fill): record k of trajectory j lives at log_off[j] + k, memory = sum of the counts
+        const unsigned long long lo = a.log_off[j], cap = a.log_off[j + 1] - lo;
+        if (L.n_log < cap) {
+            const size_t q = (size_t)(lo + L.n_log);
+            a.t_log[q] = t;
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_log[q * MAP::NT + MAP::gi(c)] = yv[c];
+        }
+    } else if (L.n_log < a.max_log) {
         const size_t k = L.n_log;
         a.t_log[k * B + j] = t;
 #pragma unroll

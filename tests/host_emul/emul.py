@@ -29,7 +29,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("t_eval", VP), ("n_eval", C.c_int32),
         ("y_eval", VP), ("eval_idx", VP), ("n_filled", VP), ("next_idx", VP),
         ("max_log", C.c_uint32),
-        ("t_log", VP), ("y_log", VP), ("n_log", VP), ("t_last", VP),
+        ("t_log", VP), ("y_log", VP), ("n_log", VP), ("t_last", VP), ("log_off", VP),
         ("collect_dense", C.c_int32),
         ("seg_cont", VP), ("seg_xold", VP), ("seg_h", VP), ("n_seg", VP),
         ("ev_direction", C.c_int32 * 4), ("ev_terminal", C.c_uint32 * 4), ("max_events", C.c_uint32),

@@ -1,0 +1,157 @@
+"""More of the reference's own tests restated (file:line relative to /root/reference), against the CPU oracle (no GPU
+needed) and against the product API on the GPU (marked gpu):
+
+  tests/test_args.py:9-70            args + three event functions (directional, terminal) + dense output
+  tests/test_stiff.py:122-145        BDF on the Robertson problem: nfev / njev budgets
+  tests/test_basic_integration.py:138-154   the 'vectorized' variant of the rational problem (same contract)
+  tests/test_events.py:100-160       terminal event, Direction::Positive / Negative counts, the duplicate-timestamp
+                                     cannon with its known answers
+
+The reference runs test_args_with_events with Radau (outside this path's scope); the explicit-RK path integrates the
+same non-stiff system with DOP853 at the same tolerances and must satisfy the same assertions.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+OMEGA, K, TFINAL, ZFINAL = 2.0, 4.0, 5.0, 0.99
+Z0 = np.exp(-K * TFINAL) / ((1 - ZFINAL) / ZFINAL + np.exp(-K * TFINAL))
+W0 = [0.0, -1.0, Z0]
+
+
+def _check_sys3(t_events, sol_at, t_last_event):
+    # tests/test_args.py:55-70
+    np.testing.assert_allclose(t_events[0], [0.5 * np.pi, 1.5 * np.pi], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(t_events[1], [0.25 * np.pi, 1.25 * np.pi], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(t_events[2], [TFINAL], rtol=1e-5, atol=1e-5)
+    t = np.linspace(0, t_last_event, 250)
+    w = np.array([sol_at(ti) for ti in t]).T
+    np.testing.assert_allclose(w[0], np.sin(OMEGA * t), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w[1], -np.cos(OMEGA * t), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w[2], 1 / (((1 - Z0) / Z0) * np.exp(-K * t) + 1), rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_args_with_events():  # tests/test_args.py:9-70
+    fun = lambda t, w, p: [-p[0] * w[1], p[0] * w[0], p[1] * w[2] * (1 - w[2])]
+    ev = lambda t, w, p: [w[0], w[1], w[2] - p[2]]
+    s = O.solve_ivp(fun, 0.0, 2 * TFINAL, W0, params=(OMEGA, K, ZFINAL), events=ev, n_events=3, event_direction=[-1, 1, 0],
+                    event_terminal=[0, 0, 1], dense_output=True, method="DOP853", rtol=1e-10, atol=1e-13)
+    assert s.status == 1
+    _check_sys3(s.t_events, s.sol, s.t_events[2][0])
+
+
+def test_oracle_robertson_bdf_budgets():  # tests/test_stiff.py:122-145
+    s = O.solve_ivp("robertson", 0.0, 1e8, [1e4, 0.0, 0.0], method="BDF", rtol=1e-6, atol=1e-6)
+    assert s.status == 0 and s.nfev < 5000 and s.njev < 600
+
+
+def test_oracle_integration_vectorized_contract():  # tests/test_basic_integration.py:138-154 (same RHS, RK45, dense)
+    s = O.solve_ivp("rational", 5.0, 9.0, [1 / 3, 2 / 9], method="RK45", rtol=1e-3, atol=1e-6, dense_output=True)
+    assert s.t[0] == 5.0 and s.status == 0
+
+
+def test_oracle_event_suite():  # tests/test_events.py:100-160
+    y0 = [1 / 3, 2 / 9]
+    s = O.solve_ivp("rational_ev", 5.0, 8.0, y0, method="RK45", event_direction=[0, 0, 0], event_terminal=[0, 0, 1], dense_output=True)
+    assert s.status == 1 and len(s.t_events[2]) == 1 and 7.3 < s.t_events[2][0] < 7.5             # :100-113
+    s = O.solve_ivp("rational_ev", 5.0, 8.0, y0, method="RK45", event_direction=[1, 0, 0], event_terminal=[0, 0, 0])
+    assert s.status == 0 and len(s.t_events[0]) == 1 and 5.3 < s.t_events[0][0] < 5.7           # :116-129
+    s = O.solve_ivp("rational_ev", 5.0, 8.0, y0, method="RK45", event_direction=[-1, 0, 0], event_terminal=[0, 0, 0])
+    assert s.status == 0 and len(s.t_events[0]) == 0                                            # :132-144
+    s = O.solve_ivp("cannon", 0.0, np.inf, [0.0, 0.01], method="RK45", max_step=0.05 * 0.001 / 9.80665,
+                    event_direction=[-1], event_terminal=[1], dense_output=True)                    # :147-165
+    np.testing.assert_allclose(s.sol_extrapolate(0.01), [-0.00039033, -0.08806632], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(s.t_events[0], [0.00203943], rtol=1e-5, atol=1e-8)
+    assert s.status == 1
+
+
+# ---- the same, through the product API on the GPU -----------------------------------------------------------------
+SYS3_SRC = r"""
+__device__ void ode(double t, const double* w, double* d, const double* p)
+{ d[0] = -p[0] * w[1]; d[1] = p[0] * w[0]; d[2] = p[1] * w[2] * (1.0 - w[2]); }
+__device__ void events(double t, const double* w, double* g, const double* p)
+{ g[0] = w[0]; g[1] = w[1]; g[2] = w[2] - p[2]; }
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_args_with_events():  # tests/test_args.py:9-70: `args` are the problem struct's fields (per-trajectory params)
+    import ivp_amd
+    from ivp_amd import EventConfig
+    f = ivp_amd.DeviceIVP(SYS3_SRC, n=3, params=(OMEGA, K, ZFINAL),
+                          events=[EventConfig().negative(), EventConfig().positive(), EventConfig().terminal()])
+    s = ivp_amd.solve_ivp(f, 0.0, 2 * TFINAL, W0, ivp_amd.Options(method="DOP853", rtol=1e-10, atol=1e-13, dense_output=True))
+    assert s.status == ivp_amd.Status.UserInterrupt
+    _check_sys3(s.t_events, s.sol, s.t_events[2][0])
+    # ... and it is the oracle's answer bit for bit (same event times, same interpolants)
+    fun = lambda t, w, p: [-p[0] * w[1], p[0] * w[0], p[1] * w[2] * (1 - w[2])]
+    ev = lambda t, w, p: [w[0], w[1], w[2] - p[2]]
+    o = O.solve_ivp(fun, 0.0, 2 * TFINAL, W0, params=(OMEGA, K, ZFINAL), events=ev, n_events=3, event_direction=[-1, 1, 0],
+                    event_terminal=[0, 0, 1], dense_output=True, method="DOP853", rtol=1e-10, atol=1e-13, detpow=True)
+    for i in range(3):
+        assert np.array_equal(s.t_events[i], o.t_events[i])
+    assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
+
+
+@pytest.mark.gpu
+def test_gpu_robertson_bdf_budgets():  # tests/test_stiff.py:122-145
+    import ivp_amd
+    s = ivp_amd.solve_ivp(ivp_amd.Robertson(), 0.0, 1e8, [1e4, 0.0, 0.0], ivp_amd.Options(method="BDF", rtol=1e-6, atol=1e-6))
+    assert s.status == ivp_amd.Status.Success and s.nfev < 5000 and s.njev < 600
+
+
+@pytest.mark.gpu
+def test_gpu_integration_vectorized_contract():  # tests/test_basic_integration.py:138-154
+    import ivp_amd
+    s = ivp_amd.solve_ivp(ivp_amd.Rational(), 5.0, 9.0, [1 / 3, 2 / 9], ivp_amd.Options(method="RK45", rtol=1e-3, atol=1e-6, dense_output=True))
+    assert s.t[0] == 5.0 and s.status == ivp_amd.Status.Success and s.status.is_success()
+
+
+@pytest.mark.gpu
+def test_gpu_event_suite():  # tests/test_events.py:100-160
+    import ivp_amd
+    from ivp_amd import Cannon, Direction, EventConfig, Options, RationalEvents, Status, solve_ivp
+    y0 = [1 / 3, 2 / 9]
+    s = solve_ivp(RationalEvents(EventConfig(), EventConfig(), EventConfig().terminal()), 5.0, 8.0, y0, Options(method="RK45", dense_output=True))
+    assert s.status == Status.UserInterrupt and len(s.t_events[2]) == 1 and 7.3 < s.t_events[2][0] < 7.5
+    s = solve_ivp(RationalEvents(EventConfig().positive()), 5.0, 8.0, y0, Options(method="RK45"))
+    assert s.status == Status.Success and len(s.t_events[0]) == 1 and 5.3 < s.t_events[0][0] < 5.7
+    s = solve_ivp(RationalEvents(EventConfig().negative()), 5.0, 8.0, y0, Options(method="RK45"))
+    assert s.status == Status.Success and len(s.t_events[0]) == 0
+    s = solve_ivp(Cannon(EventConfig(Direction.Negative, 1)), 0.0, np.inf, [0.0, 0.01],
+                  Options(method="RK45", max_step=0.05 * 0.001 / 9.80665, dense_output=True))
+    np.testing.assert_allclose(s.continuous_sol.evaluate_extrapolate(0.01), [-0.00039033, -0.08806632], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(s.t_events[0], [0.00203943], rtol=1e-5, atol=1e-8)
+    assert s.status == Status.UserInterrupt
+
+
+# ---- the power-function substitution, quantified on the HEADLINE configuration ------------------------------------
+def test_detpow_substitution_statistics_on_the_full_c2_horizon():
+    """The strict GPU path is bit-identical to the oracle built with the portable power function (ivp_pow / orc_detpow);
+    the reference calls libm's pow.  On the full BASELINE C2 configuration (100k CR3BP trajectories, one Arenstorf
+    period -- a chaotic horizon) the two oracles must tell the same story: identical step counts for almost every
+    trajectory, and an end-state difference far below the integration error itself."""
+    import json
+    import os
+    from ivp_amd import workloads as W
+    B = 100_000
+    y0, p, t0, t1 = W.cr3bp_batch(B)
+    kw = dict(method="DOPRI5", rtol=1e-6, atol=1e-9, threads=8)
+    a = O.solve_batch("cr3bp", y0, p, t0, t1, detpow=False, **kw)     # libm pow: what the Rust crate calls
+    b = O.solve_batch("cr3bp", y0, p, t0, t1, detpow=True, **kw)      # the GPU's arithmetic
+    same_steps = float(np.mean((a["naccpt"] == b["naccpt"]) & (a["nrejct"] == b["nrejct"])))
+    rel_steps = abs(float(a["naccpt"].sum()) - float(b["naccpt"].sum())) / float(a["naccpt"].sum())
+    delta = np.abs(a["y_end"] - b["y_end"]).max(axis=0)
+    truth = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scipy_truth.json")))["truth"]["cr3bp"]
+    n = int(truth["subset"])
+    ref = np.asarray(truth["y_end"]).T
+    err_libm = np.abs(a["y_end"][:, :n] - ref).max(axis=0)             # integration error of the faithful oracle
+    err_det = np.abs(b["y_end"][:, :n] - ref).max(axis=0)
+    print(f"identical (naccpt, nrejct): {same_steps:.4f}; total accepted steps differ by {rel_steps:.2e}; "
+          f"median |dy| {np.median(delta):.2e}, max |dy| {delta.max():.2e}; "
+          f"truth error median libm {np.median(err_libm):.2e} detpow {np.median(err_det):.2e}")
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    assert same_steps > 0.90 and rel_steps < 1e-3
+    assert np.median(delta) < 1e-2 * np.median(err_libm)               # the substitution is invisible next to the method's error
+    assert np.median(err_det) < 1.5 * np.median(err_libm) and err_det.max() < 10 * err_libm.max()   # BASELINE: within 10x of the CPU reference
