@@ -91,7 +91,8 @@ typedef enum {
     IVP_RHS_BALL = 12,    /* bouncing ball  p={gravity,drag}, g = height n=2  examples/bouncing_ball.rs:5-31     */
     IVP_RHS_CANNON = 13,  /* y'' = -9.80665, g = y0                     n=2  tests/test_ivp.py:152-160          */
     IVP_RHS_RATIONAL_EV = 14, /* rational problem + 3 events            n=2  tests/test_ivp.py:345-353          */
-    IVP_RHS_BUILTIN_COUNT = 15,
+    IVP_RHS_ROBERTSON_JAC = 15, /* Robertson + analytic `jac` override (trait IVP::jac, src/ivp.rs:67-107)  n=3 */
+    IVP_RHS_BUILTIN_COUNT = 16,
     /* Large state dimensions (8 < n <= 512): one 64-lane wavefront integrates one trajectory, the state is
      * distributed over its lanes and the error norm is a wavefront reduction.  RK23 / DOPRI5 / DOP853 / RK4 with
      * every output mode (t_eval, step log, dense output), events (hiprtc problems) and scalar or vector tolerances;
@@ -346,9 +347,14 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
  * directory (key: hash of the generated source, options and hiprtc version).
  * ivp_rhs_compile_events: the snippet additionally defines the trait's event functions
  *     __device__ void events(double x, const double* y, double* g, const double* p);   // g[0..n_events)
+ * ivp_rhs_compile_ex: flags & IVP_RHS_HAS_JAC -- the snippet also overrides the trait's Jacobian (src/ivp.rs:67-107;
+ * used by BDF instead of the default forward differences), row-major j[row*n + col], n <= 8:
+ *     __device__ void jac(double x, const double* y, double* j, const double* p);
  */
+#define IVP_RHS_HAS_JAC 1u
 int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, void **handle);
 int ivp_rhs_compile_events(ivp_ctx_t *ctx, const char *source, int32_t n, int32_t n_params, int32_t n_events, void **handle);
+int ivp_rhs_compile_ex(ivp_ctx_t *ctx, const char *source, int32_t n, int32_t n_params, int32_t n_events, uint32_t flags, void **handle);
 void ivp_rhs_free(void *handle);
 
 #ifdef __cplusplus

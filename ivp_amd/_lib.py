@@ -69,7 +69,7 @@ EXPORTS = (
     "ivp_abi_version", "ivp_device_count", "ivp_ctx_create", "ivp_ctx_destroy", "ivp_last_error_string",
     "ivp_ctx_get_stats", "ivp_options_default", "ivp_options_method_defaults", "ivp_rhs_dims", "ivp_rhs_n_events", "ivp_batch_solve",
     "ivp_batch_solve_device", "ivp_batch_submit_device", "ivp_batch_poll", "ivp_batch_wait", "ivp_batch_solve_multi", "ivp_batch_solve_multi_host",
-    "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_free",
+    "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_compile_ex", "ivp_rhs_free",
 )
 
 ERRORS = {
@@ -145,6 +145,8 @@ def load():
     L.ivp_rhs_compile.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.ivp_rhs_compile_events.restype = C.c_int
     L.ivp_rhs_compile_events.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.ivp_rhs_compile_ex.restype = C.c_int
+    L.ivp_rhs_compile_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.ivp_rhs_n_events.restype = C.c_int
     L.ivp_rhs_n_events.argtypes = [C.c_int32]
     L.ivp_rhs_free.restype = None

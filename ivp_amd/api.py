@@ -209,6 +209,11 @@ class Robertson(IVP):  # tests/test_ivp.py:327-333
 
 
 @dataclass
+class RobertsonJac(IVP):  # Robertson + `fn jac` override: the analytic Jacobian (trait IVP::jac, src/ivp.rs:67-107)
+    rhs_id = 15; n = 3; n_params = 0
+
+
+@dataclass
 class StiffVanDerPol(IVP):  # examples/van_der_pol.rs:5-15
     eps: float = 1e-3
     rhs_id = 10; n = 2; n_params = 1
@@ -270,7 +275,7 @@ class Heat1D256(IVP):
 MAX_LANE_N = 8   # largest n of the thread-per-trajectory kernels; above it one wavefront owns a trajectory
 
 BUILTIN = {"linear_decay100": LinearDecay100, "heat1d256": Heat1D256, "sho_ev": SHOZeroEvent, "ball": BouncingBall, "cannon": Cannon, "rational_ev": RationalEvents,
-           "linear": LinearSystem, "robertson": Robertson, "vdp_eps": StiffVanDerPol, "decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
+           "linear": LinearSystem, "robertson": Robertson, "robertson_jac": RobertsonJac, "vdp_eps": StiffVanDerPol, "decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
            "zero": ZeroRhs, "rational": Rational, "exp2": Exp2}
 
 
@@ -287,9 +292,12 @@ class DeviceIVP(IVP):
     rhs_id = 1000
 
     def __init__(self, source: str, n: int, params: Sequence[float] = (), ctx: "Context" = None,
-                 events: Sequence[EventConfig] = ()):
+                 events: Sequence[EventConfig] = (), jac: bool = False):
         """``events``: one EventConfig per event function; ``source`` must then also define
-        ``__device__ void events(double x, const double* y, double* g, const double* p)``."""
+        ``__device__ void events(double x, const double* y, double* g, const double* p)``.
+        ``jac=True``: ``source`` also overrides the trait's Jacobian (src/ivp.rs:67-107), used by BDF in place of the
+        default forward differences: ``__device__ void jac(double x, const double* y, double* j, const double* p)``
+        with ``j[row * n + col]`` (n <= 8)."""
         self.source = source
         self.n = int(n)
         self._params = tuple(float(v) for v in params)
@@ -297,8 +305,8 @@ class DeviceIVP(IVP):
         self._events = list(events)
         self._ctx = ctx or default_context()
         h = C.c_void_p()
-        rc = self._ctx.lib.ivp_rhs_compile_events(self._ctx.handle, source.encode(), self.n, self.n_params,
-                                                  len(self._events), C.byref(h))
+        rc = self._ctx.lib.ivp_rhs_compile_ex(self._ctx.handle, source.encode(), self.n, self.n_params,
+                                              len(self._events), 1 if jac else 0, C.byref(h))
         if rc != 0:
             raise ConfigError(rc, self._ctx.last_error())
         self.handle = h

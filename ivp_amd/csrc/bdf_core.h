@@ -209,6 +209,21 @@ IVP_HD void bdf_fd_jac(double x, const double *y, const double *p, double (&jac)
     }
 }
 
+// f.jac(x, y, &mut j): the problem's own `jac` (an `impl IVP` override: the functor defines
+//     static void jac(double x, const double* y, double (&j)[N][N], const double* p)
+// or, for hiprtc problems, the snippet defines  __device__ void jac(double x, const double* y, double* j /* row-major */, const double* p))
+// when it has one, else the trait's default forward-difference implementation above.
+template <class R, class = void>
+struct HasJac { enum { v = 0 }; };
+template <class R>
+struct HasJac<R, decltype((void)&R::jac)> { enum { v = 1 }; };
+template <class R>
+IVP_HD void bdf_eval_jac(double x, const double *y, const double *p, double (&jac)[R::N][R::N])
+{
+    if constexpr (HasJac<R>::v) R::jac(x, y, jac, p);
+    else bdf_fd_jac<R>(x, y, p, jac);
+}
+
 template <int N>
 struct BdfLane {
     double y[N], d[8][N], jac[N][N], lu[N][N];
@@ -275,7 +290,7 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
     const double hmax = fabs(a.has_max_step ? a.max_step : fabs(L.xend - L.x0));
     R::ode(L.x0, y, f0, L.p);
     double jac[N][N];
-    bdf_fd_jac<R>(L.x0, y, L.p, jac);
+    bdf_eval_jac<R>(L.x0, y, L.p, jac);
     double h_abs;
     if (a.has_first_step) {
         if (a.first_step == 0.0) {   // Err(InvalidStepSize), bdf.rs:192-197
@@ -462,7 +477,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         iters += 1;
     }
     if (!converged) {   // bdf.rs:448-459: refresh the Jacobian at the predictor, halve the step
-        bdf_fd_jac<R>(x_new, y_predict, L.p, S.jac);
+        bdf_eval_jac<R>(x_new, y_predict, L.p, S.jac);
         S.d_njev += 1;
         lu_current = false;
         S.pending_factor = 0.5; S.flags |= IVP_BDF_PENDING;
@@ -575,7 +590,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         order = new_order;
         n_equal = 0;
         lu_current = false;
-        if (new_order != old_order) { bdf_fd_jac<R>(S.x, S.y, L.p, S.jac); S.d_njev += 1; }
+        if (new_order != old_order) { bdf_eval_jac<R>(S.x, S.y, L.p, S.jac); S.d_njev += 1; }
     }
     pack();
     return true;

@@ -1,0 +1,646 @@
+// bdf_group.h -- variable-order BDF(1..5) for LARGE state dimensions (8 < n <= 512): one group of G lanes (a whole
+// 64-lane wavefront for the built-in problems) integrates one trajectory.  Device only.
+//
+// Restates src/methods/bdf.rs:86-732 like bdf_core.h does for n <= 8 -- same control flow, same arithmetic per
+// component -- with the state distributed over the group's lanes (lane l owns components l, l+G, ...: the mapping of
+// rk_group.h, whose GroupRhs / NormOps / OutMap it reuses) and the per-trajectory n x n matrices in memory:
+//   * J and LU = (I - cJ) live in global memory, one contiguous n*n block per trajectory, COLUMN-major, so that
+//     "lane <-> row" makes every column operation a coalesced access;
+//   * lu_decomp (src/matrix/lu.rs:37-125): right-looking elimination with partial pivoting, column by column.  The
+//     pivot search is a group reduction that returns the FIRST row attaining the maximum (the reference's strict `>`
+//     scan); multipliers stay in the owning lanes' registers; the trailing update a[i][j] += a[i][k] * t_j runs over
+//     the columns with rows in lanes.  Every element sees the reference's operations in the reference's order (each
+//     a[i][j] is only ever touched by the lane that owns row i), so the factors are bit-identical;
+//   * lin_solve (src/matrix/linear.rs:55-96): the right-hand side sits in LDS; forward and backward substitution are
+//     2n sequential pivot steps, each a broadcast of b[k] and one column axpy over the owning lanes;
+//   * the forward-difference Jacobian (trait IVP::jac default, src/ivp.rs:67-107) perturbs one component at a time:
+//     n + 1 evaluations of the component-form right-hand side through LDS.
+// The weighted RMS norms use NormOps<GroupRhs>::sum (strict build: index-order sum, the reference's bits).
+// All controller scalars are computed redundantly by every lane, so control flow is group-uniform.
+// Outputs: end state, t_eval sampling and the accepted-step log (dense_output segments are not collected here).
+#pragma once
+
+namespace IVP_NS {
+
+template <class R, int G>
+struct BdfG {
+    using GR = GroupRhs<R, G>;
+    enum { NT = R::N, C = GR::N, P = R::P, NGROUP = IVP_WAVE / G };
+    static __device__ __forceinline__ int gl() { return GR::gl(); }
+    static __device__ __forceinline__ int gi(int c) { return GR::gl() + G * c; }
+    static __device__ __forceinline__ bool own(int c) { return gi(c) < NT; }
+    static __device__ __forceinline__ int wl0() { return ((int)threadIdx.x / G) * G; }   // wave lane of the group's lane 0
+
+    // weighted_rms_scaled (bdf.rs:659-667) over all NT components
+    static __device__ __forceinline__ double wrms(const double *v, const double *scale)
+    {
+        double term[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double denom = scale[c] == 0.0 ? 2.220446049250313e-16 : scale[c];
+            const double ratio = v[c] / denom;
+            term[c] = own(c) ? ratio * ratio : 0.0;
+        }
+        return sqrt(NormOps<GR>::sum(term) / (double)NT);
+    }
+
+    // default IVP::jac (src/ivp.rs:67-107): forward differences; jac is column-major [col * NT + row]
+    static __device__ __forceinline__ void fd_jac(double x, const double (&y)[C], const double *p, double *jac)
+    {
+        double fo[C], fp[C], yp[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) yp[c] = y[c];
+        GR::ode(x, y, fo, p);
+        const double eps = 1.4901161193847656e-08;   // f64::EPSILON.sqrt() = 2^-26
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+#pragma unroll 1
+            for (int ll = 0; ll < G; ++ll) {
+                const int col = ll + G * cc;
+                if (col >= NT) break;
+                const double yo = __shfl(y[cc], wl0() + ll);
+                const double pert = eps * fmax(fabs(yo), 1.0);
+                if (gl() == ll) yp[cc] = yo + pert;
+                GR::ode(x, yp, fp, p);
+                if (gl() == ll) yp[cc] = yo;
+#pragma unroll
+                for (int c = 0; c < C; ++c) if (own(c)) jac[(size_t)col * NT + gi(c)] = (fp[c] - fo[c]) / pert;
+            }
+        }
+    }
+
+    // (value, row) of the first row >= k attaining max |a[row][k]| (NaNs never win; none found -> row = NT)
+    static __device__ __forceinline__ int pivot_row(const double *a, int k)
+    {
+        double lv = -1.0;
+        int li = NT;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int i = gi(c);
+            if (i >= k && i < NT) {
+                const double v = fabs(a[(size_t)k * NT + i]);
+                if (v > lv) { lv = v; li = i; }
+            }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(lv, o);
+            const int oi = __shfl_xor(li, o);
+            if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
+        }
+        return li;
+    }
+
+    // lu_decomp (src/matrix/lu.rs:37-125) in place on the column-major matrix a; pivots to piv[0..NT-2].
+    static __device__ __forceinline__ bool lu_decomp(double *a, uint32_t *piv)
+    {
+        if (NT == 1) return a[0] != 0.0;
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < NT - 1; ++k) {
+            const double akk = a[(size_t)k * NT + k];
+            int m = k;
+            if (akk == akk) { const int r = pivot_row(a, k); m = r < NT ? r : k; }   // |a[k][k]| NaN: every `>` is false
+            if (gl() == 0) piv[k] = (uint32_t)m;
+            const double pivot = a[(size_t)k * NT + m];
+            if (pivot == 0.0) return false;
+            __syncthreads();   // everyone has read column k before the swap
+            if (gl() == 0 && m != k) { a[(size_t)k * NT + m] = akk; a[(size_t)k * NT + k] = pivot; }
+            __syncthreads();
+            const double t = 1.0 / pivot;
+            double mult[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = gi(c);
+                mult[c] = 0.0;
+                if (i > k && i < NT) { mult[c] = -a[(size_t)k * NT + i] * t; a[(size_t)k * NT + i] = mult[c]; }
+            }
+#pragma unroll 1
+            for (int j = k + 1; j < NT; ++j) {
+                double *col = a + (size_t)j * NT;
+                const double tj = col[m], akj = col[k];   // read before anything in this column is written
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int i = gi(c);
+                    if (i > k && i < NT) {
+                        double cur = (i == m) ? akj : col[i];   // row m receives row k's entry (the swap)
+                        if (tj != 0.0) cur += mult[c] * tj;
+                        col[i] = cur;
+                    } else if (i == k) {
+                        col[i] = tj;
+                    }
+                }
+            }
+            __syncthreads();   // column k+1 is complete before the next pivot search reads it
+        }
+        return a[(size_t)(NT - 1) * NT + (NT - 1)] != 0.0;
+    }
+
+    // lin_solve (src/matrix/linear.rs:55-96): b (this lane's components) <- A^-1 b
+    static __device__ __forceinline__ void lin_solve(const double *a, const uint32_t *piv, double (&bl)[C])
+    {
+        __shared__ double rhs_lds[NGROUP * NT];
+        double *b = rhs_lds + GR::gb();
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c) if (own(c)) b[gi(c)] = bl[c];
+        __syncthreads();
+        if (NT == 1) { if (gl() == 0) b[0] /= a[0]; __syncthreads(); bl[0] = b[0]; return; }
+#pragma unroll 1
+        for (int k = 0; k < NT - 1; ++k) {
+            const int m = (int)piv[k];
+            const double t = b[m], bk_old = b[k];
+            __syncthreads();
+            if (gl() == 0) { b[m] = bk_old; b[k] = t; }
+            const double *col = a + (size_t)k * NT;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = gi(c);
+                if (i > k && i < NT) {
+                    const double bi = (i == m) ? bk_old : b[i];
+                    b[i] = bi + col[i] * t;
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int kb = 1; kb < NT; ++kb) {
+            const int k = NT - kb;
+            const double *col = a + (size_t)k * NT;
+            const double bk = b[k] / col[k];
+            __syncthreads();
+            if (gl() == 0) b[k] = bk;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = gi(c);
+                if (i < k) b[i] += col[i] * -bk;
+            }
+            __syncthreads();
+        }
+        const double b0 = b[0] / a[0];
+        __syncthreads();
+        if (gl() == 0) b[0] = b0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c) bl[c] = own(c) ? b[gi(c)] : 0.0;
+    }
+};
+
+// smallest rtol over all components (bdf.rs:174-185)
+template <class R, int G>
+__device__ __forceinline__ double bdfg_rtol_min(const IvpKArgs &a)
+{
+    double r = a.rtol[0];
+    if (a.rtol_dev) {
+        r = u2d(0x7FF0000000000000ull);
+        for (int i = 0; i < R::N; ++i) r = fmin(r, a.rtol_dev[i]);
+    }
+    return fmax(r, 2.220446049250313e-16);
+}
+
+template <class R, bool FULL, int G>
+__device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32_t j)
+{
+    using BG = BdfG<R, G>;
+    using GR = GroupRhs<R, G>;
+    using MAP = typename OutMap<GR>::type;
+    constexpr int C = BG::C, NT = BG::NT, P = R::P;
+    const size_t B = a.B;
+    Lane<C, P> L;
+    double y[C], f0[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) y[c] = map_ld<MAP>(a.y0, c, B, j);
+#pragma unroll
+    for (int c = 0; c < P; ++c) L.p[c] = a.params[c * B + j];
+    L.x0 = a.t0[(size_t)j * a.t0_stride];
+    L.xend = a.t1[(size_t)j * a.t1_stride];
+    L.flags = 0;
+    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    auto store_so = [&]() {
+        if (FULL) {
+            a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
+            a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+        }
+    };
+    a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; a.njev[j] = 0; a.nlu[j] = 0;
+    a.facold[j] = 0.0; a.hlamb[j] = 1.0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { map_st<MAP>(a.y, c, B, j, y[c]); map_st<MAP>(a.k1, c, B, j, 0.0); }
+
+    if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
+        if (FULL) {
+            if (a.n_eval >= 0) {
+                for (int32_t i = 0; i < a.n_eval; ++i)
+                    if (fabs(a.t_eval[i] - L.x0) < 1e-12) so_emit_eval<M_BDF, C, P, MAP>(a, j, L, i, y);
+            } else if (a.t_log != nullptr) {
+                so_push_log<M_BDF, C, P, MAP>(a, j, L, L.x0, y);
+            }
+        }
+        store_so();
+        a.x[j] = L.x0; a.h[j] = 0.0; a.flags[j] = 0; a.status[j] = 0;
+        return 0;
+    }
+    if (L.x0 != L.x0 || L.xend != L.xend) {   // NaN interval: see init_body in rk_core.h
+        store_so();
+        a.x[j] = L.x0; a.h[j] = 0.0; a.flags[j] = 0; a.status[j] = 3;
+        return 3;
+    }
+    const double direction = rs_signum(L.xend - L.x0);
+    const double hmax = fabs(a.has_max_step ? a.max_step : fabs(L.xend - L.x0));
+    GR::ode(L.x0, y, f0, L.p);
+    double *jac = a.bdf_jac + (size_t)j * NT * NT;
+    BG::fd_jac(L.x0, y, L.p, jac);
+    double h_abs;
+    if (a.has_first_step) {
+        if (a.first_step == 0.0) {   // Err(InvalidStepSize), bdf.rs:192-197
+            ivp_flag_error(a, IVP_ERRFLAG_INVALID_STEP);
+            store_so();
+            a.x[j] = L.x0; a.h[j] = 0.0; a.flags[j] = 0; a.status[j] = 0;
+            return 0;
+        }
+        h_abs = fabs(a.first_step);
+    } else {
+        double guess = hinit<GR>(a, L.x0, y, direction, f0, L.p, 1, hmax);
+        const double max_h = fabs(L.xend - L.x0);
+        if (fabs(guess) > max_h) guess = max_h * direction;
+        h_abs = fabs(guess);
+    }
+    h_abs = fmin(h_abs, fmax(hmax, 2.2250738585072014e-308));
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (!MAP::own(c)) continue;
+        const size_t g = (size_t)MAP::gi(c);
+        a.bdf_d[(0 * (size_t)NT + g) * B + j] = y[c];
+        a.bdf_d[(1 * (size_t)NT + g) * B + j] = f0[c] * h_abs * direction;
+#pragma unroll
+        for (int k = 2; k < 8; ++k) a.bdf_d[((size_t)k * NT + g) * B + j] = 0.0;
+    }
+    L.x = L.x0;
+    if (FULL) (void)solout_full<M_BDF, GR>(a, j, L, L.x0, L.x0, y, y, nullptr, 0.0, L.x0);
+    store_so();
+    a.nfev[j] = 1; a.njev[j] = 1;
+    a.x[j] = L.x0; a.h[j] = h_abs;
+    a.flags[j] = (1u << IVP_BDF_ORDER_SHIFT) | (L.flags & IVP_F_FIRSTOUT);
+    a.status[j] = IVP_RUNNING;
+    return IVP_RUNNING;
+}
+
+template <int C>
+struct BdfGLane {
+    double y[C], d[8][C];
+    double x, current_h, current_c, pending_factor, xend, x0, direction, hmax, hmin, rtol_min;
+    uint32_t flags;
+    int32_t status;
+    uint32_t d_nfev, d_njev, d_nlu, d_nstep, d_naccpt, d_nrejct, budget;
+    bool over;
+};
+
+// One pass of the main loop (bdf.rs:276-607). Returns false when the trajectory retired.
+template <class R, bool FULL, int G>
+__device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j, BdfGLane<BdfG<R, G>::C> &S, Lane<BdfG<R, G>::C, R::P> &L,
+                                                  double *jac, double *lu, uint32_t *piv)
+{
+    using BG = BdfG<R, G>;
+    using GR = GroupRhs<R, G>;
+    constexpr int C = BG::C;
+    constexpr BdfTables T{};
+    constexpr double EPS = 2.220446049250313e-16, MIN_POSITIVE = 2.2250738585072014e-308;
+    constexpr int newton_maxiter = 4;
+    int order = (int)((S.flags >> IVP_BDF_ORDER_SHIFT) & 7u);
+    int n_equal = (int)((S.flags >> IVP_BDF_NEQ_SHIFT) & 7u);
+    bool lu_current = (S.flags & IVP_BDF_LU_CURRENT) != 0;
+    auto pack = [&]() {
+        S.flags = (S.flags & ~((7u << IVP_BDF_ORDER_SHIFT) | (7u << IVP_BDF_NEQ_SHIFT) | IVP_BDF_LU_CURRENT)) |
+                  ((uint32_t)order << IVP_BDF_ORDER_SHIFT) | ((uint32_t)n_equal << IVP_BDF_NEQ_SHIFT) |
+                  (lu_current ? IVP_BDF_LU_CURRENT : 0u);
+    };
+
+    if (S.over || S.d_nstep >= S.budget) { S.status = 2; return false; }                 // steps.total >= nmax
+    if (S.current_h < MIN_POSITIVE) { S.status = 3; return false; }
+    double h_try = S.current_h;
+    double h_signed = 0.0, x_new = 0.0;
+    bool finished = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {   // the D-rescalings before the predictor (see bdf_core.h)
+        double factor = 1.0;
+        bool doit = false;
+        if (pass == 0) {
+            if (S.flags & IVP_BDF_PENDING) { factor = S.pending_factor; doit = true; S.flags &= ~IVP_BDF_PENDING; }
+        } else if (pass == 1) {
+            if (h_try > S.hmax) {
+                factor = S.hmax / h_try; doit = true;
+                h_try = S.hmax; S.current_h = h_try; n_equal = 0; lu_current = false;
+            }
+        } else if (pass == 2) {
+            if (h_try < S.hmin && S.hmin > 0.0) {
+                factor = fmax(S.hmin / h_try, 1.0); doit = true;
+                h_try = S.hmin; S.current_h = h_try; n_equal = 0; lu_current = false;
+            }
+        } else {
+            h_signed = S.direction * h_try;
+            x_new = S.x + h_signed;
+            if (S.direction * (x_new - S.xend) > 0.0) {
+                const double step_to_end = fabs(S.xend - S.x);
+                if (step_to_end == 0.0) { finished = true; }
+                else {
+                    factor = step_to_end / h_try; doit = true;
+                    S.current_h *= factor;
+                    h_try = S.current_h;
+                    h_signed = S.direction * h_try;
+                    x_new = S.x + h_signed;
+                    n_equal = 0; lu_current = false;
+                }
+            }
+        }
+        if (doit) bdf_change_d<C>(S.d, order, factor);
+    }
+    if (finished) { pack(); S.status = 0; return false; }
+    if ((S.x + 0.1 * fabs(h_signed)) == S.x) { pack(); S.status = 3; return false; }
+    const double x_start = S.x;
+    S.d_nstep += 1;
+
+    double y_predict[C], scale[C], psi[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k <= order) sum += S.d[k][i];
+        y_predict[i] = sum;
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        scale[i] = NormOps<GR>::atol(a, i) + NormOps<GR>::rtol(a, i) * fabs(y_predict[i]);
+        if (scale[i] == 0.0) scale[i] = EPS;
+    }
+    const double alpha_o = bdf_sel6(T.alpha, order);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int jj = 1; jj < 6; ++jj) if (jj <= order) sacc += T.gamma[jj] * S.d[jj][i];
+        psi[i] = sacc / alpha_o;
+    }
+    const double c = h_signed / alpha_o;
+    bool lu_failed = false;
+    if (!lu_current || fabs(c - S.current_c) / fmax(fabs(c), 1.0) > 0.1) {
+        __syncthreads();
+#pragma unroll 1
+        for (int col = 0; col < BG::NT; ++col) {
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                const int r = BG::gi(cc);
+                if (r < BG::NT) {
+                    double v = -c * jac[(size_t)col * BG::NT + r];
+                    if (r == col) v += 1.0;
+                    lu[(size_t)col * BG::NT + r] = v;
+                }
+            }
+        }
+        S.d_nlu += 1;
+        if (BG::lu_decomp(lu, piv)) { lu_current = true; S.current_c = c; }
+        else lu_failed = true;
+        __syncthreads();
+    }
+    if (lu_failed) {   // bdf.rs:373-381
+        S.pending_factor = 0.5; S.flags |= IVP_BDF_PENDING;
+        S.current_h *= 0.5; n_equal = 0; lu_current = false; S.d_nrejct += 1;
+        pack();
+        return true;
+    }
+
+    double y_new[C], delta[C], rhs[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { y_new[i] = y_predict[i]; delta[i] = 0.0; }
+    bool converged = false, has_prev = false;
+    double dy_norm_prev = 0.0;
+    int iters = 0;
+    double newton_tol = fmax(10.0 * EPS / S.rtol_min, fmin(sqrt(S.rtol_min), 0.03));   // bdf.rs:174-185
+    if (newton_tol <= 0.0) newton_tol = 1e-9;
+#pragma unroll 1
+    while (iters < newton_maxiter) {
+        GR::ode(x_new, y_new, rhs, L.p);
+        S.d_nfev += 1;
+#pragma unroll
+        for (int i = 0; i < C; ++i) rhs[i] = c * rhs[i] - psi[i] - delta[i];
+        BG::lin_solve(lu, piv, rhs);
+        const double dy_norm = BG::wrms(rhs, scale);
+        bool rate_condition = false;
+        if (has_prev && dy_norm_prev > 0.0) {
+            const double rate = dy_norm / dy_norm_prev;
+            if (rate >= 1.0) rate_condition = true;
+            else {
+                const double remaining = (double)(newton_maxiter - iters);
+                const double estimate = ivp_pow(rate, remaining) / (1.0 - rate) * dy_norm;
+                if (estimate > newton_tol) rate_condition = true;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) { y_new[i] += rhs[i]; delta[i] += rhs[i]; }
+        if (dy_norm == 0.0) { converged = true; break; }
+        if (has_prev && dy_norm_prev > 0.0) {
+            const double rate = dy_norm / dy_norm_prev;
+            if (rate < 1.0) {
+                const double estimate = rate / (1.0 - rate) * dy_norm;
+                if (estimate < newton_tol) { converged = true; break; }
+            }
+        }
+        if (rate_condition) break;
+        dy_norm_prev = dy_norm; has_prev = true;
+        iters += 1;
+    }
+    if (!converged) {   // bdf.rs:448-459: refresh the Jacobian at the predictor, halve the step
+        BG::fd_jac(x_new, y_predict, L.p, jac);
+        S.d_njev += 1;
+        lu_current = false;
+        S.pending_factor = 0.5; S.flags |= IVP_BDF_PENDING;
+        S.current_h *= 0.5; n_equal = 0; S.d_nrejct += 1;
+        pack();
+        return true;
+    }
+    const double safety = 0.9 * (2.0 * (double)newton_maxiter + 1.0) / (2.0 * (double)newton_maxiter + (double)(iters + 1));
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        scale[i] = NormOps<GR>::atol(a, i) + NormOps<GR>::rtol(a, i) * fabs(y_new[i]);
+        if (scale[i] == 0.0) scale[i] = EPS;
+    }
+    const double ec_o = bdf_sel6(T.error_const, order);
+#pragma unroll
+    for (int i = 0; i < C; ++i) rhs[i] = ec_o * delta[i];
+    const double error_norm = BG::wrms(rhs, scale);
+    if (error_norm > 1.0) {   // bdf.rs:481-489
+        double factor = safety * ivp_pow(error_norm, -1.0 / ((double)order + 1.0));
+        factor = fmax(factor, 0.2);
+        S.pending_factor = factor; S.flags |= IVP_BDF_PENDING;
+        S.current_h *= factor; n_equal = 0; S.d_nrejct += 1;
+        pack();
+        return true;
+    }
+
+    S.d_naccpt += 1;
+    n_equal += 1;
+    S.x = x_new;
+    double yold[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { yold[i] = S.y[i]; S.y[i] = y_new[i]; }
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+#pragma unroll
+        for (int k = 2; k < 8; ++k) {
+            if (k == order + 2) S.d[k][i] = delta[i] - S.d[k - 1][i];
+        }
+#pragma unroll
+        for (int k = 1; k < 7; ++k) {
+            if (k == order + 1) S.d[k][i] = delta[i];
+        }
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+            if (k <= order) S.d[k][i] += S.d[k + 1][i];
+        }
+    }
+    if (FULL) {
+        double cont[7 * C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            cont[i * 7] = S.d[0][i];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cont[i * 7 + 1 + k] = (k + 1 <= order) ? S.d[k + 1][i] : 0.0;
+            cont[i * 7 + 6] = (double)order;
+        }
+        L.x0 = S.x0;
+        if (solout_full<M_BDF, GR>(a, j, L, S.x - h_signed, S.x, S.y, yold, cont, h_signed, x_start)) { pack(); S.status = 1; return false; }
+    }
+    if (S.direction * (S.x - S.xend) >= 0.0) { pack(); S.status = 0; return false; }
+
+    if (n_equal >= order + 1) {   // order / step adaptation, bdf.rs:551-606
+        double err_m = u2d(0x7FF0000000000000ull), err_p = u2d(0x7FF0000000000000ull);
+        if (order > 1) {
+            const double ecm = bdf_sel6(T.error_const, order - 1);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                double dv = S.d[1][i];
+                IVP_OPAQUE_V(dv);
+#pragma unroll
+                for (int k = 2; k < 6; ++k) { double dk = S.d[k][i]; IVP_OPAQUE_V(dk); dv = (k == order) ? dk : dv; }
+                rhs[i] = ecm * dv;
+            }
+            err_m = BG::wrms(rhs, scale);
+        }
+        if (order < BDF_MAXO) {
+            const double ecp = bdf_sel6(T.error_const, order + 1);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                double dv = S.d[3][i];
+                IVP_OPAQUE_V(dv);
+#pragma unroll
+                for (int k = 4; k < 8; ++k) { double dk = S.d[k][i]; IVP_OPAQUE_V(dk); dv = (k == order + 2) ? dk : dv; }
+                rhs[i] = ecp * dv;
+            }
+            err_p = BG::wrms(rhs, scale);
+        }
+        double factors[3];
+        const double errors[3] = {err_m, error_norm, err_p};
+#pragma unroll 1
+        for (int idx = 0; idx < 3; ++idx) {
+            const double e = idx == 0 ? errors[0] : (idx == 1 ? errors[1] : errors[2]);
+            const double v = ivp_pow(e, -1.0 / ((double)order + (double)idx));
+            if (idx == 0) factors[0] = v; else if (idx == 1) factors[1] = v; else factors[2] = v;
+        }
+        int best = 0;   // Iterator::max_by keeps a later element unless the current maximum is strictly greater
+        double bestv = factors[0];
+        if (!(bestv > factors[1])) { best = 1; bestv = factors[1]; }
+        if (!(bestv > factors[2])) { best = 2; bestv = factors[2]; }
+        int new_order = order;
+        if (best == 0 && order > 1) new_order -= 1;
+        else if (best == 2 && order < BDF_MAXO) new_order += 1;
+        double max_factor = fmax(fmax(fmax(0.0, factors[0]), factors[1]), factors[2]);
+        const double step_factor = fmin(safety * max_factor, 10.0);
+        const int old_order = order;
+        S.pending_factor = step_factor; S.flags |= IVP_BDF_PENDING;   // change_d(d, new_order, step_factor)
+        S.current_h *= step_factor;
+        order = new_order;
+        n_equal = 0;
+        lu_current = false;
+        if (new_order != old_order) { BG::fd_jac(S.x, S.y, L.p, jac); S.d_njev += 1; }
+    }
+    pack();
+    return true;
+}
+
+template <class R, bool FULL, int G>
+__device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
+{
+    using BG = BdfG<R, G>;
+    using GR = GroupRhs<R, G>;
+    using MAP = typename OutMap<GR>::type;
+    constexpr int C = BG::C, NT = BG::NT, P = R::P;
+    const size_t B = a.B;
+    BdfGLane<C> S;
+    Lane<C, P> L;
+#pragma unroll
+    for (int c = 0; c < C; ++c) S.y[c] = map_ld<MAP>(a.y, c, B, j);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int c = 0; c < C; ++c) S.d[k][c] = MAP::own(c) ? a.bdf_d[((size_t)k * NT + MAP::gi(c)) * B + j] : 0.0;
+#pragma unroll
+    for (int c = 0; c < P; ++c) L.p[c] = a.params[c * B + j];
+    double *jac = a.bdf_jac + (size_t)j * NT * NT, *lu = a.bdf_lu + (size_t)j * NT * NT;
+    uint32_t *piv = a.bdf_piv + (size_t)j * NT;
+    S.x = a.x[j];
+    S.current_h = a.h[j];
+    S.current_c = a.facold[j];
+    S.pending_factor = a.hlamb[j];
+    S.flags = a.flags[j];
+    S.x0 = a.t0[(size_t)j * a.t0_stride];
+    S.xend = a.t1[(size_t)j * a.t1_stride];
+    S.direction = rs_signum(S.xend - S.x0);
+    S.hmax = fabs(a.has_max_step ? a.max_step : fabs(S.xend - S.x0));
+    S.hmin = fabs(a.has_min_step ? a.min_step : 0.0);
+    S.rtol_min = bdfg_rtol_min<R, G>(a);
+    S.status = IVP_RUNNING;
+    S.d_nfev = S.d_njev = S.d_nlu = S.d_nstep = S.d_naccpt = S.d_nrejct = 0;
+    const uint64_t nstep0 = a.nstep[j];
+    S.over = nstep0 >= a.nmax;
+    const uint64_t left = S.over ? 0 : a.nmax - nstep0;
+    S.budget = left > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)left;
+    L.flags = S.flags & IVP_F_FIRSTOUT;
+    L.x0 = S.x0;
+    L.kz = 0;
+    if (FULL) {
+        L.next_idx = a.next_idx[j]; L.n_filled = a.n_filled[j]; L.n_log = a.n_log[j];
+        L.n_seg = a.n_seg[j]; L.t_last = a.t_last[j];
+    } else {
+        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    }
+    uint32_t it = 0;
+    bool run = true;
+    while (run && it < a.chunk) {
+        run = bdf_group_attempt<R, FULL, G>(a, j, S, L, jac, lu, piv);
+        ++it;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c) map_st<MAP>(a.y, c, B, j, S.y[c]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int c = 0; c < C; ++c) if (MAP::own(c)) a.bdf_d[((size_t)k * NT + MAP::gi(c)) * B + j] = S.d[k][c];
+    a.x[j] = S.x;
+    a.h[j] = S.status == IVP_RUNNING ? S.current_h : S.direction * S.current_h;   // IntegrationResult.h, bdf.rs:609-614
+    a.facold[j] = S.current_c;
+    a.hlamb[j] = S.pending_factor;
+    a.flags[j] = (S.flags & ~IVP_F_FIRSTOUT) | (L.flags & IVP_F_FIRSTOUT);
+    a.status[j] = S.status;
+    if (BG::gl() == 0) {   // counters are read-modify-write: one lane per trajectory
+        a.nfev[j] += S.d_nfev; a.njev[j] += S.d_njev; a.nlu[j] += S.d_nlu;
+        a.nstep[j] += S.d_nstep; a.naccpt[j] += S.d_naccpt; a.nrejct[j] += S.d_nrejct;
+    }
+    if (FULL) {
+        a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
+        a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+    }
+    status_out = S.status;
+    return it;
+}
+
+}  // namespace IVP_NS

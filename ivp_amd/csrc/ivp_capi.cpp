@@ -25,8 +25,8 @@ namespace {
 
 struct RhsDim { int n, p; };
 const RhsDim kRhsDims[IVP_RHS_BUILTIN_COUNT] = {{1, 1}, {2, 0}, {2, 1}, {6, 1}, {3, 3}, {3, 0}, {2, 0}, {2, 0}, {2, 0}, {3, 0}, {2, 1},
-                                                {2, 0}, {2, 2}, {2, 0}, {2, 0}};
-const int kRhsEvents[IVP_RHS_BUILTIN_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 3};
+                                                {2, 0}, {2, 2}, {2, 0}, {2, 0}, {3, 0}};
+const int kRhsEvents[IVP_RHS_BUILTIN_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 3, 0};
 
 // wave-per-trajectory problems (rk_group.h): ids 100.., n > IVP_MAX_N
 #define IVP_MAX_GROUP_N 512
@@ -155,10 +155,8 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     if (prob->n != n || prob->n_params != p)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "problem dims (n=%d,p=%d) do not match rhs (n=%d,p=%d)", prob->n, prob->n_params, n, p);
     if (n < 1 || n > IVP_MAX_GROUP_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
-    if (n > IVP_MAX_N) {   // wave-per-trajectory kernels: explicit RK methods, scalar tolerances, no events
-        if (opt->method == IVP_BDF)
-            return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "n = %d > %d: BDF is not available for large-n problems", n, IVP_MAX_N);
-    }
+    if (n > IVP_MAX_N && opt->method == IVP_BDF && opt->dense_output)   // wave-per-trajectory BDF (bdf_group.h)
+        return fail(ctx, IVP_ERR_BAD_ARGUMENT, "n = %d > %d: BDF does not collect dense-output segments for large-n problems (t_eval / step log are available)", n, IVP_MAX_N);
     if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
     if (opt->method == IVP_RADAU)
         return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "method %d (RADAU) is not on the accelerated path", opt->method);
@@ -241,6 +239,18 @@ hipError_t pend_launch(ivp_ctx *ctx, int what, const IvpKArgs &ka, uint32_t lane
     return (fast ? ivp_launch_fast : ivp_launch_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
 }
 
+// a kernel launch; when a hiprtc module had to be built for it and the build failed, the context's error string
+// carries the build log (IVP_ERR_JIT) instead of a bare HIP error
+#define LAUNCH_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            if ((ctx)->pend.jit && ivp_jit_last_log((ctx)->pend.prob.jit)[0])                                   \
+                return fail((ctx), IVP_ERR_JIT, "building the kernel for this launch failed: %.400s", ivp_jit_last_log((ctx)->pend.prob.jit)); \
+            return fail((ctx), IVP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                            \
+        }                                                                                                       \
+    } while (0)
+
 // One round = the chunk launches between two host polls of the active count; the still-running ids are compacted on
 // the device from launch to launch.
 // Launch policy.  While the active set still over-subscribes the chip (more than one wave per SIMD:
@@ -302,7 +312,7 @@ int enqueue_round(ivp_ctx *ctx)
         if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
-        HIP_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, lanes, use_hoist, use_coop));
+        LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, lanes, use_hoist, use_coop));
         if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(use_coop ? 1 : 0); }
         ctx->stats.launches += 1;
         if (use_coop) ctx->stats.coop_launches += 1;
@@ -323,7 +333,7 @@ int enqueue_round(ivp_ctx *ctx)
         if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
-        HIP_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, std::min<uint32_t>(lanes, ka.spec_cap), false, true));
+        LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, std::min<uint32_t>(lanes, ka.spec_cap), false, true));
         if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(1); }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 2, counts + ((c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // what the bulk left
         P.c += 1;
@@ -602,7 +612,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         HIP_TRY(ctx, ctx->bdf_d.reserve(sizeof(double) * 8 * n * B));
         HIP_TRY(ctx, ctx->bdf_jac.reserve(sizeof(double) * n * n * B));
         HIP_TRY(ctx, ctx->bdf_lu.reserve(sizeof(double) * n * n * B));
-        HIP_TRY(ctx, ctx->bdf_piv.reserve(sizeof(uint32_t) * B));
+        HIP_TRY(ctx, ctx->bdf_piv.reserve(sizeof(uint32_t) * B * (group ? (size_t)n : 1)));   // large n: [B][n] pivot rows
         a.bdf_d = (double *)ctx->bdf_d.p;
         a.bdf_jac = (double *)ctx->bdf_jac.p;
         a.bdf_lu = (double *)ctx->bdf_lu.p;
@@ -721,7 +731,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     ka.perm_out = nullptr;
     ka.count_out = nullptr;
     if (profile) { P.ev_t0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(P.ev_t0, s)); }
-    HIP_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_INIT, ka, (uint32_t)B, false, false));
+    LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_INIT, ka, (uint32_t)B, false, false));
     if (profile) { P.ev_init1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(P.ev_init1, s)); }
     ctx->stats.init_launches = 1;
     P.active = true;
@@ -1015,11 +1025,18 @@ int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n
 
 int ivp_rhs_compile_events(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, int32_t n_events, void **handle)
 {
+    return ivp_rhs_compile_ex(ctx, ode_source, n, n_params, n_events, 0u, handle);
+}
+
+int ivp_rhs_compile_ex(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, int32_t n_events, uint32_t flags, void **handle)
+{
     if (!ctx || !ode_source || !handle) return IVP_ERR_BAD_ARGUMENT;
     if (n < 1 || n > IVP_MAX_GROUP_N || n_params < 0 || n_params > IVP_MAX_P || n_events < 0 || n_events > 4)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
+    if (flags & ~IVP_RHS_HAS_JAC) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown flags 0x%x", flags);
+    if ((flags & IVP_RHS_HAS_JAC) && n > IVP_MAX_N) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "a jac() override needs n <= %d", IVP_MAX_N);
     std::string log;
-    int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, n_events, handle, &log);
+    int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, n_events, flags, handle, &log);
     if (rc != IVP_OK) ctx->err = log;
     return rc;
 }

@@ -33,10 +33,13 @@ struct JitModule {
 
 struct JitRhs {
     int device, n, np, ne;
+    bool has_jac = false;   // the snippet defines jac(): IVP::jac override (src/ivp.rs:67-107)
     std::string ode_source;
     std::string arch;
     std::mutex mu;
-    std::map<std::tuple<int, int, bool, bool>, JitModule> modules;  // (method, fp_mode, full, ctl)
+    // (device, method, fp_mode, full, ctl): hipModuleLoadData binds a module to the device that is current when it is
+    // loaded, so a handle shared by contexts on several GPUs keeps one module per device
+    std::map<std::tuple<int, int, int, bool, bool>, JitModule> modules;
     std::string log;
 };
 
@@ -54,8 +57,9 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
     s += "#define IVP_HD __device__ __forceinline__\n";
     s += "#define IVP_NS ivp_jit\n";
     s += "#define IVP_USER_NE " + std::to_string(r.ne) + "\n";
+    s += std::string("#define IVP_USER_JAC ") + (r.has_jac ? "1" : "0") + "\n";
     const bool group = r.n > IVP_MAX_N;   // wave-per-trajectory kernels (rk_group.h): user code defines ode_comp()
-    if (group) s += "#define IVP_HOIST 1\n";
+    if (group) s += "#define IVP_HOIST 2\n";   // a lone wave per trajectory: coefficients pinned in registers (rk_core.h KC)
     s += join(k_src_ivp_kargs_h);
     s += "\n// ---- user right-hand side ----\n";
     s += r.ode_source;
@@ -66,6 +70,7 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
         s += join(k_src_bdf_core_h);
         s += join(k_src_rk_global_h);   // compact_append
         s += join(k_src_rk_group_h);
+        s += join(k_src_bdf_group_h);
         std::snprintf(buf, sizeof buf,
                       "namespace ivp_jit { struct RhsUser { enum { N = %d, P = %d, NE = IVP_USER_NE };\n"
                       "  static __device__ __forceinline__ double ode_comp(int i, double x, const double* y, const double* p) { return ::ode_comp(i, x, y, p); }\n"
@@ -87,6 +92,9 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
                   "#if IVP_USER_NE > 0\n"
                   "  static IVP_HD void events(double x, const double* y, double* g, const double* p) { ::events(x, y, g, p); }\n"
                   "#endif\n"
+                  "#if IVP_USER_JAC\n"
+                  "  static IVP_HD void jac(double x, const double* y, double (&j)[N][N], const double* p) { ::jac(x, y, &j[0][0], p); }\n"
+                  "#endif\n"
                   "}; }\n"
                   "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a)\n"
                   "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::any_init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
@@ -107,6 +115,8 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
 
 // Optional on-disk cache of compiled code objects (hiprtc takes 1-2 s per module): set IVP_JIT_CACHE_DIR to an
 // existing directory.  Key = FNV-1a of the complete generated source, the compile options and the hiprtc version.
+// The directory must be PRIVATE to the user and trusted: entries are GPU code objects that are loaded and run as they
+// are found (the 64-bit key locates an entry, it does not authenticate it).
 std::string cache_path(const std::string &src, const std::string &opts)
 {
     const char *dir = std::getenv("IVP_JIT_CACHE_DIR");
@@ -193,10 +203,11 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitM
 
 int ivp_jit_n_events(void *handle) { return handle ? ((JitRhs *)handle)->ne : 0; }
 
-int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, int n_events, void **handle, std::string *log)
+int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, int n_events, unsigned flags, void **handle, std::string *log)
 {
     JitRhs *r = new JitRhs();
     r->device = device;
+    r->has_jac = (flags & IVP_RHS_HAS_JAC) != 0;
     r->n = n;
     r->np = n_params;
     r->ne = n_events;
@@ -210,7 +221,8 @@ int ivp_jit_compile(int device, const char *ode_source, int n, int n_params, int
         r->arch = "gfx950";
     }
     // compile the default configuration now so that syntax errors surface at ivp_rhs_compile() time
-    const int rc = compile_module(*r, IVP_DOPRI5, IVP_FP_STRICT, n_events > 0, false, nullptr);
+    int rc = compile_module(*r, IVP_DOPRI5, IVP_FP_STRICT, n_events > 0, false, nullptr);
+    if (rc == IVP_OK && r->has_jac) rc = compile_module(*r, IVP_BDF, IVP_FP_STRICT, n_events > 0, false, nullptr);   // jac() is only instantiated by BDF
     if (rc != IVP_OK) {
         if (log) *log = r->log;
         delete r;
@@ -229,6 +241,8 @@ void ivp_jit_free(void *handle)
     delete r;
 }
 
+const char *ivp_jit_last_log(void *handle) { return handle ? ((JitRhs *)handle)->log.c_str() : ""; }
+
 void ivp_jit_dims(void *handle, int *n, int *np)
 {
     JitRhs *r = (JitRhs *)handle;
@@ -244,14 +258,13 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool 
     {
         std::lock_guard<std::mutex> lk(r->mu);
         const bool ctl = a.has_ctl != 0;
-        auto key = std::make_tuple(method, fp_mode, full, ctl);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+        auto key = std::make_tuple(dev, method, fp_mode, full, ctl);
         auto it = r->modules.find(key);
         if (it == r->modules.end()) {
             JitModule nm;
-            if (compile_module(*r, method, fp_mode, full, ctl, &nm) != IVP_OK) {
-                std::fprintf(stderr, "ivp_hip: JIT build failed: %s\n", r->log.c_str());
-                return hipErrorInvalidValue;
-            }
+            if (compile_module(*r, method, fp_mode, full, ctl, &nm) != IVP_OK) return hipErrorInvalidValue;   // r->log says why (ivp_jit_last_log)
             it = r->modules.emplace(key, nm).first;
         }
         m = it->second;

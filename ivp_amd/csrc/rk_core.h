@@ -307,6 +307,16 @@ struct RhsRobertson {   // tests/test_ivp.py:327-333
         d[2] = 3e7 * y * y;
     }
 };
+// Robertson with an `impl IVP { fn jac(..) }` override (src/ivp.rs:67-107): the analytic Jacobian, j[row][col]
+struct RhsRobertsonJac : RhsRobertson {
+    static IVP_HD void jac(double, const double *s, double (&j)[3][3], const double *)
+    {
+        const double y = s[1], z = s[2];
+        j[0][0] = -0.04;  j[0][1] = 1e4 * z;              j[0][2] = 1e4 * y;
+        j[1][0] = 0.04;   j[1][1] = -1e4 * z - 6e7 * y;   j[1][2] = -1e4 * y;
+        j[2][0] = 0.0;    j[2][1] = 6e7 * y;              j[2][2] = 0.0;
+    }
+};
 struct RhsVdpEps {   // examples/van_der_pol.rs:9-14
     enum { N = 2, P = 1, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *p)

@@ -137,13 +137,20 @@ struct NormOps<GroupRhs<R, G>, void> {
     }
 };
 
+// BDF for large n (bdf_group.h, included after this header)
+template <class R, bool FULL, int G>
+__device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32_t j);
+template <class R, bool FULL, int G>
+__device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out);
+
 // init: one group of G lanes per trajectory, 64 / G trajectories per wavefront
 template <int M, class R, bool FULL, int G = IVP_WAVE>
 __device__ __forceinline__ void group_init_body(const IvpKArgs &a)
 {
     const uint32_t j = blockIdx.x * (IVP_WAVE / G) + threadIdx.x / G;
     if (j >= a.B) return;
-    (void)init_body<M, GroupRhs<R, G>, FULL>(a, j);
+    if constexpr (M == M_BDF) (void)bdf_group_init_body<R, FULL, G>(a, j);
+    else (void)init_body<M, GroupRhs<R, G>, FULL>(a, j);
 }
 
 // up to a.chunk step attempts for the trajectories of this wave; controller fields from IvpKArgs (CTL = true)
@@ -163,7 +170,10 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
     int32_t st = 0;
     uint32_t it = 0;
     constexpr bool kCtl = M == M_RK23 || M == M_DOPRI5 || M == M_DOP853;
-    if (active) it = chunk_body<M, GroupRhs<R, G>, FULL, kCtl>(a, j, st);
+    if (active) {
+        if constexpr (M == M_BDF) it = bdf_group_chunk_body<R, FULL, G>(a, j, st);
+        else it = chunk_body<M, GroupRhs<R, G>, FULL, kCtl>(a, j, st);
+    }
     const bool lead = (threadIdx.x & (G - 1)) == 0;
     compact_append(a, j, active && lead && st == IVP_RUNNING);   // still running: next launch's list
     if (a.slot_counter) {

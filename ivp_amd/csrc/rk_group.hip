@@ -20,6 +20,7 @@
 #include "bdf_core.h"
 #include "rk_global.h"
 #include "rk_group.h"
+#include "bdf_group.h"
 #include "rk_coop.h"
 #include "rk_launch.h"
 
@@ -45,6 +46,7 @@ hipError_t launch_group(int what, int method, bool full, const IvpKArgs &a, uint
     case M_DOPRI5: return full ? launch_group_one<M_DOPRI5, R, true>(what, a, n, s) : launch_group_one<M_DOPRI5, R, false>(what, a, n, s);
     case M_DOP853: return full ? launch_group_one<M_DOP853, R, true>(what, a, n, s) : launch_group_one<M_DOP853, R, false>(what, a, n, s);
     case M_RK4: return full ? launch_group_one<M_RK4, R, true>(what, a, n, s) : launch_group_one<M_RK4, R, false>(what, a, n, s);
+    case M_BDF: return full ? launch_group_one<M_BDF, R, true>(what, a, n, s) : launch_group_one<M_BDF, R, false>(what, a, n, s);
     }
     return hipErrorInvalidValue;
 }
@@ -94,6 +96,7 @@ hipError_t IVP_COOP_LAUNCH_NAME(int method, int rhs_id, bool full, const IvpKArg
     case 12: return launch_coop<IVP_NS::RhsBall>(method, full, a, trajectories, s);
     case 13: return launch_coop<IVP_NS::RhsCannon>(method, full, a, trajectories, s);
     case 14: return launch_coop<IVP_NS::RhsRationalEv>(method, full, a, trajectories, s);
+    case 15: return launch_coop<IVP_NS::RhsRobertsonJac>(method, full, a, trajectories, s);
     }
     return hipErrorInvalidValue;
 }

@@ -104,6 +104,7 @@ hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const Iv
     case 12: return launch_rhs<IVP_NS::RhsBall>(what, method, full, a, lanes, s);
     case 13: return launch_rhs<IVP_NS::RhsCannon>(what, method, full, a, lanes, s);
     case 14: return launch_rhs<IVP_NS::RhsRationalEv>(what, method, full, a, lanes, s);
+    case 15: return launch_rhs<IVP_NS::RhsRobertsonJac>(what, method, full, a, lanes, s);
     }
     return hipErrorInvalidValue;
 }

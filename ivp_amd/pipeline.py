@@ -35,13 +35,20 @@ class BatchPipeline:
         """``batches``: dicts with keys t0, t1, y0, params (CUDA tensors / scalars as for solve_ivp_batch).  Results
         come back in input order.  ``out_per_context``: one reusable BatchSolution per stream (results of different
         batches then alias: consume them in ``on_done``)."""
+        import time
         import torch
         results: List[Optional[api.BatchSolution]] = [None] * len(batches)
         nxt = 0
         inflight: List[Optional[tuple]] = [None] * len(self.ctxs)   # (batch index, PendingBatch) per context
         remaining = len(batches)
+        # the inputs may have been produced by work still queued on the caller's stream: every side stream starts
+        # behind it, and the caller's stream is made to wait for the side streams at the end (results are consumed there)
+        caller = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            st.wait_stream(caller)
         try:
             while remaining:
+                progressed = False
                 for w in range(len(self.ctxs)):
                     if inflight[w] is not None:
                         k, pend = inflight[w]
@@ -49,6 +56,7 @@ class BatchPipeline:
                             results[k] = pend.result()
                             inflight[w] = None
                             remaining -= 1
+                            progressed = True
                             if on_done is not None:
                                 on_done(k, results[k])
                     if inflight[w] is None and nxt < len(batches):
@@ -58,7 +66,11 @@ class BatchPipeline:
                             inflight[w] = (nxt, api.solve_ivp_batch(f, b["t0"], b["t1"], b["y0"], b.get("params"), options,
                                                                     self.ctxs[w], out, wait=False))
                         nxt += 1
-                # nothing ready: poll again (a round lasts 0.3-2 ms; each poll is one hipEventQuery per context)
+                        progressed = True
+                # nothing ready: poll again (a round lasts 0.3-2 ms; each poll is one hipEventQuery per context),
+                # yielding the core between sweeps instead of spinning flat out
+                if not progressed:
+                    time.sleep(0)
         finally:
             for slot in inflight:   # an exception must not leave solves in flight on the pipeline's contexts
                 if slot is not None:
@@ -66,6 +78,13 @@ class BatchPipeline:
                         slot[1].result()
                     except Exception:
                         pass
+        for st in self.streams:   # results were allocated and written on the side streams: order the caller's stream after them
+            caller.wait_stream(st)
+        for r in results:
+            if r is not None:
+                for t in (r.y_end, r.t_end, r.status, r.nfev, r.nstep, r.naccpt, r.nrejct, r.h_next):
+                    if t is not None and hasattr(t, "record_stream"):
+                        t.record_stream(caller)
         torch.cuda.synchronize(self.device)
         return results  # type: ignore[return-value]
 

@@ -247,13 +247,24 @@ orc_event_fn orc_builtin_events(int rhs_id, int *n_events)
     }
 }
 
+/* `impl IVP { fn jac }` of the Robertson problem: the analytic Jacobian of rhs_robertson */
+static void jac_robertson(double t, const double *s, double *j, const double *p)
+{
+    (void)t; (void)p;
+    const double y = s[1], z = s[2];
+    j[0] = -0.04;  j[1] = 1e4 * z;              j[2] = 1e4 * y;
+    j[3] = 0.04;   j[4] = -1e4 * z - 6e7 * y;   j[5] = -1e4 * y;
+    j[6] = 0.0;    j[7] = 6e7 * y;              j[8] = 0.0;
+}
+orc_jac_fn orc_builtin_jac(int rhs_id) { return rhs_id == ORC_RHS_ROBERTSON_JAC ? jac_robertson : NULL; }
+
 orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *np_out)
 {
     static const struct { orc_ode_fn f; int n, np; } tab[ORC_RHS_COUNT] = {
         {rhs_decay, 1, 1}, {rhs_sho, 2, 0}, {rhs_vdp, 2, 1}, {rhs_cr3bp, 6, 1},
         {rhs_lorenz, 3, 3}, {rhs_zero, 3, 0}, {rhs_rational, 2, 0}, {rhs_exp2, 2, 0},
         {rhs_linear, 2, 0}, {rhs_robertson, 3, 0}, {rhs_vdp_eps, 2, 1},
-        {rhs_sho, 2, 0}, {rhs_ball, 2, 2}, {rhs_cannon, 2, 0}, {rhs_rational, 2, 0},
+        {rhs_sho, 2, 0}, {rhs_ball, 2, 2}, {rhs_cannon, 2, 0}, {rhs_rational, 2, 0}, {rhs_robertson, 3, 0},
     };
     if (rhs_id == ORC_RHS_LINEAR_DECAY_100) { if (n_out) *n_out = 100; if (np_out) *np_out = 0; return rhs_linear_decay100; }
     if (rhs_id == ORC_RHS_HEAT1D_256) { if (n_out) *n_out = 256; if (np_out) *np_out = 1; return rhs_heat1d256; }
@@ -1290,6 +1301,13 @@ static void fd_jac(orc_ode_fn f, const double *p, int n, double x, const double 
     }
 }
 
+/* f.jac(x, y, &mut j): the user's override when the problem has one, else the trait default above */
+static void eval_jac(const orc_options *opt, orc_ode_fn f, const double *p, int n, double x, const double *y, double *jac)
+{
+    if (opt->jac) opt->jac(x, y, jac, p);
+    else fd_jac(f, p, n, x, y, jac);
+}
+
 /* ------------------------------------------------------------------------------------------
  * BDF 1..5 (src/methods/bdf.rs:86-732)
  * ---------------------------------------------------------------------------------------- */
@@ -1370,7 +1388,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
     memcpy(y, y0, (size_t)n * sizeof(double));
     f(x, y, f0, p);
     nfev += 1;
-    fd_jac(f, p, n, x, y, jac);
+    eval_jac(opt, f, p, n, x, y, jac);
     njev += 1;
     int lu_is_current = 0;
     double current_c = 0.0;
@@ -1500,7 +1518,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
             iters += 1;
         }
         if (!converged) {
-            fd_jac(f, p, n, x_new, y_predict, jac);
+            eval_jac(opt, f, p, n, x_new, y_predict, jac);
             njev += 1;
             lu_is_current = 0;
             change_d(d, n, order, 0.5);
@@ -1568,7 +1586,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
             order = new_order;
             n_equal_steps = 0;
             lu_is_current = 0;
-            if (new_order != old_order) { fd_jac(f, p, n, x, y, jac); njev += 1; }
+            if (new_order != old_order) { eval_jac(opt, f, p, n, x, y, jac); njev += 1; }
         }
     }
     res->h = direction * current_h; res->status = status;
@@ -1772,6 +1790,9 @@ int64_t orc_batch_solve(int rhs_id, size_t B, const double *y0, const double *pa
     int n = 0, np = 0;
     orc_ode_fn f = orc_builtin_rhs(rhs_id, &n, &np);
     if (!f) return ORC_ERR_BAD_ARGUMENT;
+    orc_options opt_j = *opt;           /* a built-in problem with an analytic jac override brings it along */
+    if (!opt_j.jac) opt_j.jac = orc_builtin_jac(rhs_id);
+    opt = &opt_j;
     int64_t total = 0;
     int err = 0;
     (void)threads;

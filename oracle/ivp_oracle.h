@@ -70,7 +70,8 @@ enum {
     ORC_RHS_BALL = 12,    /* examples/bouncing_ball.rs            p={g,drag}     n=2, event g = y0 */
     ORC_RHS_CANNON = 13,  /* tests/test_ivp.py:152-170                           n=2, event g = y0 */
     ORC_RHS_RATIONAL_EV = 14, /* tests/test_ivp.py:345-353: rational + 3 events  n=2 */
-    ORC_RHS_COUNT = 15,
+    ORC_RHS_ROBERTSON_JAC = 15, /* Robertson with the analytic IVP::jac override (src/ivp.rs:67-107)  n=3 */
+    ORC_RHS_COUNT = 16,
     /* large-n problems (wave-per-trajectory kernels on the GPU side) */
     ORC_RHS_LINEAR_DECAY_100 = 100, /* benches/benchmark.py:40-42,139-148             n=100 */
     ORC_RHS_HEAT1D_256 = 101        /* y_i' = kappa (y_{i-1} - 2 y_i + y_{i+1}), p={kappa}  n=256 */
@@ -78,6 +79,7 @@ enum {
 
 typedef void (*orc_ode_fn)(double x, const double *y, double *dydx, const double *p);
 typedef void (*orc_event_fn)(double x, const double *y, double *g, const double *p);   /* IVP::events, src/ivp.rs:31-40 */
+typedef void (*orc_jac_fn)(double x, const double *y, double *jac, const double *p);   /* IVP::jac override, jac[row*n+col] */
 #define ORC_MAX_EVENTS 4
 #define ORC_MAX_N 512   /* largest state dimension the fixed-size work arrays accept */
 
@@ -113,6 +115,9 @@ typedef struct {
     int has_settings;
     double uround, safety_factor, scale_min, scale_max, beta;
     uint64_t stiff_test;
+    /* trait IVP::jac (src/ivp.rs:67-107): NULL = the default forward-difference implementation; else the user's
+     * override, called wherever BDF calls f.jac() (bdf.rs: start, Newton failure, order change) */
+    orc_jac_fn jac;
 } orc_options;
 
 /* Solution (src/solve/solution.rs:7-20) minus events. Owned by the library; free with orc_solution_free. */
@@ -152,6 +157,7 @@ enum {
 
 orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *n_params_out);
 orc_event_fn orc_builtin_events(int rhs_id, int *n_events);
+orc_jac_fn orc_builtin_jac(int rhs_id);   /* analytic Jacobian override of a built-in problem, or NULL */
 
 /* solve_ivp (src/solve/solve_ivp.rs:99-313) for one trajectory. Returns ORC_OK or a negative error. */
 int orc_solve_ivp(orc_ode_fn f, const double *params, int n, double x0, double xend,

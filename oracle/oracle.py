@@ -18,9 +18,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3, "BDF": 5}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
        "linear": 8, "robertson": 9, "vdp_eps": 10, "sho_ev": 11, "ball": 12, "cannon": 13, "rational_ev": 14,
-       "linear_decay100": 100, "heat1d256": 101}
+       "robertson_jac": 15, "linear_decay100": 100, "heat1d256": 101}
 RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0),
-            8: (2, 0), 9: (3, 0), 10: (2, 1), 11: (2, 0), 12: (2, 2), 13: (2, 0), 14: (2, 0), 100: (100, 0), 101: (256, 1)}
+            8: (2, 0), 9: (3, 0), 10: (2, 1), 11: (2, 0), 12: (2, 2), 13: (2, 0), 14: (2, 0), 15: (3, 0), 100: (100, 0), 101: (256, 1)}
 STATUS = ["Success", "UserInterrupt", "NeedLargerNMax", "StepSizeTooSmall", "ProbablyStiff",
           "SingularMatrix", "PoorConvergence"]
 
@@ -40,6 +40,7 @@ class _Options(C.Structure):
         ("attempt_guard", C.c_uint64),
         ("has_settings", C.c_int), ("uround", C.c_double), ("safety_factor", C.c_double), ("scale_min", C.c_double),
         ("scale_max", C.c_double), ("beta", C.c_double), ("stiff_test", C.c_uint64),
+        ("jac", C.c_void_p),
     ]
 
 
@@ -92,6 +93,8 @@ def lib(detpow: bool = False):
         L.orc_builtin_rhs.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_builtin_events.restype = C.c_void_p
         L.orc_builtin_events.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.orc_builtin_jac.restype = C.c_void_p
+        L.orc_builtin_jac.argtypes = [C.c_int]
         L.orc_solve_ivp.restype = C.c_int
         L.orc_solve_ivp.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double,
                                     C.POINTER(C.c_double), C.POINTER(_Options), C.POINTER(_Solution)]
@@ -222,7 +225,7 @@ class OracleSolution:
 
 
 def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Sequence[float] = (),
-              detpow: bool = False, events=None, n_events: int = 0, **options) -> OracleSolution:
+              detpow: bool = False, events=None, n_events: int = 0, jac=None, **options) -> OracleSolution:
     """One reference-style ``solve_ivp`` call.  ``fun`` is a built-in RHS name (see ``RHS``) or a
     Python callable ``f(x, y, p) -> dydx`` (slow; small cases only)."""
     L = lib(detpow)
@@ -260,6 +263,18 @@ def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Seque
         evp = L.orc_builtin_events(RHS[fun], C.byref(ne))
         if evp:
             oh.c.events, oh.c.n_events = evp, ne.value
+    keep_jac = None
+    if jac is not None:   # Python callable J = jac(x, y, p) -> n x n (the trait's jac override, src/ivp.rs:67-107)
+        def _jac_tramp(x, yp, jp, pp):
+            yy = np.ctypeslib.as_array(yp, shape=(n,))
+            pv = np.ctypeslib.as_array(pp, shape=(pa.size,))
+            J = np.asarray(jac(x, yy, pv), dtype=np.float64).reshape(n * n)
+            for i in range(n * n):
+                jp[i] = J[i]
+        keep_jac = _ODE_FN(_jac_tramp)
+        oh.c.jac = C.cast(keep_jac, C.c_void_p).value
+    elif isinstance(fun, str):
+        oh.c.jac = L.orc_builtin_jac(RHS[fun])
     s = _Solution()
     rc = L.orc_solve_ivp(fptr, _dptr(pa), n, float(x0), float(xend), _dptr(y0a), C.byref(oh.c), C.byref(s))
     if rc != 0:
@@ -278,7 +293,7 @@ def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Seque
         m = s.ev_len[i]
         out.t_events.append(np.ctypeslib.as_array(s.t_events[i], shape=(m,)).copy() if m else np.zeros(0))
         out.y_events.append(np.ctypeslib.as_array(s.y_events[i], shape=(m, n)).copy() if m else np.zeros((0, n)))
-    del keep
+    del keep, keep_jac
     return out
 
 

@@ -83,6 +83,7 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
     case 12: rc = run_rhs<RhsBall>(method, full, a, chunks); break;
     case 13: rc = run_rhs<RhsCannon>(method, full, a, chunks); break;
     case 14: rc = run_rhs<RhsRationalEv>(method, full, a, chunks); break;
+    case 15: rc = run_rhs<RhsRobertsonJac>(method, full, a, chunks); break;
     }
     if (rc == 0 && (err_flag & 0x1u)) return -5;  // IVP_ERR_INVALID_STEP_SIZE
     return rc;

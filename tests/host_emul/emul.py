@@ -44,7 +44,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
 
 _libs = {}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
-       "linear": 8, "robertson": 9, "vdp_eps": 10, "sho_ev": 11, "ball": 12, "cannon": 13, "rational_ev": 14}
+       "linear": 8, "robertson": 9, "vdp_eps": 10, "sho_ev": 11, "ball": 12, "cannon": 13, "rational_ev": 14, "robertson_jac": 15}
 RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0),
             8: (2, 0), 9: (3, 0), 10: (2, 1), 11: (2, 0), 12: (2, 2), 13: (2, 0), 14: (2, 0)}
 RHS_NE = {11: 1, 12: 1, 13: 1, 14: 3}

@@ -155,3 +155,51 @@ def test_detpow_substitution_statistics_on_the_full_c2_horizon():
     assert same_steps > 0.90 and rel_steps < 1e-3
     assert np.median(delta) < 1e-2 * np.median(err_libm)               # the substitution is invisible next to the method's error
     assert np.median(err_det) < 1.5 * np.median(err_libm) and err_det.max() < 10 * err_libm.max()   # BASELINE: within 10x of the CPU reference
+
+
+# ---- trait IVP::jac override (src/ivp.rs:67-107) ---------------------------------------------------------------------
+def _rob_jac(t, s, p):
+    y, z = s[1], s[2]
+    return [[-0.04, 1e4 * z, 1e4 * y], [0.04, -1e4 * z - 6e7 * y, -1e4 * y], [0.0, 6e7 * y, 0.0]]
+
+
+def test_oracle_robertson_with_analytic_jacobian():  # tests/test_ivp.py:327-342 budgets, with the `jac` override
+    fd = O.solve_ivp("robertson", 0.0, 1e8, [1e4, 0.0, 0.0], method="BDF", rtol=1e-6, atol=1e-6)
+    an = O.solve_ivp("robertson_jac", 0.0, 1e8, [1e4, 0.0, 0.0], method="BDF", rtol=1e-6, atol=1e-6)
+    assert an.status == 0 and an.nfev < 5000 and an.njev < 200
+    np.testing.assert_allclose(an.y[-1], fd.y[-1], rtol=1e-3)
+    assert abs(an.y[-1].sum() - 1e4) < 1e-2 * 1e4 * 1e-3          # mass conservation of the kinetics
+    # a Python callable as the override is the same function
+    py = O.solve_ivp(lambda t, s, p: [-0.04 * s[0] + 1e4 * s[1] * s[2], 0.04 * s[0] - 1e4 * s[1] * s[2] - 3e7 * s[1] * s[1], 3e7 * s[1] * s[1]],
+                     0.0, 1e8, [1e4, 0.0, 0.0], jac=_rob_jac, method="BDF", rtol=1e-6, atol=1e-6)
+    assert py.njev == an.njev and py.nfev == an.nfev and np.array_equal(py.y[-1], an.y[-1])
+
+
+@pytest.mark.gpu
+def test_gpu_jac_override_builtin_and_hiprtc():
+    import ivp_amd
+    opt = ivp_amd.Options(method="BDF", rtol=1e-6, atol=1e-6)
+    o = O.solve_ivp("robertson_jac", 0.0, 1e8, [1e4, 0.0, 0.0], method="BDF", rtol=1e-6, atol=1e-6, detpow=True)
+    s = ivp_amd.solve_ivp(ivp_amd.RobertsonJac(), 0.0, 1e8, [1e4, 0.0, 0.0], opt)
+    assert s.status == ivp_amd.Status.Success and s.nfev < 5000 and s.njev < 200          # tests/test_ivp.py:327-342
+    assert (s.nfev, s.njev, s.nlu, s.naccpt) == (o.nfev, o.njev, o.nlu, o.naccpt) and np.array_equal(s.y, o.y) and np.array_equal(s.t, o.t)
+    src = r"""
+    __device__ void ode(double t, const double* s, double* d, const double* p)
+    { const double x = s[0], y = s[1], z = s[2];
+      d[0] = -0.04 * x + 1e4 * y * z; d[1] = 0.04 * x - 1e4 * y * z - 3e7 * y * y; d[2] = 3e7 * y * y; }
+    __device__ void jac(double t, const double* s, double* j, const double* p)
+    { const double y = s[1], z = s[2];
+      j[0] = -0.04; j[1] = 1e4 * z;            j[2] = 1e4 * y;
+      j[3] = 0.04;  j[4] = -1e4 * z - 6e7 * y; j[5] = -1e4 * y;
+      j[6] = 0.0;   j[7] = 6e7 * y;            j[8] = 0.0; }
+    """
+    u = ivp_amd.solve_ivp(ivp_amd.DeviceIVP(src, n=3, jac=True), 0.0, 1e8, [1e4, 0.0, 0.0], opt)
+    assert np.array_equal(u.y, s.y) and (u.nfev, u.njev, u.nlu) == (s.nfev, s.njev, s.nlu)
+    # without the override the same problem takes the forward-difference default: different Jacobians, different path
+    fd = ivp_amd.solve_ivp(ivp_amd.Robertson(), 0.0, 1e8, [1e4, 0.0, 0.0], opt)
+    np.testing.assert_allclose(fd.y[-1], s.y[-1], rtol=1e-3)
+    # a batch: bit-exact vs the oracle
+    y0 = np.array([[1e4, 9e3, 1.1e4], [0.0, 0.0, 1.0], [0.0, 10.0, 0.0]])
+    rb = ivp_amd.solve_ivp_batch(ivp_amd.RobertsonJac(), 0.0, 1e5, y0, None, opt)
+    ob = O.solve_batch("robertson_jac", y0, None, 0.0, 1e5, method="BDF", rtol=1e-6, atol=1e-6, detpow=True)
+    assert np.array_equal(rb.y_end, ob["y_end"]) and np.array_equal(rb.njev.astype(np.uint64), ob["njev"])
