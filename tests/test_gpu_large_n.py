@@ -89,8 +89,8 @@ def test_large_n_unsupported_requests_fail_loudly():
     import ivp_amd
     y0 = np.ones((100, 4))
     f = ivp_amd.LinearDecay100()
-    with pytest.raises(ivp_amd.ConfigError) as e:
-        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="BDF"))
+    with pytest.raises(ivp_amd.ConfigError) as e:   # RADAU is not on the accelerated path for any n
+        ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="RADAU"))
     assert e.value.code == -101
     with pytest.raises(ivp_amd.ConfigError) as e:   # Tolerance::Vector of the wrong length (mod.rs:156-161)
         ivp_amd.solve_ivp_batch(f, 0.0, 1.0, y0, None, ivp_amd.Options(method="DOPRI5", rtol=[1e-6] * 99))
@@ -286,3 +286,41 @@ def test_group_width_follows_the_system_size(K, method):
     assert int(s.status) == o.status == 1
     assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
     assert np.array_equal(s.t_events[0], o.t_events[0]) and np.array_equal(s.y_events[0], o.y_events[0])
+
+
+# ---- BDF for large n (bdf_group.h): LU of the per-trajectory n x n matrices by the trajectory's wavefront ----------
+def test_bdf_linear_decay100_equals_the_oracle():
+    """`bdf.rs:86` is generic in n: the reference benchmark's N = 100 system through BDF (forward-difference Jacobian,
+    100 x 100 LU with partial pivoting, Newton) equals the oracle bit for bit, counters included."""
+    y0, p, t0, t1 = _decay_batch(40)
+    for chunk in (0, 3):
+        ref = oracle_batch("linear_decay100", y0, p, t0, t1, method="BDF", rtol=1e-5, atol=1e-8)
+        got = gpu_batch("linear_decay100", y0, p, t0, t1, method="BDF", rtol=1e-5, atol=1e-8, chunk=chunk)
+        assert_bitexact(got, ref, f"bdf decay100 chunk={chunk} ")
+        assert (got["status"] == 0).all() and (got["nlu"] > 0).all()
+    np.testing.assert_allclose(got["y_end"], y0 * np.exp(-t1)[None, :], rtol=0, atol=2e-3)
+
+
+def test_bdf_heat1d256_stiff_equals_the_oracle():
+    """The stiff case the explicit methods give up on (ProbablyStiff above): kappa = 4000 on 256 cells, t = 20.  BDF
+    takes a few dozen steps; pivoting, LU reuse and Jacobian refreshes follow the oracle's path exactly."""
+    y0, p, t0, _ = _heat_batch(12)
+    p[:] = 4000.0
+    ref = oracle_batch("heat1d256", y0, p, t0, 20.0, method="BDF", rtol=1e-4, atol=1e-7)
+    got = gpu_batch("heat1d256", y0, p, t0, 20.0, method="BDF", rtol=1e-4, atol=1e-7)
+    assert_bitexact(got, ref, "bdf heat ")
+    assert (got["status"] == 0).all() and int(got["nstep"].max()) < 2000
+    # outputs: t_eval sampling with the BDF interpolant, vector tolerances
+    te = np.linspace(0.0, 20.0, 9)
+    rt = np.full(256, 1e-4); rt[::2] = 1e-5
+    ref = oracle_batch("heat1d256", y0[:, :4], p[:, :4], t0, 20.0, method="BDF", rtol=rt, atol=1e-7, t_eval=te)
+    got = gpu_batch("heat1d256", y0[:, :4], p[:, :4], t0, 20.0, method="BDF", rtol=rt, atol=1e-7, t_eval=te)
+    assert_bitexact(got, ref, "bdf heat t_eval ")
+    assert np.array_equal(got["n_filled"], ref["n_filled"]) and np.array_equal(got["y_eval"][:9], ref["y_eval"][:9])
+
+
+def test_bdf_large_n_rejects_dense_output():
+    import ivp_amd
+    y0, p, t0, t1 = _decay_batch(2)
+    with pytest.raises(ivp_amd.ConfigError):
+        ivp_amd.solve_ivp_batch(ivp_amd.LinearDecay100(), t0, t1, y0, None, ivp_amd.Options(method="BDF", dense_output=True, max_log=16))
