@@ -270,20 +270,20 @@ int enqueue_round(ivp_ctx *ctx)
     // problems whose stragglers may be handed to the lane-cooperative kernels by a speculative launch (see below)
     const bool spec_ok = P.coop_ok && P.variant == 0 && P.adaptive && P.n >= 4 && P.fp_mode == IVP_FP_STRICT && !P.jit;
     // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
-    // registers; auto = resident once at most two waves per SIMD are left to run
-    // (strict results are bit-identical in both variants, so the choice may follow the shrinking active set;
-    //  fast-mode FMA fusion differs between them, so there it is fixed by the batch size to keep every
-    //  trajectory's result independent of what else is in the batch at launch time)
+    // registers, 3 = lane-cooperative.  Strict results are bit-identical in all of them, so in strict mode the choice
+    // follows the shrinking active set: resident once at most two waves per SIMD are left to run, cooperative for the
+    // tail.  Fast-mode FMA fusion differs between the variants, so there the choice must not depend on anything but the
+    // problem itself -- not on the batch size, not on what else is in the batch: resident for n >= 4, lean below
+    // (where the register footprint is small and occupancy is what pays), cooperative only on request (variant 3).
+    const bool fast = P.fp_mode == IVP_FP_FAST;
     const bool use_hoist = !P.has_settings &&   // run-time controller fields exist in the lean builds only
                            (P.variant == 2 ||
-                            (P.variant == 0 && (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) <= 2 * (size_t)kOneWavePerSimd));
+                            (P.variant == 0 && (fast ? P.n >= 4 : (size_t)lanes <= 2 * (size_t)kOneWavePerSimd)));
     // eight lanes per trajectory pay off once the cooperative waves fit two per SIMD, and only for systems
-    // with enough components to share out (measured: 1.3-1.45x at n = 6, break-even at n = 3, a loss at n = 2)
-    // (fast mode: decided by the batch size alone, like the lean / resident choice above)
-    const size_t coop_cap = kCoopCapLanes;   // a cooperative wave keeps its SIMD < 60 % busy: two share one well
+    // with enough components to share out (measured: break-even at n = 3, a loss at n = 2)
+    const size_t coop_cap = kCoopCapLanes;
     const bool use_coop = P.coop_ok && (P.variant == 3 ||
-                                        (P.variant == 0 && P.adaptive && P.n >= 4 &&
-                                         (P.fp_mode == IVP_FP_FAST ? P.B : (size_t)lanes) * 8u <= coop_cap));
+                                        (P.variant == 0 && P.adaptive && P.n >= 4 && !fast && (size_t)lanes * 8u <= coop_cap));
     // Long chunks (one launch per poll) once compaction cannot help any more: in the cooperative kernels, and for
     // problems without a cooperative kernel when the active set fits one wave per SIMD.  A set that will still be
     // handed to the cooperative kernels keeps short chunks + the speculative hand-over whatever its size: an attempt

@@ -470,3 +470,31 @@ def test_pipeline_recovers_after_a_failing_batch():
     good = pipe.map(ivp_amd.CR3BP(), [b, b, b], ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
     ref = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, t1, b["y0"], b["params"], ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
     assert all(torch.equal(g.y_end, ref.y_end) for g in good)
+
+
+def test_fast_mode_results_do_not_depend_on_the_batch():
+    """Fast-mode FMA fusion differs between the kernel variants, so the variant is chosen from the problem alone (never
+    from the batch size or from what else is in the batch): the same trajectories give the same bits in a batch of 300,
+    inside a batch of 140 000 (> the two-waves-per-SIMD threshold the strict-mode policy switches on) and next to
+    trajectories that finish at once."""
+    import torch
+    import ivp_amd
+    dev = torch.device("cuda:0")
+    y0, p, t0, t1 = W.cr3bp_batch(140_000)
+    opt = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=ivp_amd.FpMode.FAST)
+    big = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, 3.0, torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev), opt)
+    sel = np.arange(0, 140_000, 467)
+    small = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, 3.0, torch.as_tensor(np.ascontiguousarray(y0[:, sel]), device=dev),
+                                    torch.as_tensor(np.ascontiguousarray(p[:, sel]), device=dev), opt)
+    idx = torch.as_tensor(sel, device=dev)
+    assert torch.equal(small.y_end, big.y_end[:, idx]) and torch.equal(small.naccpt, big.naccpt[idx]) and torch.equal(small.h_next, big.h_next[idx])
+    t1v = np.full(sel.size, 3.0); t1v[::2] = 1e-3                    # half of the batch retires after a step or two
+    mixed = ivp_amd.solve_ivp_batch(ivp_amd.CR3BP(), t0, torch.as_tensor(t1v, device=dev), torch.as_tensor(np.ascontiguousarray(y0[:, sel]), device=dev),
+                                    torch.as_tensor(np.ascontiguousarray(p[:, sel]), device=dev), opt)
+    assert torch.equal(mixed.y_end[:, 1::2], small.y_end[:, 1::2])
+    y2, p2, _, t2 = W.vdp_batch(150_000)                             # n = 2: the lean variant, whatever the batch size
+    o2 = ivp_amd.Options(method="DOP853", rtol=1e-8, atol=1e-10, fp_mode=ivp_amd.FpMode.FAST)
+    b2 = ivp_amd.solve_ivp_batch(ivp_amd.VanDerPol(), 0.0, 5.0, torch.as_tensor(y2, device=dev), torch.as_tensor(p2, device=dev), o2)
+    s2 = ivp_amd.solve_ivp_batch(ivp_amd.VanDerPol(), 0.0, 5.0, torch.as_tensor(np.ascontiguousarray(y2[:, :100]), device=dev),
+                                 torch.as_tensor(np.ascontiguousarray(p2[:, :100]), device=dev), o2)
+    assert torch.equal(s2.y_end, b2.y_end[:, :100])
