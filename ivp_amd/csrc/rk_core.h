@@ -119,9 +119,33 @@ IVP_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 // ivp_pow takes the common case -- x a positive normal number, e finite and non-zero -- through one
 // straight-line instruction stream (no exec-mask branches: the out-of-range results are selected at the
 // end) and hands everything else to ivp_pow_full.
+#if defined(__HIP_DEVICE_COMPILE__)
+// a * b + c with the wave-uniform c read from an SGPR pair (three-address VOP3 form)
+__device__ __forceinline__ double ivp_fma_sgpr_addend(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+#endif
 IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
 {
+    // Coefficients of the two Horner chains.  In the resident-coefficient build of the thread-per-trajectory kernels
+    // (IVP_HOIST = 1, two waves per SIMD) they are kept OUT of the vector registers: with the constants pinned there LLVM
+    // emits `v_mov_b64 tmp, c; v_fmac_f64 tmp, p, z` per step (a copy to protect the pinned value), whereas an SGPR
+    // operand gives the single three-address `v_fma_f64 p, p, z, s[..]` and the s_xor that re-creates it issues on the
+    // scalar port beside the other wave's vector work.
+#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 1
+    const uint64_t ivp_kzp = IVP_NS::ivp_opaque_zero();
+#define KP(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kzp)
+    // ... and the fused multiply-add is spelled out, because instruction selection otherwise turns fma(p, z, c) with a
+    // freshly made c into the two-address v_fmac_f64 (dst = c), which wants c in a VGPR: two v_mov_b32 per step.
+#define PFMA(a, b, c) IVP_NS::ivp_fma_sgpr_addend((a), (b), (c))
+#else
+#define PFMA(a, b, c) fma((a), (b), (c))
     KC_SCOPE_KZ(kz)
+#define KP(c) KC(c)
+#endif
     (void)kz;
     int k = k0;
     const uint64_t u = d2u(x);
@@ -133,38 +157,38 @@ IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
     k += ex;
     const double t = (m - 1.0) / (m + 1.0);
     const double z = t * t;
-    double p = KC(1.0 / 25.0);
-    p = fma(p, z, KC(1.0 / 23.0));
-    p = fma(p, z, KC(1.0 / 21.0));
-    p = fma(p, z, KC(1.0 / 19.0));
-    p = fma(p, z, KC(1.0 / 17.0));
-    p = fma(p, z, KC(1.0 / 15.0));
-    p = fma(p, z, KC(1.0 / 13.0));
-    p = fma(p, z, KC(1.0 / 11.0));
-    p = fma(p, z, KC(1.0 / 9.0));
-    p = fma(p, z, KC(1.0 / 7.0));
-    p = fma(p, z, KC(1.0 / 5.0));
-    p = fma(p, z, KC(1.0 / 3.0));
+    double p = KP(1.0 / 25.0);
+    p = PFMA(p, z, KP(1.0 / 23.0));
+    p = PFMA(p, z, KP(1.0 / 21.0));
+    p = PFMA(p, z, KP(1.0 / 19.0));
+    p = PFMA(p, z, KP(1.0 / 17.0));
+    p = PFMA(p, z, KP(1.0 / 15.0));
+    p = PFMA(p, z, KP(1.0 / 13.0));
+    p = PFMA(p, z, KP(1.0 / 11.0));
+    p = PFMA(p, z, KP(1.0 / 9.0));
+    p = PFMA(p, z, KP(1.0 / 7.0));
+    p = PFMA(p, z, KP(1.0 / 5.0));
+    p = PFMA(p, z, KP(1.0 / 3.0));
     p = fma(p, z, 1.0);
     const double lnm = (2.0 * t) * p;
-    const double l2 = fma(lnm, KC(0x1.71547652b82fep+0), (double)k);
+    const double l2 = fma(lnm, KP(0x1.71547652b82fep+0), (double)k);
     const double w = e * l2;
     // w >= 1024 -> +inf and w <= -1022 -> 0 are selected at the end; a NaN w (e = +-inf with x == 1) travels through
     const double kd = rint(w);
     const double r = w - kd;
-    const double v = r * KC(0x1.62e42fefa39efp-1);
-    double q = KC(1.0 / 87178291200.0);
-    q = fma(q, v, KC(1.0 / 6227020800.0));
-    q = fma(q, v, KC(1.0 / 479001600.0));
-    q = fma(q, v, KC(1.0 / 39916800.0));
-    q = fma(q, v, KC(1.0 / 3628800.0));
-    q = fma(q, v, KC(1.0 / 362880.0));
-    q = fma(q, v, KC(1.0 / 40320.0));
-    q = fma(q, v, KC(1.0 / 5040.0));
-    q = fma(q, v, KC(1.0 / 720.0));
-    q = fma(q, v, KC(1.0 / 120.0));
-    q = fma(q, v, KC(1.0 / 24.0));
-    q = fma(q, v, KC(1.0 / 6.0));
+    const double v = r * KP(0x1.62e42fefa39efp-1);
+    double q = KP(1.0 / 87178291200.0);
+    q = PFMA(q, v, KP(1.0 / 6227020800.0));
+    q = PFMA(q, v, KP(1.0 / 479001600.0));
+    q = PFMA(q, v, KP(1.0 / 39916800.0));
+    q = PFMA(q, v, KP(1.0 / 3628800.0));
+    q = PFMA(q, v, KP(1.0 / 362880.0));
+    q = PFMA(q, v, KP(1.0 / 40320.0));
+    q = PFMA(q, v, KP(1.0 / 5040.0));
+    q = PFMA(q, v, KP(1.0 / 720.0));
+    q = PFMA(q, v, KP(1.0 / 120.0));
+    q = PFMA(q, v, KP(1.0 / 24.0));
+    q = PFMA(q, v, KP(1.0 / 6.0));
     q = fma(q, v, 0.5);
     q = fma(q, v, 1.0);
     q = fma(q, v, 1.0);
@@ -178,6 +202,8 @@ IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
     res = (w >= 1024.0) ? u2d(0x7FF0000000000000ull) : res;
     return res;
 }
+#undef KP
+#undef PFMA
 IVP_HD double ivp_pow_full(double x, double e, uint64_t kz)
 {
     if (e == 0.0) return 1.0;
