@@ -130,12 +130,12 @@ __device__ __forceinline__ double ivp_fma_sgpr_addend(double a, double b, double
 #endif
 IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
 {
-    // Coefficients of the two Horner chains.  In the resident-coefficient build of the thread-per-trajectory kernels
-    // (IVP_HOIST = 1, two waves per SIMD) they are kept OUT of the vector registers: with the constants pinned there LLVM
+    // Coefficients of the two Horner chains.  In the thread-per-trajectory kernels (IVP_HOIST = 0 / 1: two or more waves
+    // per SIMD) they are kept OUT of the vector registers: with the constants pinned there LLVM
     // emits `v_mov_b64 tmp, c; v_fmac_f64 tmp, p, z` per step (a copy to protect the pinned value), whereas an SGPR
     // operand gives the single three-address `v_fma_f64 p, p, z, s[..]` and the s_xor that re-creates it issues on the
     // scalar port beside the other wave's vector work.
-#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 1
+#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST != 2
     const uint64_t ivp_kzp = IVP_NS::ivp_opaque_zero();
 #define KP(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kzp)
     // ... and the fused multiply-add is spelled out, because instruction selection otherwise turns fma(p, z, c) with a
