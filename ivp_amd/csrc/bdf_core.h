@@ -332,7 +332,7 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
 template <class R, bool FULL>
 IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R::N, R::P> &L)
 {
-    KC_SCOPE
+    KC_SCOPE_KZ(L.kz)
     constexpr int N = R::N, P = R::P;
     constexpr BdfTables T{};
     constexpr double EPS = 2.220446049250313e-16, MIN_POSITIVE = 2.2250738585072014e-308;
@@ -458,7 +458,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
             if (rate >= 1.0) rate_condition = true;
             else {
                 const double remaining = (double)(newton_maxiter - iters);
-                const double estimate = ivp_pow(rate, remaining) / (1.0 - rate) * dy_norm;
+                const double estimate = ivp_pow(rate, remaining, IVP_KZ_ARG) / (1.0 - rate) * dy_norm;
                 if (estimate > newton_tol) rate_condition = true;
             }
         }
@@ -496,7 +496,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     for (int i = 0; i < N; ++i) rhs[i] = ec_o * delta[i];
     const double error_norm = bdf_wrms<N>(rhs, scale);
     if (error_norm > 1.0) {   // bdf.rs:481-489
-        double factor = safety * ivp_pow(error_norm, -1.0 / ((double)order + 1.0));
+        double factor = safety * ivp_pow(error_norm, -1.0 / ((double)order + 1.0), IVP_KZ_ARG);
         factor = fmax(factor, 0.2);
         S.pending_factor = factor; S.flags |= IVP_BDF_PENDING;
         S.current_h *= factor; n_equal = 0; S.d_nrejct += 1;
@@ -572,7 +572,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
 #pragma unroll 1
         for (int idx = 0; idx < 3; ++idx) {
             const double e = idx == 0 ? errors[0] : (idx == 1 ? errors[1] : errors[2]);
-            const double v = ivp_pow(e, -1.0 / ((double)order + (double)idx));
+            const double v = ivp_pow(e, -1.0 / ((double)order + (double)idx), IVP_KZ_ARG);
             if (idx == 0) factors[0] = v; else if (idx == 1) factors[1] = v; else factors[2] = v;
         }
         int best = 0;   // Iterator::max_by keeps a later element unless the current maximum is strictly greater
@@ -634,6 +634,11 @@ IVP_HD uint32_t bdf_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_ou
     S.budget = left > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)left;
     L.flags = S.flags & IVP_F_FIRSTOUT;
     L.x0 = S.x0;
+#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 2
+    L.kz = ivp_opaque_zero_v();   // pinned-coefficient build: see KC() in rk_core.h
+#else
+    L.kz = 0;
+#endif
     if (FULL) {
         L.next_idx = a.next_idx[j]; L.n_filled = a.n_filled[j]; L.n_log = a.n_log[j];
         L.n_seg = a.n_seg[j]; L.t_last = a.t_last[j];

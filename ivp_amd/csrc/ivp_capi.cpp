@@ -234,6 +234,7 @@ hipError_t pend_launch(ivp_ctx *ctx, int what, const IvpKArgs &ka, uint32_t lane
     const bool fast = P.fp_mode == IVP_FP_FAST;
     if (P.jit) return ivp_jit_launch(P.prob.jit, (use_coop && what == IVP_LAUNCH_CHUNK) ? IVP_LAUNCH_COOP : what, P.method, P.fp_mode, P.full, ka, lanes, s);
     if (P.group) return (fast ? ivp_launch_group_fast : ivp_launch_group_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
+    if (P.method == IVP_BDF) return (fast ? ivp_launch_bdf_fast : ivp_launch_bdf_strict)(what, P.prob.rhs_id, P.full, ka, lanes, s);
     if (use_coop && what == IVP_LAUNCH_CHUNK) return (fast ? ivp_launch_coop_fast : ivp_launch_coop_strict)(P.method, P.prob.rhs_id, P.full, ka, lanes, s);
     if (use_hoist) return (fast ? ivp_launch_fast_hoist : ivp_launch_strict_hoist)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
     return (fast ? ivp_launch_fast : ivp_launch_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);

@@ -79,7 +79,7 @@ hipError_t launch_rhs(int what, int method, bool full, const IvpKArgs &a, uint32
     case M_RK4:
         return full ? launch_one<M_RK4, R, true>(what, a, lanes, s) : launch_one<M_RK4, R, false>(what, a, lanes, s);
     case M_BDF:
-        return full ? launch_one<M_BDF, R, true>(what, a, lanes, s) : launch_one<M_BDF, R, false>(what, a, lanes, s);
+        return hipErrorInvalidValue;   // BDF lives in rk_bdf.hip (pinned-coefficient build only)
     }
     return hipErrorInvalidValue;
 }

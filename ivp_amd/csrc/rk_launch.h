@@ -23,3 +23,7 @@ hipError_t ivp_launch_group_fast(int what, int method, int rhs_id, bool full, co
 // DOPRI5 / DOP853, built-in right-hand sides without events
 hipError_t ivp_launch_coop_strict(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
 hipError_t ivp_launch_coop_fast(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+
+// thread-per-trajectory BDF kernels (rk_bdf.hip: pinned-coefficient build, n <= 8)
+hipError_t ivp_launch_bdf_strict(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_bdf_fast(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
