@@ -398,14 +398,18 @@ def cpu_baseline(y0, p, t0, t1):
     except OSError:
         pass
     rej = float(r["nrejct"].sum()) / max(float(r["nstep"].sum()), 1.0)
+    # headline = the faster of the two thread counts (a container's affinity mask may list far more logical CPUs than its
+    # CPU quota lets run at once: 256 threads on a 16-core share is slower than 16); both are reported
+    best_dt, best_threads = (dt, cores) if dt <= dt16 else (dt16, t16)
     return {
-        "value": r["total_accepted"] / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-        "sample": f"the same {nall} CR3BP trajectories, one solve_ivp call each, OpenMP over trajectories "
-                  f"({cores} threads = every core of the affinity mask, median of 5 runs after a warm-up: {dt:.2f} s wall); "
-                  f"{t16} threads: {r['total_accepted'] / dt16:.3e} steps/s; single thread on the first {n1}: {single:.3e} steps/s",
+        "value": r["total_accepted"] / best_dt, "unit": "steps/s", "cores": best_threads, "kind": "port",
+        "sample": f"the same {nall} CR3BP trajectories, one solve_ivp call each, OpenMP over trajectories, median of 5 runs after "
+                  f"a warm-up: {cores} threads (every CPU of the affinity mask) {r['total_accepted'] / dt:.3e} steps/s ({dt:.2f} s wall); "
+                  f"{t16} threads {r['total_accepted'] / dt16:.3e} steps/s ({dt16:.2f} s wall); single thread on the first {n1}: {single:.3e} steps/s",
+        "all_affinity_cpus": cores, "all_affinity_cpus_value": r["total_accepted"] / dt,
         "threads16_value": r["total_accepted"] / dt16, "threads16": t16,
-        "single_core_value": single, "cpu_model": model, "wall_s": dt,
-        "attempts_per_s": float(r["nstep"].sum()) / dt, "rejection_ratio": rej,
+        "single_core_value": single, "cpu_model": model, "wall_s": best_dt,
+        "attempts_per_s": float(r["nstep"].sum()) / best_dt, "rejection_ratio": rej,
         "what": "oracle/ivp_oracle.c: C restatement of the reference (Rust) algorithm; the crate cannot be built here",
         "reference_crate": reference_crate_timing(),
     }
