@@ -118,3 +118,28 @@ def test_c2_full_step_log_fits_in_sum_of_records():
         s = O.solve_ivp("cr3bp", t0, t1, y0[:, b], params=p[:, b], detpow=True, method="DOPRI5", rtol=1e-6, atol=1e-9)
         t, y = r.log_of(b)
         assert np.array_equal(t.cpu().numpy(), s.t) and np.array_equal(y.cpu().numpy(), s.y)
+
+
+def test_csr_step_log_on_every_lane_mapping():
+    """The CSR log goes through the same so_push_log in all three lane mappings: thread per trajectory (variant 1),
+    eight lanes per trajectory (variant 3) and one wavefront per trajectory (n = 256)."""
+    import torch
+    y0, p, t0, t1 = W.cr3bp_batch(600)
+    opt = dict(method="DOP853", rtol=1e-8, atol=1e-11)
+    dev = torch.device("cuda:0")
+    y0d, pd = torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev)
+    a = ivp_amd.solve_ivp_batch_logged(ivp_amd.CR3BP(), t0, 4.0, y0d, pd, ivp_amd.Options(variant=1, **opt))
+    b = ivp_amd.solve_ivp_batch_logged(ivp_amd.CR3BP(), t0, 4.0, y0d, pd, ivp_amd.Options(variant=3, **opt))
+    assert torch.equal(a.log_offsets, b.log_offsets) and torch.equal(a.t_log, b.t_log) and torch.equal(a.y_log, b.y_log)
+    s = O.solve_ivp("cr3bp", t0, 4.0, y0[:, 7], params=p[:, 7], detpow=True, **opt)
+    t, y = b.log_of(7)
+    assert np.array_equal(t.cpu().numpy(), s.t) and np.array_equal(y.cpu().numpy(), s.y)
+    rng = np.random.default_rng(11)
+    x = np.arange(1, 257) / 257.0
+    h0 = np.sin(np.pi * x[:, None] * np.array([1, 2, 3])[None, :]) + 0.05 * rng.standard_normal((256, 3))
+    kappa = np.array([[30.0, 80.0, 200.0]])
+    g = ivp_amd.solve_ivp_batch_logged(ivp_amd.Heat1D256(), 0.0, 0.2, h0, kappa, ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
+    for bb in range(3):
+        s = O.solve_ivp("heat1d256", 0.0, 0.2, h0[:, bb], params=kappa[:, bb], detpow=True, method="DOPRI5", rtol=1e-6, atol=1e-9)
+        t, y = g.log_of(bb)
+        assert np.array_equal(t.cpu().numpy(), s.t) and np.array_equal(y.cpu().numpy(), s.y), bb
