@@ -351,40 +351,38 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     double h_try = S.current_h;
     double h_signed = 0.0, x_new = 0.0;
     bool finished = false;
-    // Up to four D-rescalings before the predictor; one instantiation of change_d (see the header comment).
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        double factor = 1.0;
-        bool doit = false;
-        if (pass == 0) {
-            if (S.flags & IVP_BDF_PENDING) { factor = S.pending_factor; doit = true; S.flags &= ~IVP_BDF_PENDING; }
-        } else if (pass == 1) {
-            if (h_try > S.hmax) {
-                factor = S.hmax / h_try; doit = true;
-                h_try = S.hmax; S.current_h = h_try; n_equal = 0; lu_current = false;
-            }
-        } else if (pass == 2) {
-            if (h_try < S.hmin && S.hmin > 0.0) {
-                factor = fmax(S.hmin / h_try, 1.0); doit = true;
-                h_try = S.hmin; S.current_h = h_try; n_equal = 0; lu_current = false;
-            }
-        } else {
+    // The four D-rescalings that may precede the predictor (a pending one from the previous attempt, the h_max clamp,
+    // the h_min clamp, the last-step clamp; bdf.rs:276-340).  Their conditions only involve scalars, so the scalar
+    // bookkeeping runs first, straight-line, and the rescalings follow in the reference's order through ONE instance of
+    // change_d (it is the fattest helper; a factor of exactly 1.0 is its own early exit).
+    double fpass[4] = {1.0, 1.0, 1.0, 1.0};
+    if (S.flags & IVP_BDF_PENDING) { fpass[0] = S.pending_factor; S.flags &= ~IVP_BDF_PENDING; }
+    if (h_try > S.hmax) {
+        fpass[1] = S.hmax / h_try;
+        h_try = S.hmax; S.current_h = h_try; n_equal = 0; lu_current = false;
+    }
+    if (h_try < S.hmin && S.hmin > 0.0) {
+        fpass[2] = fmax(S.hmin / h_try, 1.0);
+        h_try = S.hmin; S.current_h = h_try; n_equal = 0; lu_current = false;
+    }
+    h_signed = S.direction * h_try;
+    x_new = S.x + h_signed;
+    if (S.direction * (x_new - S.xend) > 0.0) {
+        const double step_to_end = fabs(S.xend - S.x);
+        if (step_to_end == 0.0) { finished = true; }
+        else {
+            fpass[3] = step_to_end / h_try;
+            S.current_h *= fpass[3];
+            h_try = S.current_h;
             h_signed = S.direction * h_try;
             x_new = S.x + h_signed;
-            if (S.direction * (x_new - S.xend) > 0.0) {
-                const double step_to_end = fabs(S.xend - S.x);
-                if (step_to_end == 0.0) { finished = true; }
-                else {
-                    factor = step_to_end / h_try; doit = true;
-                    S.current_h *= factor;
-                    h_try = S.current_h;
-                    h_signed = S.direction * h_try;
-                    x_new = S.x + h_signed;
-                    n_equal = 0; lu_current = false;
-                }
-            }
+            n_equal = 0; lu_current = false;
         }
-        if (doit) bdf_change_d<N>(S.d, order, factor);
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const double factor = pass == 0 ? fpass[0] : (pass == 1 ? fpass[1] : (pass == 2 ? fpass[2] : fpass[3]));
+        if (factor != 1.0) bdf_change_d<N>(S.d, order, factor);
     }
     if (finished) { pack(); S.status = 0; return false; }
     if ((S.x + KC(0.1) * fabs(h_signed)) == S.x) { pack(); S.status = 3; return false; }

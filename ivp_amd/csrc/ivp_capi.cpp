@@ -206,10 +206,12 @@ struct Tune {
     size_t coop_cap_lanes = kCoopCapLanesDefault;
     uint32_t bulk_chunk = 64;        // attempts per bulk launch
     int launches_per_poll = 3;       // bulk launches between two host polls
+    int bdf_lpw = 0;                 // trajectories per wave of the BDF chunk launches: 0 = auto (spread the active set over the SIMDs)
     Tune()
     {
         if (const char *e = getenv("IVP_TUNE_COOP_CAP_LANES")) coop_cap_lanes = (size_t)strtoull(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BULK_CHUNK")) bulk_chunk = (uint32_t)std::max(1l, strtol(e, nullptr, 10));
+        if (const char *e = getenv("IVP_TUNE_BDF_LPW")) bdf_lpw = (int)std::min(64l, std::max(0l, strtol(e, nullptr, 10)));
         if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10)));
     }
 };
@@ -295,10 +297,22 @@ int enqueue_round(ivp_ctx *ctx)
     const bool tail = P.adaptive && (use_coop || (fits_one_wave && !spec_ok));
     const int launches_per_sync = tail ? 1 : tune().launches_per_poll;
     const uint32_t this_chunk = tail ? 1024u : P.chunk;
+    // BDF (thread per trajectory): thin waves.  BASELINE C5's 10 000 trajectories are 157 full waves on a chip with 256 CUs.
+    // A wave pays for the union of its lanes' control flow on every attempt, and (measured, MI355X) a wave that has its
+    // CU to itself runs this branch-heavy kernel fastest: 10.95 ms with 64 lanes per wave (157 waves), 10.5 ms with 40
+    // (250 waves), but 13.7-16.8 ms with 313-625 waves and 11.2 ms with 1000 -- so the active set is spread over at most
+    // one wave per CU, never thinner than 8 lanes.
+    uint32_t lpw = 0;
+    if (P.method == IVP_BDF && !P.group && !P.jit) {
+        const uint32_t cus = 256u;
+        const uint32_t want = tune().bdf_lpw > 0 ? (uint32_t)tune().bdf_lpw : std::max(8u, (lanes + cus - 1u) / cus);
+        lpw = std::min(64u, want);
+    }
     for (int r = 0; r < launches_per_sync; ++r, ++P.c) {
         const uint64_t c = P.c;
         IvpKArgs ka = P.a;
         ka.chunk = this_chunk;
+        ka.lpw = lpw;
         if (c == 0) {
             ka.perm_in = nullptr;
             ka.count_in = nullptr;

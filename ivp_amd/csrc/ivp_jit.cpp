@@ -39,7 +39,7 @@ struct JitRhs {
     std::mutex mu;
     // (device, method, fp_mode, full, ctl): hipModuleLoadData binds a module to the device that is current when it is
     // loaded, so a handle shared by contexts on several GPUs keeps one module per device
-    std::map<std::tuple<int, int, int, bool, bool>, JitModule> modules;
+    std::map<std::tuple<int, int, int, bool, bool, bool>, JitModule> modules;   // ... , lane-cooperative module
     std::string log;
 };
 
@@ -50,7 +50,7 @@ std::string join(const char *const *parts)
     return s;
 }
 
-std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
+std::string build_source(const JitRhs &r, int method, bool full, bool ctl, bool coop_only)
 {
     std::string s;
     s += "typedef unsigned int uint32_t;\ntypedef int int32_t;\ntypedef unsigned long long uint64_t;\ntypedef long long int64_t;\n";
@@ -59,7 +59,7 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
     s += "#define IVP_USER_NE " + std::to_string(r.ne) + "\n";
     s += std::string("#define IVP_USER_JAC ") + (r.has_jac ? "1" : "0") + "\n";
     const bool group = r.n > IVP_MAX_N;   // wave-per-trajectory kernels (rk_group.h): user code defines ode_comp()
-    if (group) s += "#define IVP_HOIST 2\n";   // a lone wave per trajectory: coefficients pinned in registers (rk_core.h KC)
+    if (group || coop_only) s += "#define IVP_HOIST 2\n";   // a wave that owns its SIMD: coefficients pinned in registers (rk_core.h KC)
     s += join(k_src_ivp_kargs_h);
     s += "\n// ---- user right-hand side ----\n";
     s += r.ode_source;
@@ -95,21 +95,24 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl)
                   "#if IVP_USER_JAC\n"
                   "  static IVP_HD void jac(double x, const double* y, double (&j)[N][N], const double* p) { ::jac(x, y, &j[0][0], p); }\n"
                   "#endif\n"
-                  "}; }\n"
-                  "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a)\n"
-                  "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::any_init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
-                  "extern \"C\" __global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void ivp_jit_chunk(const IvpKArgs a)\n"
-                  "{ ivp_jit::chunk_kernel_body<%d, ivp_jit::RhsUser, %s, %s>(a); }\n",
-                  r.n, r.np, method, full ? "true" : "false", method, full ? "true" : "false",
-                  (ctl && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? "true" : "false");
+                  "}; }\n", r.n, r.np);
     s += buf;
-    if ((r.ne == 0 || full) && (method == IVP_DOPRI5 || method == IVP_DOP853)) {   // eight lanes per trajectory for the tail of a batch
+    if (coop_only) {   // eight lanes per trajectory for the tail of a batch: its own module, pinned coefficients
         s += join(k_src_rk_coop_h);
         std::snprintf(buf, sizeof buf,
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_coop(const IvpKArgs a)\n"
                       "{ ivp_jit::coop_chunk_body<%d, ivp_jit::RhsUser, %s>(a); }\n", method, full ? "true" : "false");
         s += buf;
+        return s;
     }
+    std::snprintf(buf, sizeof buf,
+                  "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a)\n"
+                  "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::any_init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
+                  "extern \"C\" __global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void ivp_jit_chunk(const IvpKArgs a)\n"
+                  "{ ivp_jit::chunk_kernel_body<%d, ivp_jit::RhsUser, %s, %s>(a); }\n",
+                  method, full ? "true" : "false", method, full ? "true" : "false",
+                  (ctl && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? "true" : "false");
+    s += buf;
     return s;
 }
 
@@ -131,24 +134,24 @@ std::string cache_path(const std::string &src, const std::string &opts)
     return std::string(dir) + name;
 }
 
-int load_module(JitRhs &r, const std::vector<char> &code, JitModule *out)
+int load_module(JitRhs &r, const std::vector<char> &code, JitModule *out, bool coop_only)
 {
     if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) { r.log = "hipModuleLoadData failed"; return IVP_ERR_HIP; }
+    if (coop_only) {
+        if (hipModuleGetFunction(&out->coop, out->mod, "ivp_jit_coop") != hipSuccess) { r.log = "kernel lookup failed"; return IVP_ERR_HIP; }
+        return IVP_OK;
+    }
     if (hipModuleGetFunction(&out->init, out->mod, "ivp_jit_init") != hipSuccess ||
         hipModuleGetFunction(&out->chunk, out->mod, "ivp_jit_chunk") != hipSuccess) {
         r.log = "kernel lookup failed";
         return IVP_ERR_HIP;
     }
-    if (hipModuleGetFunction(&out->coop, out->mod, "ivp_jit_coop") != hipSuccess) {   // not every module has one
-        out->coop = nullptr;
-        (void)hipGetLastError();   // the failed lookup must not surface as the "last error" of a later launch
-    }
     return IVP_OK;
 }
 
-int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitModule *out)
+int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitModule *out, bool coop_only = false)
 {
-    const std::string src = build_source(r, method, full, ctl);
+    const std::string src = build_source(r, method, full, ctl, coop_only);
     const std::string opt_key = r.arch + (fp_mode == IVP_FP_FAST ? "|fast" : "|strict");
     const std::string cpath = cache_path(src, opt_key);
     if (!cpath.empty()) {
@@ -157,7 +160,7 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitM
             std::vector<char> code((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
             if (!code.empty()) {
                 if (!out) return IVP_OK;
-                if (load_module(r, code, out) == IVP_OK) return IVP_OK;
+                if (load_module(r, code, out, coop_only) == IVP_OK) return IVP_OK;
                 (void)hipGetLastError();   // unreadable cache entry: fall through and compile
             }
         }
@@ -196,7 +199,7 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitM
         }
     }
     if (!out) return IVP_OK;  // compile-only check
-    return load_module(r, code, out);
+    return load_module(r, code, out, coop_only);
 }
 
 }  // namespace
@@ -258,13 +261,15 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool 
     {
         std::lock_guard<std::mutex> lk(r->mu);
         const bool ctl = a.has_ctl != 0;
+        const bool coop = what == IVP_LAUNCH_COOP;   // the cooperative kernel reads the controller fields at run time anyway
+        if (coop && !((r->ne == 0 || full) && (method == IVP_DOPRI5 || method == IVP_DOP853) && r->n <= IVP_MAX_N)) return hipErrorInvalidValue;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-        auto key = std::make_tuple(dev, method, fp_mode, full, ctl);
+        auto key = std::make_tuple(dev, method, fp_mode, full, coop ? false : ctl, coop);
         auto it = r->modules.find(key);
         if (it == r->modules.end()) {
             JitModule nm;
-            if (compile_module(*r, method, fp_mode, full, ctl, &nm) != IVP_OK) return hipErrorInvalidValue;   // r->log says why (ivp_jit_last_log)
+            if (compile_module(*r, method, fp_mode, full, coop ? false : ctl, &nm, coop) != IVP_OK) return hipErrorInvalidValue;   // r->log says why (ivp_jit_last_log)
             it = r->modules.emplace(key, nm).first;
         }
         m = it->second;

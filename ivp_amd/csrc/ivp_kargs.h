@@ -108,4 +108,9 @@ struct IvpKArgs {
     // ---- speculative launch of the lane-cooperative kernel (rk_coop.h) ----
     uint32_t spec_cap;        // != 0: do nothing unless *count_in <= spec_cap (the host enqueued this launch before
                               // it knew the active count; it reads count_in afterwards to see which way it went)
+    // ---- thin waves ----
+    uint32_t lpw;             // trajectories per wavefront of a thread-per-trajectory chunk launch (0 = 64).  A wave executes the
+                              // UNION of its lanes' control flow; when the active set leaves SIMDs idle anyway, fewer lanes per
+                              // wave on more SIMDs cost nothing and shrink that union (BDF: Newton iteration counts, D-rescaling,
+                              // order adaptation, refactorisation and rejection differ from lane to lane on every attempt)
 };

@@ -29,7 +29,8 @@ using namespace IVP_NS;
 template <class R, bool FULL>
 hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {
-    const dim3 grid((lanes + IVP_WAVE - 1) / IVP_WAVE), block(IVP_WAVE);
+    const uint32_t per_wave = (what == IVP_LAUNCH_CHUNK && a.lpw) ? a.lpw : (uint32_t)IVP_WAVE;   // thin waves (ivp_kargs.h)
+    const dim3 grid((lanes + per_wave - 1) / per_wave), block(IVP_WAVE);
     if (grid.x == 0) return hipSuccess;
     (void)hipGetLastError();   // drop a stale error of some earlier runtime call: the value returned below is this launch's
     if (a.has_ctl) return hipErrorInvalidValue;   // BDF has no per-method controller struct on this path

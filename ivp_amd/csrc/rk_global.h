@@ -38,10 +38,11 @@ __global__ __launch_bounds__(IVP_WAVE) void init_kernel_t(const IvpKArgs a)
 template <int M, class R, bool FULL, bool CTL = false>
 __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 {
-    const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x;
+    const uint32_t lpw = a.lpw ? a.lpw : (uint32_t)IVP_WAVE;   // trajectories per wave (thin waves: ivp_kargs.h)
+    const uint32_t i = blockIdx.x * lpw + threadIdx.x;
     const uint32_t count = a.perm_in ? *a.count_in : a.B;
-    if (blockIdx.x * IVP_WAVE >= count) return;  // whole wave beyond the active set (stale grid bound)
-    const bool valid = i < count;
+    if (blockIdx.x * lpw >= count) return;  // whole wave beyond the active set (stale grid bound)
+    const bool valid = threadIdx.x < lpw && i < count;
     uint32_t j = 0;
     bool active = false;
     if (valid) {
