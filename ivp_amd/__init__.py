@@ -9,11 +9,11 @@ from .api import (  # noqa: F401
     FpMode, Heat1D256, LinearDecay100, InterpolationError, IVP, IvpError, LinearSystem, Lorenz, Method, Options, PendingBatch, Rational, Robertson, RobertsonJac, SHO, Solution, Status, StiffVanDerPol,
     VanDerPol, ZeroRhs, default_context, solve_ivp, solve_ivp_batch, solve_ivp_batch_logged,
 )
-from . import workloads  # noqa: F401
+from . import pyfront, workloads  # noqa: F401
 
 __all__ = [
     "BUILTIN", "BouncingBall", "Cannon", "CR3BP", "Direction", "EventConfig", "RationalEvents", "SHOZeroEvent", "BatchSolution", "ConfigError", "Context", "ContinuousOutput", "DeviceIVP", "Exp2",
     "ExponentialDecay", "FpMode", "Heat1D256", "LinearDecay100", "InterpolationError", "IVP", "IvpError", "LinearSystem", "Lorenz", "Method", "Options", "PendingBatch",
     "Rational", "Robertson", "RobertsonJac", "SHO", "Solution", "Status", "StiffVanDerPol", "VanDerPol", "ZeroRhs", "default_context", "solve_ivp",
-    "solve_ivp_batch", "solve_ivp_batch_logged", "workloads",
+    "solve_ivp_batch", "solve_ivp_batch_logged", "pyfront", "workloads",
 ]

@@ -472,6 +472,8 @@ def default_context(device: int = 0) -> Context:
 # ------------------------------------------------------------------------------------------------
 def _interpolate(method: Method, xi: float, cont: np.ndarray, n: int, xold: float, h: float) -> np.ndarray:
     """dopri5.rs:467-478, dop853.rs:659-670, rk23.rs:313-321 (same association)."""
+    if n == 0:
+        return np.zeros(0)
     c = cont.reshape(-1, n)
     if method == Method.DOPRI5:
         th = (xi - xold) / h

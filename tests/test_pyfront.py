@@ -1,0 +1,298 @@
+"""The reference's Python test-suite (tests/test_ivp.py, adapted there from SciPy's) restated against
+``ivp_amd.pyfront.solve_ivp``: same arguments, same assertions, with the Python callables written as device code."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_equal
+
+from ivp_amd import api
+from ivp_amd.pyfront import Event, OdeResult, solve_ivp
+
+gpu = pytest.mark.gpu
+EXPLICIT = ["RK23", "RK45", "DOP853"]
+METHODS = EXPLICIT + ["BDF"]
+
+FUN_RATIONAL = "dydx[0] = y[1] / x; dydx[1] = y[1] * (y[0] + 2 * y[1] - 1) / (x * (y[0] - 1));"   # test_ivp.py:44-46
+JAC_RATIONAL = ("j[0] = 0; j[1] = 1 / x; j[2] = -2 * y[1] * y[1] / (x * (y[0] - 1) * (y[0] - 1));"
+                "j[3] = (y[0] + 4 * y[1] - 1) / (x * (y[0] - 1));")                                 # test_ivp.py:55-60
+FUN_LINEAR = "dydx[0] = -y[0] - 5 * y[1]; dydx[1] = y[0] + y[1];"                                  # test_ivp.py:31-32
+
+
+def sol_rational(t):
+    return np.asarray((t / (t + 10), 10 * t / (t + 10) ** 2))
+
+
+def sol_linear(t):
+    return np.vstack((-5 * np.sin(2 * t), 2 * np.cos(2 * t) + np.sin(2 * t)))
+
+
+def compute_error(y, y_true, rtol, atol):   # test_ivp.py:146-148
+    e = (y - y_true) / (atol + rtol * np.abs(y_true))
+    return np.linalg.norm(e, axis=0) / np.sqrt(e.shape[0])
+
+
+# ---- host-only cases: these never reach an integrator, so they run without a GPU --------------------------------
+@pytest.mark.parametrize("method", METHODS)
+def test_no_integration(method):   # test_ivp.py:704-709
+    sol = solve_ivp("dydx[0] = -y[0]; dydx[1] = -y[1];", [4, 4], [2, 3], method=method, dense_output=True)
+    assert_equal(sol.sol(4), [2, 3])
+    assert_equal(sol.sol([4, 5, 6]), [[2, 2, 2], [3, 3, 3]])
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("tf", [10, np.inf])
+def test_empty(method, tf):   # test_ivp.py:712-728
+    sol = solve_ivp("", [0, tf], np.zeros((0,)), method=method, dense_output=True)
+    assert_equal(sol.sol(10), np.zeros((0,)))
+    assert_equal(sol.sol([1, 2, 3]), np.zeros((0, 3)))
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_zero_interval(method):   # test_ivp.py:874-883
+    res = solve_ivp("dydx[0] = 2 * y[0];", (0.0, 0.0), np.array([1.0]), method=method)
+    assert res.success
+    assert_allclose(res.y[0, -1], 1.0)
+    assert res.y.shape == (1, 1) and res.t_events is None and res.sol is None
+
+
+def test_result_object_and_argument_checks():   # result.rs:60-99, solve.rs:150-166
+    res = solve_ivp("dydx[0] = 0;", (1.0, 1.0), [3.0], events=Event("y[0] - 1", terminal=True))
+    assert isinstance(res, OdeResult)
+    assert res["status"] == res.status == 0 and res["message"] == "Success" and res["success"] is True
+    assert res["sol"] is None and res["t_events"] is res.t_events and len(res.t_events) == 1
+    assert "message: Success" in repr(res) and "nfev: 0" in repr(res)
+    with pytest.raises(KeyError):
+        res["nope"]
+    with pytest.raises(NotImplementedError):
+        solve_ivp("dydx[0] = 0;", (0, 1), [1.0], jac_sparsity=np.eye(1))
+    with pytest.raises(TypeError):
+        solve_ivp(lambda t, y: -y, (0, 1), [1.0])
+    with pytest.raises(ValueError):
+        solve_ivp(api.ExponentialDecay(0.5), (0, 0), [1.0], args=(1.0,))
+
+
+# ---- the path proper ------------------------------------------------------------------------------------------------
+@gpu
+@pytest.mark.parametrize("method", METHODS)
+def test_integration_zero_rhs(method):   # test_ivp.py:844-849
+    result = solve_ivp("dydx[0] = 0; dydx[1] = 0; dydx[2] = 0;", [0, 10], np.ones(3), method=method)
+    assert result.success
+    assert_equal(result.status, 0)
+    assert_allclose(result.y, 1.0, rtol=1e-15)
+    assert result.y.shape == (3, result.t.size)
+
+
+@gpu
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("t_span", [[5, 9], [5, 1]])
+@pytest.mark.parametrize("jac", [None, JAC_RATIONAL])
+def test_integration(method, t_span, jac):   # test_ivp.py:173-241 (vectorized / sparse-jac legs collapse: one device RHS)
+    rtol, atol = 1e-3, 1e-6
+    res = solve_ivp(FUN_RATIONAL, t_span, [1 / 3, 2 / 9], rtol=rtol, atol=atol, method=method, dense_output=True,
+                    jac=jac, vectorized=False)
+    assert_equal(res.t[0], t_span[0])
+    assert res.t_events is None and res.y_events is None
+    assert res.success
+    assert_equal(res.status, 0)
+    if method == "DOP853":
+        assert res.nfev < 50
+    if method in EXPLICIT:
+        assert_equal(res.njev, 0)
+        assert_equal(res.nlu, 0)
+    else:
+        assert 0 < res.njev
+        assert 0 < res.nlu
+    e = compute_error(res.y, sol_rational(res.t), rtol, atol)
+    assert np.all(e < 5)
+    tc = np.linspace(*t_span)
+    e = compute_error(res.sol(tc), sol_rational(tc), rtol, atol)
+    assert np.all(e < 5)
+    tc = (t_span[0] + t_span[-1]) / 2
+    e = compute_error(res.sol(tc), sol_rational(tc), rtol, atol)
+    assert np.all(e < 5)
+    assert_allclose(res.sol(res.t), res.y, rtol=1e-15, atol=1e-15)
+
+
+@gpu
+def test_integration_const_jac():   # test_ivp.py:272-317 (BDF leg; Radau is outside the path)
+    rtol, atol = 1e-3, 1e-6
+    t_span = [0, 2]
+    res = solve_ivp(FUN_LINEAR, t_span, [0, 2], rtol=rtol, atol=atol, method="BDF", dense_output=True,
+                    jac=np.array([[-1, -5], [1, 1]]))
+    assert_equal(res.t[0], t_span[0])
+    assert res.t_events is None and res.y_events is None and res.success
+    assert_equal(res.status, 0)
+    assert res.nfev < 100
+    assert_equal(res.njev, 0)
+    e = compute_error(res.y, sol_linear(res.t), rtol, atol)
+    assert np.all(e < 10)
+    tc = np.linspace(*t_span)
+    e = compute_error(res.sol(tc), sol_linear(tc), rtol, atol)
+    assert np.all(e < 60)
+    assert_allclose(res.sol(res.t), res.y, rtol=1e-14, atol=1e-14)
+
+
+@gpu
+def test_integration_stiff():   # test_ivp.py:319-342
+    res = solve_ivp("dydx[0] = -0.04 * y[0] + 1e4 * y[1] * y[2];"
+                    "dydx[1] = 0.04 * y[0] - 1e4 * y[1] * y[2] - 3e7 * y[1] * y[1];"
+                    "dydx[2] = 3e7 * y[1] * y[1];", [0, 1e8], [1e4, 0, 0], rtol=1e-6, atol=1e-6, method="BDF")
+    assert res.nfev < 5000
+    assert res.njev < 200
+    assert res.success
+
+
+@gpu
+def test_duplicate_timestamps():   # test_ivp.py:152-170
+    sol = solve_ivp("dydx[0] = y[1]; dydx[1] = -9.80665;", [0, np.inf], [0, 0.01], max_step=0.05 * 0.001 / 9.80665,
+                    events=Event("y[0]", terminal=True, direction=-1), dense_output=True)
+    assert_allclose(sol.sol(0.01), np.asarray([-0.00039033, -0.08806632]), rtol=1e-5, atol=1e-8)
+    assert_allclose(sol.t_events[0], np.asarray([0.00203943]), rtol=1e-5, atol=1e-8)
+    assert sol.success
+    assert_equal(sol.status, 1)
+    assert sol.message == "UserInterrupt"
+
+
+@gpu
+def test_t_eval():   # test_ivp.py:586-645
+    rtol, atol = 1e-3, 1e-6
+    y0 = [1 / 3, 2 / 9]
+    cases = [([5, 9], np.linspace(5, 9, 10), True), ([5, 1], np.linspace(5, 1, 10), True),
+             ([5, 9], [5, 5.01, 7, 8, 8.01, 9], True), ([5, 1], [5, 4.99, 3, 1.5, 1.1, 1.01, 1], False),
+             ([5, 9], [5.01, 7, 8, 8.01], True), ([5, 1], [4.99, 3, 1.5, 1.1, 1.01], False)]
+    for t_span, t_eval, check_error in cases:
+        res = solve_ivp(FUN_RATIONAL, t_span, y0, rtol=rtol, atol=atol, t_eval=t_eval)
+        assert_equal(res.t, t_eval)
+        assert res.t_events is None and res.success
+        assert_equal(res.status, 0)
+        if check_error:
+            e = compute_error(res.y, sol_rational(res.t), rtol, atol)
+            assert np.all(e < 5)
+
+
+@gpu
+def test_t_eval_dense_output():   # test_ivp.py:648-672
+    rtol, atol = 1e-3, 1e-6
+    t_span = [5, 9]
+    t_eval = np.linspace(t_span[0], t_span[1], 10)
+    res = solve_ivp(FUN_RATIONAL, t_span, [1 / 3, 2 / 9], rtol=rtol, atol=atol, t_eval=t_eval)
+    res_d = solve_ivp(FUN_RATIONAL, t_span, [1 / 3, 2 / 9], rtol=rtol, atol=atol, t_eval=t_eval, dense_output=True)
+    assert_equal(res.t, t_eval)
+    assert res.t_events is None and res.success
+    assert_equal(res.t, res_d.t)
+    assert_equal(res.y, res_d.y)
+    assert res_d.t_events is None and res_d.success
+    assert_equal(res_d.status, 0)
+    e = compute_error(res.y, sol_rational(res.t), rtol, atol)
+    assert np.all(e < 5)
+
+
+@gpu
+@pytest.mark.parametrize("method", METHODS)
+def test_t_eval_early_event(method):   # test_ivp.py:675-701
+    early_event = Event("x - 7", terminal=True)
+    res = solve_ivp(FUN_RATIONAL, [5, 9], [1 / 3, 2 / 9], rtol=1e-3, atol=1e-6, method=method,
+                    t_eval=np.linspace(7.5, 9, 16), events=early_event, jac=JAC_RATIONAL)
+    assert res.success
+    assert res.status == 1
+    assert len(res.t_events) == 1
+    assert res.t_events[0].size == 1
+    assert res.t_events[0][0] == 7
+
+
+@gpu
+@pytest.mark.parametrize("method", ["DOP853", "BDF"])
+def test_args(method):   # test_ivp.py:731-820 (Radau in the reference: DOP853 at its tolerances, BDF with the Jacobian)
+    omega, k, tfinal, zfinal = 2, 4, 5, 0.99
+    z0 = np.exp(-k * tfinal) / ((1 - zfinal) / zfinal + np.exp(-k * tfinal))
+    tight = method == "DOP853"
+    sol = solve_ivp("dydx[0] = -p[0] * y[1]; dydx[1] = p[0] * y[0]; dydx[2] = p[1] * y[2] * (1 - y[2]);",
+                    [0, 2 * tfinal], [0, -1, z0],
+                    events=[Event("y[0]", direction=-1), Event("y[1]", direction=1), Event("y[2] - p[2]", terminal=True)],
+                    dense_output=True, args=(omega, k, zfinal), method=method,
+                    jac="j[0] = 0; j[1] = -p[0]; j[2] = 0; j[3] = p[0]; j[4] = 0; j[5] = 0;"
+                        "j[6] = 0; j[7] = 0; j[8] = p[1] * (1 - 2 * y[2]);",
+                    rtol=1e-10 if tight else 1e-8, atol=1e-13 if tight else 1e-11)
+    x0events_t, y0events_t, zfinalevents_t = sol.t_events
+    tol = dict(rtol=1e-7) if tight else dict(rtol=1e-4)
+    assert_allclose(x0events_t, [0.5 * np.pi, 1.5 * np.pi], **tol)
+    assert_allclose(y0events_t, [0.25 * np.pi, 1.25 * np.pi], **tol)
+    assert_allclose(zfinalevents_t, [tfinal], rtol=1e-5, atol=1e-5)
+    assert sol.status == 1
+    t = np.linspace(0, zfinalevents_t[0], 250)
+    w = sol.sol(t)
+    tol = dict(rtol=1e-5, atol=1e-6) if tight else dict(rtol=1e-3, atol=1e-4)
+    assert_allclose(w[0], np.sin(omega * t), **tol)
+    assert_allclose(w[1], -np.cos(omega * t), **tol)
+    assert_allclose(w[2], 1 / (((1 - z0) / z0) * np.exp(-k * t) + 1), **tol)
+    x0events, y0events, zfinalevents = sol.sol(x0events_t), sol.sol(y0events_t), sol.sol(zfinalevents_t)
+    a0, a1 = (1e-10, 1e-6) if tight else (1e-6, 1e-4)
+    assert_allclose(x0events[0], np.zeros_like(x0events[0]), atol=a0)
+    assert_allclose(x0events[1], np.ones_like(x0events[1]), atol=a1)
+    assert_allclose(y0events[0], np.ones_like(y0events[0]), atol=a1)
+    assert_allclose(y0events[1], np.zeros_like(y0events[1]), atol=a0)
+    assert_allclose(zfinalevents[2], [zfinal], atol=a1)
+    # y_events rows are the states at the event times (solve.rs:383-400)
+    assert sol.y_events[0].shape == (2, 3) and sol.y_events[2].shape == (1, 3)
+    assert_allclose(sol.y_events[2][0, 2], zfinal, atol=1e-9)
+
+
+@gpu
+def test_array_rtol():   # test_ivp.py:824-841
+    f = "dydx[0] = y[0]; dydx[1] = y[1];"
+    sol = solve_ivp(f, (0, 1), [1., 1.], rtol=[1e-1, 1e-1])
+    err1 = np.abs(np.linalg.norm(sol.y[:, -1] - np.exp(1)))
+    sol = solve_ivp(f, (0, 1), [1., 1.], rtol=[1e-1, 1e-16])
+    err2 = np.abs(np.linalg.norm(sol.y[:, -1] - np.exp(1)))
+    assert err2 < err1
+
+
+@gpu
+def test_args_single_value():   # test_ivp.py:852-861
+    sol = solve_ivp("dydx[0] = p[0] * y[0];", (0, 0.1), [1], args=(-1,))
+    assert_allclose(sol.y[0, -1], np.exp(-0.1))
+
+
+@gpu
+@pytest.mark.parametrize("method", METHODS)
+def test_max_step_first_step(method):   # test_ivp.py:521-583
+    rtol, atol = 1e-3, 1e-6
+    y0 = [1 / 3, 2 / 9]
+    for t_span in ([5, 9], [5, 1]):
+        res = solve_ivp(FUN_RATIONAL, t_span, y0, rtol=rtol, max_step=0.5, atol=atol, method=method, dense_output=True)
+        assert_equal(res.t[0], t_span[0])
+        assert_equal(res.t[-1], t_span[-1])
+        assert np.all(np.abs(np.diff(res.t)) <= 0.5 + 1e-15)
+        assert res.t_events is None and res.success
+        e = compute_error(res.y, sol_rational(res.t), rtol, atol)
+        assert np.all(e < 5)
+        tc = np.linspace(*t_span)
+        e = compute_error(res.sol(tc), sol_rational(tc), rtol, atol)
+        assert np.all(e < 5)
+        assert_allclose(res.sol(res.t), res.y, rtol=1e-15, atol=1e-15)
+        first_step = 0.1
+        res = solve_ivp(FUN_RATIONAL, t_span, y0, rtol=rtol, max_step=0.5, atol=atol, method=method, dense_output=True,
+                        first_step=first_step)
+        assert_allclose(first_step, np.abs(res.t[1] - 5))
+        assert res.t_events is None and res.success
+        e = compute_error(res.y, sol_rational(res.t), rtol, atol)
+        assert np.all(e < 5)
+
+
+@gpu
+@pytest.mark.parametrize("method", METHODS)
+def test_tbound_respected(method):   # test_ivp.py:885-949
+    res = solve_ivp("dydx[0] = 1 / sqrt(1 - x);", (0.0, 1 - 1e-8), [0.0], method=method, rtol=1e-6, atol=1e-9)
+    assert res.success and res.t[-1] <= 1 - 1e-8
+    res = solve_ivp("dydx[0] = y[1]; dydx[1] = -y[0];", (0.0, 2 * np.pi), [1.0, 0.0], method=method, rtol=1e-8, atol=1e-10)
+    assert res.success and res.t[-1] == 2 * np.pi
+    assert_allclose(res.y[:, -1], [1.0, 0.0], atol=2e-4 if method == "BDF" else 1e-5)
+
+
+@gpu
+def test_builtin_problem_and_failure_status():   # an IVP instance as `fun`; status -1 / message (solve.rs:405-428)
+    res = solve_ivp(api.ExponentialDecay(0.5), (0, 10), [2.0], t_eval=[0, 5, 10])
+    assert_allclose(res.y[0], 2 * np.exp(-0.5 * np.array([0, 5, 10.0])), rtol=5e-3)
+    res = solve_ivp(api.BouncingBall(), (0, 10), [10.0, 0.0])
+    assert res.status == 1 and res.t_events[0].size == 1 and res.y_events[0].shape == (1, 2)
+    res = solve_ivp(api.VanDerPol(1.0), (0, 100), [2.0, 0.0], max_steps=5)
+    assert res.status == -1 and not res.success and res.message == "NeedLargerNMax"
