@@ -65,11 +65,11 @@ IVP_HD double bdf_wrms(const double *v, const double *scale)
 }
 
 // change_d (bdf.rs:669-732): D[0..order] <- (R(order, factor) . R(order, 1))^T applied to D.
+// The literal form: every product and every zero test of compute_r / matmul / the application loop.  Only taken for a
+// factor that is not finite or astronomically large (see bdf_change_d below).
 template <int N>
-IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
+IVP_HD void bdf_change_d_generic(double (&d)[8][N], int order, double factor)
 {
-    if (factor == 1.0) return;
-    if (order > BDF_MAXO) order = BDF_MAXO;
     const int size = order + 1;
     double r[6][6];
 #pragma unroll
@@ -104,6 +104,82 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
                         for (int c = 0; c < N; ++c) scratch[row][c] += ru * d[k][c];
                     }
                 }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i <= order) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) d[i][c] = scratch[i][c];
+        }
+}
+
+// U = compute_r(order, 1.0) (bdf.rs:694-712) does not depend on the order (only its size does):
+// U[m][j] = prod_{i=1..m} (i - 1 - j) / i, evaluated here with the reference's operations in the reference's order.
+struct BdfU {
+    double v[6][6];
+    constexpr BdfU() : v{}
+    {
+        for (int j = 0; j < 6; ++j) v[0][j] = 1.0;
+        for (int i = 1; i < 6; ++i)
+            for (int j = 0; j < 6; ++j)
+                v[i][j] = j == 0 ? v[i - 1][j] * 0.0 : v[i - 1][j] * (((double)i - 1.0 - 1.0 * (double)j) / (double)i);
+    }
+};
+
+// change_d, structured.  With R = compute_r(order, factor) and U as above the reference forms RU = R.U with matmul()
+// (terms with a zero R entry skipped) and D[row] <- sum_k RU[k][row] D[k] (zero coefficients skipped).  For a finite
+// factor the following holds exactly, rounding included:
+//   * U[m][row] is +-0 for m > row, R[k][0] is 0 for k >= 1: those products are +-0, and adding +-0 to an accumulator
+//     that started at +0.0 never changes it (it cannot become -0) -- the same reason why matmul's zero-skip is a no-op;
+//     so RU[k][row] = sum_{m=1..row} R[k][m] U[m][row] for k, row >= 1, RU[k][0] = 0 for k >= 1;
+//   * RU[0][0] = 1 and RU[0][row] = sum_m U[m][row] = 0 exactly (alternating binomials) for row >= 1;
+//   * entries with m > order only reach rows > order, which are not stored; k > order is excluded by the predicate.
+// This is a third of the literal form's instructions (no 6 x 6 x 6 guarded products), and change_d is the fattest phase
+// of an attempt: a wave pays for it whenever any of its lanes rescales.  A factor that is NaN / infinite / > 1e50 (R
+// could overflow, and 0 x inf products would matter) takes the literal form.
+template <int N>
+IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
+{
+    if (factor == 1.0) return;
+    if (order > BDF_MAXO) order = BDF_MAXO;
+    if (!(fabs(factor) < 1e50)) { bdf_change_d_generic<N>(d, order, factor); return; }
+    constexpr BdfU U{};
+    double r[6][6];
+#pragma unroll
+    for (int m = 1; m < 6; ++m) {
+        const double fm = factor * (double)m;
+        r[0][m] = 1.0;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) r[k][m] = r[k - 1][m] * (((double)k - 1.0 - fm) / (double)k);
+    }
+    double ru[6][6];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+#pragma unroll
+        for (int row = 1; row < 6; ++row) {
+            double acc = r[k][1] * U.v[1][row];
+#pragma unroll
+            for (int m = 2; m < 6; ++m)
+                if (m <= row) acc = acc + r[k][m] * U.v[m][row];
+            ru[k][row] = acc;
+        }
+    }
+    double scratch[6][N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) scratch[0][c] = 0.0 + 1.0 * d[0][c];
+#pragma unroll
+    for (int row = 1; row < 6; ++row) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) scratch[row][c] = 0.0;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            const bool use = k <= order && ru[k][row] != 0.0;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const double t = scratch[row][c] + ru[k][row] * d[k][c];
+                scratch[row][c] = use ? t : scratch[row][c];
             }
         }
     }

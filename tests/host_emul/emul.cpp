@@ -89,4 +89,27 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
     return rc;
 }
 
+// bdf_change_d (structured) next to bdf_change_d_generic (the literal restatement) on the same input: d is [8][n] row-major
+extern "C" int emul_change_d(int n, int order, double factor, const double *d_in, double *d_fast, double *d_generic)
+{
+    using namespace IVP_NS;
+    auto run = [&](auto tag) {
+        constexpr int N = decltype(tag)::value;
+        double a[8][N], b[8][N];
+        for (int k = 0; k < 8; ++k)
+            for (int c = 0; c < N; ++c) a[k][c] = b[k][c] = d_in[k * N + c];
+        bdf_change_d<N>(a, order, factor);
+        if (factor != 1.0) bdf_change_d_generic<N>(b, order > BDF_MAXO ? BDF_MAXO : order, factor);
+        for (int k = 0; k < 8; ++k)
+            for (int c = 0; c < N; ++c) { d_fast[k * N + c] = a[k][c]; d_generic[k * N + c] = b[k][c]; }
+    };
+    switch (n) {
+    case 1: run(std::integral_constant<int, 1>{}); return 0;
+    case 2: run(std::integral_constant<int, 2>{}); return 0;
+    case 3: run(std::integral_constant<int, 3>{}); return 0;
+    case 6: run(std::integral_constant<int, 6>{}); return 0;
+    default: return -1;
+    }
+}
+
 extern "C" size_t emul_kargs_size(void) { return sizeof(IvpKArgs); }

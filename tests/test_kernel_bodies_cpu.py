@@ -156,3 +156,35 @@ def test_nan_interval_retires_the_lane(method):
     assert list(g["status"]) == [0, 0, 3, 0, 3] and g["nfev"][2] == 0
     r = oracle_batch("sho", y0[:, :2], None, 0.0, 2.0, method=method, rtol=1e-6, atol=1e-9)
     assert np.array_equal(g["y_end"][:, :2], r["y_end"])
+
+
+def test_bdf_change_d_structured_equals_the_literal_form():
+    """bdf_change_d exploits the structure of U = compute_r(order, 1) and of R's first row / column (bdf_core.h); the
+    literal restatement of bdf.rs:669-732 stays in the header as bdf_change_d_generic.  Same bits on random and on
+    adversarial inputs: factors that zero an R entry, signed zeros / infinities / NaNs in D, non-finite factors."""
+    import ctypes as C
+    from tests.host_emul import emul
+    lib = emul.lib()
+    lib.emul_change_d.argtypes = [C.c_int, C.c_int, C.c_double] + [np.ctypeslib.ndpointer(np.float64, flags="C")] * 3
+    lib.emul_change_d.restype = C.c_int
+    rng = np.random.default_rng(20260207)
+    special = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e300, -1e300, 5e-324]
+    factors = [0.5, 1.0 / 3.0, 0.25, 0.2, 2.0, 10.0, 1e-3, 0.75, 1.5, 4.0, 0.0, -0.0, -0.5, 1.0, 3.0, 1e49, 1e51, 1e300,
+               np.inf, -np.inf, np.nan, 1.0 + 2 ** -52]
+    n_checked = 0
+    for n in (1, 2, 3, 6):
+        for trial in range(400):
+            order = int(rng.integers(1, 7))          # 6 exercises the clamp to MAX_ORDER
+            factor = factors[trial % len(factors)] if trial < 3 * len(factors) else float(rng.uniform(0.05, 12.0))
+            d = rng.standard_normal((8, n)) * 10.0 ** rng.integers(-8, 8, size=(8, 1))
+            if trial % 3 == 0:
+                idx = rng.integers(0, 8 * n, size=3)
+                d.reshape(-1)[idx] = rng.choice(special, size=3)
+            if trial % 7 == 0:
+                d[rng.integers(0, 8)] = 0.0
+            a, b = np.empty_like(d), np.empty_like(d)
+            assert lib.emul_change_d(n, order, factor, np.ascontiguousarray(d), a, b) == 0
+            same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), (n, order, factor, d, a, b)
+            n_checked += 1
+    assert n_checked == 1600
