@@ -531,8 +531,13 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
             const double rate = dy_norm / dy_norm_prev;
             if (rate >= 1.0) rate_condition = true;
             else {
-                const double remaining = (double)(newton_maxiter - iters);
-                const double estimate = ivp_pow(rate, remaining, IVP_KZ_ARG) / (1.0 - rate) * dy_norm;
+                // rate.powf(remaining), remaining = 3, 2, 1 iterations left: the product (oracle: orc_pow_small_int)
+                static_assert(newton_maxiter == 4, "the contraction-rate power is unrolled for 1..3 iterations left");
+                const int remaining = newton_maxiter - iters;
+                double rate_pow = rate;
+                rate_pow = remaining >= 2 ? rate_pow * rate : rate_pow;
+                rate_pow = remaining >= 3 ? rate_pow * rate : rate_pow;
+                const double estimate = rate_pow / (1.0 - rate) * dy_norm;
                 if (estimate > newton_tol) rate_condition = true;
             }
         }
@@ -569,15 +574,15 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
 #pragma unroll
     for (int i = 0; i < N; ++i) rhs[i] = ec_o * delta[i];
     const double error_norm = bdf_wrms<N>(rhs, scale);
-    if (error_norm > 1.0) {   // bdf.rs:481-489
-        double factor = safety * ivp_pow(error_norm, -1.0 / ((double)order + 1.0), IVP_KZ_ARG);
-        factor = fmax(factor, 0.2);
-        S.pending_factor = factor; S.flags |= IVP_BDF_PENDING;
-        S.current_h *= factor; n_equal = 0; S.d_nrejct += 1;
-        pack();
-        return true;
-    }
-
+    // One power site per attempt.  A rejected step needs error_norm^(-1/(order+1)) (bdf.rs:481-489), the order / step
+    // adaptation of an accepted one needs that very value and its two neighbours err_m^(-1/order), err_p^(-1/(order+2))
+    // (bdf.rs:551-606).  A wave executes whatever any of its lanes needs, and with 40 trajectories some lane rejects and
+    // some lane adapts in nearly every attempt: both kinds of lane meet at ivp_pow3 below instead of running one power
+    // for the rejection and three more, one after the other, for the adaptation.
+    const bool reject = error_norm > 1.0;
+    bool adapt = false;
+    double err_m = u2d(0x7FF0000000000000ull), err_p = u2d(0x7FF0000000000000ull);
+    if (!reject) {
     S.d_naccpt += 1;
     n_equal += 1;
     S.x = x_new;
@@ -616,7 +621,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     if (S.direction * (S.x - S.xend) >= 0.0) { pack(); S.status = 0; return false; }
 
     if (n_equal >= order + 1) {   // order / step adaptation, bdf.rs:551-606
-        double err_m = u2d(0x7FF0000000000000ull), err_p = u2d(0x7FF0000000000000ull);
+        adapt = true;
         if (order > 1) {
             const double ecm = bdf_sel6(T.error_const, order - 1);
 #pragma unroll
@@ -641,13 +646,20 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
             }
             err_p = bdf_wrms<N>(rhs, scale);
         }
+    }
+    }   // !reject
+    if (reject || adapt) {
         double factors[3];
         const double errors[3] = {err_m, error_norm, err_p};
-#pragma unroll 1
-        for (int idx = 0; idx < 3; ++idx) {
-            const double e = idx == 0 ? errors[0] : (idx == 1 ? errors[1] : errors[2]);
-            const double v = ivp_pow(e, -1.0 / ((double)order + (double)idx), IVP_KZ_ARG);
-            if (idx == 0) factors[0] = v; else if (idx == 1) factors[1] = v; else factors[2] = v;
+        const double expo[3] = {-1.0 / ((double)order + 0.0), -1.0 / ((double)order + 1.0), -1.0 / ((double)order + 2.0)};
+        ivp_pow3(errors, expo, factors, IVP_KZ_ARG);
+        if (reject) {   // bdf.rs:481-489
+            double factor = safety * factors[1];
+            factor = fmax(factor, 0.2);
+            S.pending_factor = factor; S.flags |= IVP_BDF_PENDING;
+            S.current_h *= factor; n_equal = 0; S.d_nrejct += 1;
+            pack();
+            return true;
         }
         int best = 0;   // Iterator::max_by keeps a later element unless the current maximum is strictly greater
         double bestv = factors[0];

@@ -428,8 +428,13 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
             const double rate = dy_norm / dy_norm_prev;
             if (rate >= 1.0) rate_condition = true;
             else {
-                const double remaining = (double)(newton_maxiter - iters);
-                const double estimate = ivp_pow(rate, remaining) / (1.0 - rate) * dy_norm;
+                // rate.powf(remaining), remaining = 3, 2, 1 iterations left: the product (oracle: orc_pow_small_int)
+                static_assert(newton_maxiter == 4, "the contraction-rate power is unrolled for 1..3 iterations left");
+                const int remaining = newton_maxiter - iters;
+                double rate_pow = rate;
+                rate_pow = remaining >= 2 ? rate_pow * rate : rate_pow;
+                rate_pow = remaining >= 3 ? rate_pow * rate : rate_pow;
+                const double estimate = rate_pow / (1.0 - rate) * dy_norm;
                 if (estimate > newton_tol) rate_condition = true;
             }
         }

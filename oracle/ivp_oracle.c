@@ -102,9 +102,20 @@ double orc_detpow(double x, double e)
 #ifdef ORC_DETPOW
 #define ORC_POW(x, e) orc_detpow((x), (e))
 int orc_uses_detpow(void) { return 1; }
+/* powf with a small positive INTEGER exponent (the contraction-rate estimate of BDF's Newton loop, bdf.rs:408: the
+ * exponent is the number of iterations left, 1..3): the portable stand-in is the product, which is what a correctly
+ * rounded pow returns for n = 1, 2 and within an ulp of it for n = 3 -- closer to libm than the 2-ulp exp2/log2 form. */
+static inline double orc_pow_small_int(double x, int n)
+{
+    if (n == 1) return x;
+    if (n == 2) return x * x;
+    if (n == 3) return x * x * x;
+    return orc_detpow(x, (double)n);
+}
 #else
 #define ORC_POW(x, e) pow((x), (e))
 int orc_uses_detpow(void) { return 0; }
+static inline double orc_pow_small_int(double x, int n) { return pow(x, (double)n); }   /* the reference's own call */
 #endif
 
 /* Rust f64::signum: 1.0 for +0.0 and positives, -1.0 for -0.0 and negatives, NaN for NaN. */
@@ -1499,8 +1510,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
                 double rate = dy_norm / dy_norm_prev;
                 if (rate >= 1.0) rate_condition = 1;
                 else {
-                    double remaining = (double)(newton_maxiter - iters);
-                    double estimate = ORC_POW(rate, remaining) / (1.0 - rate) * dy_norm;
+                    double estimate = orc_pow_small_int(rate, newton_maxiter - iters) / (1.0 - rate) * dy_norm;
                     if (estimate > newton_tol) rate_condition = 1;
                 }
             }

@@ -112,4 +112,14 @@ extern "C" int emul_change_d(int n, int order, double factor, const double *d_in
     }
 }
 
+// ivp_pow3 next to three ivp_pow calls
+extern "C" void emul_pow3(const double *x, const double *e, double *r3, double *r1)
+{
+    using namespace IVP_NS;
+    const double xs[3] = {x[0], x[1], x[2]}, es[3] = {e[0], e[1], e[2]};
+    double out[3];
+    ivp_pow3(xs, es, out);
+    for (int i = 0; i < 3; ++i) { r3[i] = out[i]; r1[i] = ivp_pow(x[i], e[i]); }
+}
+
 extern "C" size_t emul_kargs_size(void) { return sizeof(IvpKArgs); }

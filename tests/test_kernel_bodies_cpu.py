@@ -188,3 +188,33 @@ def test_bdf_change_d_structured_equals_the_literal_form():
             assert same.all(), (n, order, factor, d, a, b)
             n_checked += 1
     assert n_checked == 1600
+
+
+def test_pow3_equals_three_pow_calls():
+    """ivp_pow3 (three interleaved powers, special cases as selects; rk_core.h) returns ivp_pow's bits argument for argument."""
+    import ctypes as C
+    from tests.host_emul import emul
+    lib = emul.lib()
+    arr = np.ctypeslib.ndpointer(np.float64, flags="C")
+    lib.emul_pow3.argtypes = [arr] * 4
+    lib.emul_pow3.restype = None
+    rng = np.random.default_rng(20260208)
+    xs_special = [0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 5e-324, 1e-310, 2.2250738585072014e-308, 1.7976931348623157e308,
+                  0.5, 2.0, 1e-300, 1e300]
+    es_special = [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, -0.5, -1.0 / 3.0, -0.25, -0.2, -1.0 / 6.0, -1.0 / 7.0, 1e3, -1e3, 1e-320]
+    r3, r1 = np.empty(3), np.empty(3)
+    n = 0
+    for trial in range(6000):
+        if trial < 3000:
+            x = np.array(rng.choice(xs_special, 3), dtype=np.float64)
+            e = np.array(rng.choice(es_special, 3), dtype=np.float64)
+            if trial % 2:
+                x[rng.integers(0, 3)] = 10.0 ** rng.uniform(-12, 6)
+        else:
+            x = 10.0 ** rng.uniform(-14, 8, 3)
+            e = -1.0 / rng.integers(1, 8, 3).astype(np.float64)
+        lib.emul_pow3(np.ascontiguousarray(x), np.ascontiguousarray(e), r3, r1)
+        same = (r3.view(np.uint64) == r1.view(np.uint64)) | (np.isnan(r3) & np.isnan(r1))
+        assert same.all(), (x, e, r3, r1)
+        n += 1
+    assert n == 6000
