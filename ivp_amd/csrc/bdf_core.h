@@ -23,6 +23,52 @@ constexpr int BDF_MAXO = 5;
 #define IVP_BDF_LU_CURRENT 0x1000u
 #define IVP_BDF_PENDING 0x2000u   // a change_d(pending_factor) is owed before D is used again
 
+// Phase clock (tools/bdf_phase_profile.sh builds rk_bdf.hip with -DIVP_PHASE_PROF): at marker k the wave adds the shader
+// clock ticks since its previous marker to slot k of an LDS table (two LDS round trips, ~200 ticks per marker); the table
+// goes to ivp_phase_ticks with atomics when the launch ends.  One wave per block; all of it a no-op in the product build.
+#if defined(IVP_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned long long *ivp_phase_lds()
+{
+    __shared__ unsigned long long t[18];   // [0..15] ticks / counts, [16] clock at the previous marker
+    return t;
+}
+__device__ __forceinline__ bool ivp_phase_leader()
+{
+    return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u;
+}
+__device__ __forceinline__ void ivp_phase_mark(int k)
+{
+    unsigned long long *t = ivp_phase_lds();
+    const unsigned long long now = __builtin_readcyclecounter();
+    if (ivp_phase_leader()) {
+        t[k] += now - t[16];
+        t[16] = now;
+        if (k == 0) t[15] += 1ull;
+    }
+}
+__device__ __forceinline__ void ivp_phase_begin()
+{
+    unsigned long long *t = ivp_phase_lds();
+    if (ivp_phase_leader()) {
+        for (int k = 0; k < 16; ++k) t[k] = 0ull;
+        t[16] = __builtin_readcyclecounter();
+    }
+}
+__device__ __forceinline__ void ivp_phase_end()
+{
+    unsigned long long *t = ivp_phase_lds();
+    if (ivp_phase_leader())
+        for (int k = 0; k < 16; ++k) atomicAdd(&::ivp_phase_ticks[k], t[k]);
+}
+#define IVP_PHASE(k) ivp_phase_mark(k)
+#define IVP_PHASE_BEGIN() ivp_phase_begin()
+#define IVP_PHASE_END() ivp_phase_end()
+#else
+#define IVP_PHASE(k) ((void)0)
+#define IVP_PHASE_BEGIN() ((void)0)
+#define IVP_PHASE_END() ((void)0)
+#endif
+
 struct BdfTables {
     double gamma[6], alpha[6], error_const[6];
     constexpr BdfTables() : gamma{}, alpha{}, error_const{}
@@ -422,6 +468,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
                   (lu_current ? IVP_BDF_LU_CURRENT : 0u);
     };
 
+    IVP_PHASE(0);   // everything since the previous attempt's last marker (its tail, the loop, the exits)
     if (S.over || S.d_nstep >= S.budget) { S.status = 2; return false; }                 // steps.total >= nmax
     if (S.current_h < MIN_POSITIVE) { S.status = 3; return false; }
     double h_try = S.current_h;
@@ -455,11 +502,13 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
             n_equal = 0; lu_current = false;
         }
     }
+    IVP_PHASE(1);   // step-size clamps
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
         const double factor = pass == 0 ? fpass[0] : (pass == 1 ? fpass[1] : (pass == 2 ? fpass[2] : fpass[3]));
         if (factor != 1.0) bdf_change_d<N>(S.d, order, factor);
     }
+    IVP_PHASE(2);   // change_d
     if (finished) { pack(); S.status = 0; return false; }
     if ((S.x + KC(0.1) * fabs(h_signed)) == S.x) { pack(); S.status = 3; return false; }
     const double x_start = S.x;
@@ -488,6 +537,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     }
     const double c = h_signed / alpha_o;
     bool lu_failed = false;
+    IVP_PHASE(3);   // predictor, scale, psi
     if (!lu_current || fabs(c - S.current_c) / fmax(fabs(c), 1.0) > KC(0.1)) {
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -506,6 +556,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         return true;
     }
 
+    IVP_PHASE(4);   // LU refresh
     double y_new[N], delta[N], rhs[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { y_new[i] = y_predict[i]; delta[i] = 0.0; }
@@ -555,6 +606,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         dy_norm_prev = dy_norm; has_prev = true;
         iters += 1;
     }
+    IVP_PHASE(5);   // Newton iterations
     if (!converged) {   // bdf.rs:448-459: refresh the Jacobian at the predictor, halve the step
         bdf_eval_jac<R>(x_new, y_predict, L.p, S.jac);
         S.d_njev += 1;
@@ -579,6 +631,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     // (bdf.rs:551-606).  A wave executes whatever any of its lanes needs, and with 40 trajectories some lane rejects and
     // some lane adapts in nearly every attempt: both kinds of lane meet at ivp_pow3 below instead of running one power
     // for the rejection and three more, one after the other, for the adaptation.
+    IVP_PHASE(6);   // error estimate
     const bool reject = error_norm > 1.0;
     bool adapt = false;
     double err_m = u2d(0x7FF0000000000000ull), err_p = u2d(0x7FF0000000000000ull);
@@ -620,6 +673,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     }
     if (S.direction * (S.x - S.xend) >= 0.0) { pack(); S.status = 0; return false; }
 
+    IVP_PHASE(7);   // accepted step: D update, output
     if (n_equal >= order + 1) {   // order / step adaptation, bdf.rs:551-606
         adapt = true;
         if (order > 1) {
@@ -648,11 +702,13 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         }
     }
     }   // !reject
+    IVP_PHASE(8);   // neighbouring-order error norms
     if (reject || adapt) {
         double factors[3];
         const double errors[3] = {err_m, error_norm, err_p};
         const double expo[3] = {-1.0 / ((double)order + 0.0), -1.0 / ((double)order + 1.0), -1.0 / ((double)order + 2.0)};
         ivp_pow3(errors, expo, factors, IVP_KZ_ARG);
+        IVP_PHASE(9);   // the three powers
         if (reject) {   // bdf.rs:481-489
             double factor = safety * factors[1];
             factor = fmax(factor, 0.2);
@@ -733,10 +789,12 @@ IVP_HD uint32_t bdf_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_ou
     }
     uint32_t it = 0;
     bool run = true;
+    IVP_PHASE_BEGIN();
     while (run && it < a.chunk) {
         run = bdf_attempt<R, FULL>(a, j, S, L);
         ++it;
     }
+    IVP_PHASE_END();
     uint32_t js = j;
     IVP_OPAQUE_V(js);
 #pragma unroll

@@ -18,6 +18,9 @@
 #define IVP_LAUNCH_NAME ivp_launch_bdf_strict
 #endif
 #include "rk_core.h"
+#ifdef IVP_PHASE_PROF
+__device__ unsigned long long ivp_phase_ticks[16];
+#endif
 #include "bdf_core.h"
 #include "rk_global.h"
 #include "rk_launch.h"
@@ -69,3 +72,16 @@ hipError_t IVP_LAUNCH_NAME(int what, int rhs_id, bool full, const IvpKArgs &a, u
     }
     return hipErrorInvalidValue;
 }
+
+#ifdef IVP_PHASE_PROF
+// tools/bdf_phase_profile.sh: ticks per phase marker summed over all waves since the last reset
+extern "C" int ivp_debug_phase_ticks(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ivp_phase_ticks), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ivp_phase_ticks), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
