@@ -181,16 +181,40 @@ struct BdfU {
 //     that started at +0.0 never changes it (it cannot become -0) -- the same reason why matmul's zero-skip is a no-op;
 //     so RU[k][row] = sum_{m=1..row} R[k][m] U[m][row] for k, row >= 1, RU[k][0] = 0 for k >= 1;
 //   * RU[0][0] = 1 and RU[0][row] = sum_m U[m][row] = 0 exactly (alternating binomials) for row >= 1;
-//   * entries with m > order only reach rows > order, which are not stored; k > order is excluded by the predicate.
-// This is a third of the literal form's instructions (no 6 x 6 x 6 guarded products), and change_d is the fattest phase
-// of an attempt: a wave pays for it whenever any of its lanes rescales.  A factor that is NaN / infinite / > 1e50 (R
-// could overflow, and 0 x inf products would matter) takes the literal form.
+//   * entries with m > order only reach rows > order, which are not stored; a row k > order of D is excluded by
+//     multiplying its coefficients with zero, and a zero coefficient times a FINITE difference is a zero that leaves
+//     the sum alone, which is also what the reference's "skip zero coefficients" amounts to.
+// This is a third of the literal form's instructions (no 6 x 6 x 6 guarded products, no per-term selects), and change_d is
+// the fattest phase of an attempt: a wave pays for it whenever any of its lanes rescales.  A factor that is NaN /
+// infinite / > 1e50 (R could overflow) or a non-finite entry of D (0 x inf would matter) takes the literal form.
+// x / C for a small integer constant C, correctly rounded: q = x * RN(1/C), the exact remainder r = x - C q (one fma),
+// q' = RN(q + r * RN(1/C)) -- Markstein's correction step, which yields the IEEE quotient whenever RN(1/C) is the
+// correctly rounded reciprocal and nothing under- or overflows (callers keep |x| in [2^-52, 1e51] or +0; a -0 would come
+// back as +0, and k - 1 - factor * m with k - 1 >= 2 cannot be one).  Three
+// independent-latency instructions instead of the 11-instruction v_div_scale / v_rcp / ... / v_div_fixup chain; checked
+// against the hardware division on 2e8 random operands per constant (tests: test_div_by_small_constant_is_ieee_division).
+template <int C>
+IVP_HD double ivp_div_small_const(double x)
+{
+    constexpr double c = (double)C, y = 1.0 / (double)C;
+    const double q = x * y;
+    const double r = fma(-c, q, x);
+    return fma(r, y, q);
+}
+
 template <int N>
 IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
 {
     if (factor == 1.0) return;
     if (order > BDF_MAXO) order = BDF_MAXO;
-    if (!(fabs(factor) < 1e50)) { bdf_change_d_generic<N>(d, order, factor); return; }
+    // the structured form needs finite arithmetic throughout: a finite, not astronomically large factor (so that R stays
+    // finite) and finite differences in the rows it reads (so that a zero coefficient times D is a zero)
+    bool plain = fabs(factor) < 1e50;
+#pragma unroll
+    for (int k = 1; k < 6; ++k)
+#pragma unroll
+        for (int c = 0; c < N; ++c) plain = plain && fabs(d[k][c]) < u2d(0x7FF0000000000000ull);
+    if (!plain) { bdf_change_d_generic<N>(d, order, factor); return; }
     constexpr BdfU U{};
     double r[6][6];
 #pragma unroll
@@ -198,8 +222,16 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
         const double fm = factor * (double)m;
         r[0][m] = 1.0;
 #pragma unroll
-        for (int k = 1; k < 6; ++k) r[k][m] = r[k - 1][m] * (((double)k - 1.0 - fm) / (double)k);
+        for (int k = 1; k < 6; ++k) {
+            const double num = (double)k - 1.0 - fm;
+            const double quot = k == 3 ? ivp_div_small_const<3>(num) : (k == 5 ? ivp_div_small_const<5>(num) : num / (double)k);
+            r[k][m] = r[k - 1][m] * quot;
+        }
     }
+    // a coefficient of a row above the order must not contribute: times zero it becomes a zero, which leaves the sum alone
+    double keep[6];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) keep[k] = k <= order ? 1.0 : 0.0;
     double ru[6][6];
 #pragma unroll
     for (int k = 1; k < 6; ++k) {
@@ -209,7 +241,7 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
 #pragma unroll
             for (int m = 2; m < 6; ++m)
                 if (m <= row) acc = acc + r[k][m] * U.v[m][row];
-            ru[k][row] = acc;
+            ru[k][row] = acc * keep[k];
         }
     }
     double scratch[6][N];
@@ -218,15 +250,11 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
 #pragma unroll
     for (int row = 1; row < 6; ++row) {
 #pragma unroll
-        for (int c = 0; c < N; ++c) scratch[row][c] = 0.0;
+        for (int c = 0; c < N; ++c) {
+            double acc = 0.0;
 #pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            const bool use = k <= order && ru[k][row] != 0.0;
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const double t = scratch[row][c] + ru[k][row] * d[k][c];
-                scratch[row][c] = use ? t : scratch[row][c];
-            }
+            for (int k = 1; k < 6; ++k) acc = acc + ru[k][row] * d[k][c];
+            scratch[row][c] = acc;
         }
     }
 #pragma unroll

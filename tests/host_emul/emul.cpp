@@ -112,6 +112,19 @@ extern "C" int emul_change_d(int n, int order, double factor, const double *d_in
     }
 }
 
+// ivp_div_small_const<C>(x) next to x / C
+extern "C" long emul_div_small_const(int c, const double *x, long n)
+{
+    using namespace IVP_NS;
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        const double a = c == 3 ? x[i] / 3.0 : x[i] / 5.0;
+        const double b = c == 3 ? ivp_div_small_const<3>(x[i]) : ivp_div_small_const<5>(x[i]);
+        if (std::memcmp(&a, &b, 8) != 0) ++bad;
+    }
+    return bad;
+}
+
 // ivp_pow3 next to three ivp_pow calls
 extern "C" void emul_pow3(const double *x, const double *e, double *r3, double *r1)
 {

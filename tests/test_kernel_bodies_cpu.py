@@ -218,3 +218,24 @@ def test_pow3_equals_three_pow_calls():
         assert same.all(), (x, e, r3, r1)
         n += 1
     assert n == 6000
+
+
+def test_div_by_small_constant_is_ieee_division():
+    """ivp_div_small_const<3|5> (bdf_core.h: multiply by the rounded reciprocal plus one exact-remainder correction) is
+    the IEEE quotient on the operand range change_d feeds it (zero, or 2^-52 <= |x| <= 1e51) -- and well beyond."""
+    import ctypes as C
+    from tests.host_emul import emul
+    lib = emul.lib()
+    lib.emul_div_small_const.argtypes = [C.c_int, np.ctypeslib.ndpointer(np.float64, flags="C"), C.c_long]
+    lib.emul_div_small_const.restype = C.c_long
+    rng = np.random.default_rng(20260209)
+    n = 2_000_000
+    mant = rng.integers(0, 1 << 52, n, dtype=np.uint64)
+    expo = rng.integers(1023 - 900, 1023 + 900, n, dtype=np.uint64)
+    sign = rng.integers(0, 2, n, dtype=np.uint64) << np.uint64(63)
+    x = (sign | (expo << np.uint64(52)) | mant).view(np.float64)
+    structured = np.concatenate([np.arange(-40000, 40001) * 0.125, 2.0 - rng.uniform(0.2, 12.0, 100000) * rng.integers(1, 6, 100000),
+                                 4.0 - rng.uniform(0.2, 12.0, 100000) * rng.integers(1, 6, 100000), [0.0, 2.0 ** -52, 1e51, -1e51]])   # not -0.0: see the helper's comment
+    for c in (3, 5):
+        assert lib.emul_div_small_const(c, np.ascontiguousarray(x), n) == 0
+        assert lib.emul_div_small_const(c, np.ascontiguousarray(structured), structured.size) == 0
