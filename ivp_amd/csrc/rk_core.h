@@ -128,7 +128,12 @@ __device__ __forceinline__ double ivp_fma_sgpr_addend(double a, double b, double
     return r;
 }
 #endif
-IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
+// W independent powers evaluated in lock step: statement by statement over all W operands, so that the W dependent chains
+// are interleaved in the instruction stream as written (a lone wave waits 8.5 cycles for a dependent f64 result and
+// issues every 5.5; the register-pressure-driven scheduler keeps source order).  Per operand the operations and their
+// order are those of the scalar form: W = 1 IS the scalar form.
+template <int W>
+IVP_HD void ivp_pow_core_w(const double (&x)[W], const double (&e)[W], const int (&k0)[W], double (&res)[W], uint64_t kz)
 {
     // Coefficients of the two Horner chains.  In the thread-per-trajectory kernels (IVP_HOIST = 0 / 1: two or more waves
     // per SIMD) they are kept OUT of the vector registers: with the constants pinned there LLVM
@@ -147,63 +152,91 @@ IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
 #define KP(c) KC(c)
 #endif
     (void)kz;
-    int k = k0;
-    const uint64_t u = d2u(x);
-    int ex = (int)(u >> 52) - 1023;
-    const uint64_t mant = u & 0x000FFFFFFFFFFFFFull;
-    const bool hi = mant > 0x6A09E667F3BCDull;
-    const double m = u2d(mant | (hi ? 0x3FE0000000000000ull : 0x3FF0000000000000ull));
-    ex += hi ? 1 : 0;
-    k += ex;
-    const double t = (m - 1.0) / (m + 1.0);
-    const double z = t * t;
-    double p = KP(1.0 / 25.0);
-    p = PFMA(p, z, KP(1.0 / 23.0));
-    p = PFMA(p, z, KP(1.0 / 21.0));
-    p = PFMA(p, z, KP(1.0 / 19.0));
-    p = PFMA(p, z, KP(1.0 / 17.0));
-    p = PFMA(p, z, KP(1.0 / 15.0));
-    p = PFMA(p, z, KP(1.0 / 13.0));
-    p = PFMA(p, z, KP(1.0 / 11.0));
-    p = PFMA(p, z, KP(1.0 / 9.0));
-    p = PFMA(p, z, KP(1.0 / 7.0));
-    p = PFMA(p, z, KP(1.0 / 5.0));
-    p = PFMA(p, z, KP(1.0 / 3.0));
-    p = fma(p, z, 1.0);
-    const double lnm = (2.0 * t) * p;
-    const double l2 = fma(lnm, KP(0x1.71547652b82fep+0), (double)k);
-    const double w = e * l2;
-    // w >= 1024 -> +inf and w <= -1022 -> 0 are selected at the end; a NaN w (e = +-inf with x == 1) travels through
-    const double kd = rint(w);
-    const double r = w - kd;
-    const double v = r * KP(0x1.62e42fefa39efp-1);
-    double q = KP(1.0 / 87178291200.0);
-    q = PFMA(q, v, KP(1.0 / 6227020800.0));
-    q = PFMA(q, v, KP(1.0 / 479001600.0));
-    q = PFMA(q, v, KP(1.0 / 39916800.0));
-    q = PFMA(q, v, KP(1.0 / 3628800.0));
-    q = PFMA(q, v, KP(1.0 / 362880.0));
-    q = PFMA(q, v, KP(1.0 / 40320.0));
-    q = PFMA(q, v, KP(1.0 / 5040.0));
-    q = PFMA(q, v, KP(1.0 / 720.0));
-    q = PFMA(q, v, KP(1.0 / 120.0));
-    q = PFMA(q, v, KP(1.0 / 24.0));
-    q = PFMA(q, v, KP(1.0 / 6.0));
-    q = fma(q, v, 0.5);
-    q = fma(q, v, 1.0);
-    q = fma(q, v, 1.0);
+#define IVP_W for (int w = 0; w < W; ++w)
+    int k[W];
+    double t[W], z[W], p[W];
+#pragma unroll
+    IVP_W {
+        const uint64_t u = d2u(x[w]);
+        int ex = (int)(u >> 52) - 1023;
+        const uint64_t mant = u & 0x000FFFFFFFFFFFFFull;
+        const bool hi = mant > 0x6A09E667F3BCDull;
+        const double m = u2d(mant | (hi ? 0x3FE0000000000000ull : 0x3FF0000000000000ull));
+        ex += hi ? 1 : 0;
+        k[w] = k0[w] + ex;
+        t[w] = (m - 1.0) / (m + 1.0);
+        z[w] = t[w] * t[w];
+        p[w] = KP(1.0 / 25.0);
+    }
+#define IVP_PSTEP(c) _Pragma("unroll") IVP_W p[w] = PFMA(p[w], z[w], KP(c));
+    IVP_PSTEP(1.0 / 23.0)
+    IVP_PSTEP(1.0 / 21.0)
+    IVP_PSTEP(1.0 / 19.0)
+    IVP_PSTEP(1.0 / 17.0)
+    IVP_PSTEP(1.0 / 15.0)
+    IVP_PSTEP(1.0 / 13.0)
+    IVP_PSTEP(1.0 / 11.0)
+    IVP_PSTEP(1.0 / 9.0)
+    IVP_PSTEP(1.0 / 7.0)
+    IVP_PSTEP(1.0 / 5.0)
+    IVP_PSTEP(1.0 / 3.0)
+#undef IVP_PSTEP
+    double wv[W], kd[W], v[W], q[W];
+#pragma unroll
+    IVP_W {
+        p[w] = fma(p[w], z[w], 1.0);
+        const double lnm = (2.0 * t[w]) * p[w];
+        const double l2 = fma(lnm, KP(0x1.71547652b82fep+0), (double)k[w]);
+        wv[w] = e[w] * l2;
+        // w >= 1024 -> +inf and w <= -1022 -> 0 are selected at the end; a NaN w (e = +-inf with x == 1) travels through
+        kd[w] = rint(wv[w]);
+        const double r = wv[w] - kd[w];
+        v[w] = r * KP(0x1.62e42fefa39efp-1);
+        q[w] = KP(1.0 / 87178291200.0);
+    }
+#define IVP_QSTEP(c) _Pragma("unroll") IVP_W q[w] = PFMA(q[w], v[w], KP(c));
+    IVP_QSTEP(1.0 / 6227020800.0)
+    IVP_QSTEP(1.0 / 479001600.0)
+    IVP_QSTEP(1.0 / 39916800.0)
+    IVP_QSTEP(1.0 / 3628800.0)
+    IVP_QSTEP(1.0 / 362880.0)
+    IVP_QSTEP(1.0 / 40320.0)
+    IVP_QSTEP(1.0 / 5040.0)
+    IVP_QSTEP(1.0 / 720.0)
+    IVP_QSTEP(1.0 / 120.0)
+    IVP_QSTEP(1.0 / 24.0)
+    IVP_QSTEP(1.0 / 6.0)
+#undef IVP_QSTEP
+#pragma unroll
+    IVP_W q[w] = fma(q[w], v[w], 0.5);
+#pragma unroll
+    IVP_W q[w] = fma(q[w], v[w], 1.0);
+#pragma unroll
+    IVP_W q[w] = fma(q[w], v[w], 1.0);
+#pragma unroll
+    IVP_W {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int ki = (int)kd;   // v_cvt_i32_f64 saturates; kd is out of range only where the result is replaced below
+        const int ki = (int)kd[w];   // v_cvt_i32_f64 saturates; kd is out of range only where the result is replaced below
 #else
-    const int ki = (kd >= -2000.0 && kd <= 2000.0) ? (int)kd : 0;
+        const int ki = (kd[w] >= -2000.0 && kd[w] <= 2000.0) ? (int)kd[w] : 0;
 #endif
-    double res = q * u2d((uint64_t)((uint32_t)ki + 1023u) << 52);
-    res = (w <= -1022.0) ? 0.0 : res;
-    res = (w >= 1024.0) ? u2d(0x7FF0000000000000ull) : res;
-    return res;
+        double r = q[w] * u2d((uint64_t)((uint32_t)ki + 1023u) << 52);
+        r = (wv[w] <= -1022.0) ? 0.0 : r;
+        r = (wv[w] >= 1024.0) ? u2d(0x7FF0000000000000ull) : r;
+        res[w] = r;
+    }
+#undef IVP_W
 }
 #undef KP
 #undef PFMA
+IVP_HD double ivp_pow_core(double x, double e, int k0, uint64_t kz)
+{
+    const double xs[1] = {x}, es[1] = {e};
+    const int ks[1] = {k0};
+    double r[1];
+    ivp_pow_core_w<1>(xs, es, ks, r, kz);
+    return r[0];
+}
 IVP_HD double ivp_pow_full(double x, double e, uint64_t kz)
 {
     if (e == 0.0) return 1.0;
@@ -240,8 +273,13 @@ IVP_HD void ivp_pow3(const double (&x)[3], const double (&e)[3], double (&r)[3],
         normal[i] = (d2u(x[i]) - 0x0010000000000000ull) < 0x7FE0000000000000ull;   // positive, normal, finite
         subnormal = subnormal || (x[i] > 0.0 && x[i] < 0x1p-1022 && e[i] == e[i] && e[i] != 0.0);
     }
+    const double xs[3] = {normal[0] ? x[0] : 1.0, normal[1] ? x[1] : 1.0, normal[2] ? x[2] : 1.0};
+    const int ks[3] = {0, 0, 0};
+    ivp_pow_core_w<3>(xs, e, ks, r, kz);
+    // the three results exist here, unconditionally: without this LLVM sinks each core into "if its result is selected",
+    // which puts the three chains into three consecutive branches
 #pragma unroll
-    for (int i = 0; i < 3; ++i) r[i] = ivp_pow_core(normal[i] ? x[i] : 1.0, e[i], 0, kz);
+    for (int i = 0; i < 3; ++i) IVP_OPAQUE_V(r[i]);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         double v = r[i];
