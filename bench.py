@@ -174,6 +174,11 @@ def main():
     el, out, _, og = run_case(*sh, profile=0, with_gather=dist is not None)
     acc_rank = int(out.naccpt.sum().item())
     ok = bool((out.status == 0).all().item())
+    # per-trajectory Status codes of this rank's shard (src/status.rs order).  C5: 9 of the 10 000 stiff Van der Pol
+    # trajectories end AT t_end with StepSizeTooSmall -- the reference's stagnation guard `(x + 0.1 |h|) == x` firing on a clamped
+    # last step of a few ulp (bdf.rs:308-328), reproduced bit for bit by the oracle (tests/test_gpu_parity.py compares the status words).
+    codes, counts = torch.unique(out.status, return_counts=True)
+    status_counts = {ivp_amd.Status(int(c)).name: int(k) for c, k in zip(codes.tolist(), counts.tolist())}
     nstep_rank = float(out.nstep.sum().item())
     nrej_rank = float(out.nrejct.sum().item())
     elapsed, total_acc = reduce_max_sum(el, acc_rank)
@@ -249,6 +254,7 @@ def main():
                            "from a separate instrumented pass of the same K steps (instrumented_ms_per_step, this rank)",
             "accepted_steps_per_batch": total_acc,
             "all_success": ok,
+            "status_counts": status_counts,
             "gathered_ok": gathered_ok,
             "wave_lane_utilisation": attempts / acc["slots"] if acc["slots"] else None,
             "attempts_per_s": attempts / el * 1.0, "rejection_ratio": nrej_rank / max(nstep_rank, 1.0),

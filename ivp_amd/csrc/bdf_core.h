@@ -216,14 +216,17 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
         for (int c = 0; c < N; ++c) plain = plain && fabs(d[k][c]) < u2d(0x7FF0000000000000ull);
     if (!plain) { bdf_change_d_generic<N>(d, order, factor); return; }
     constexpr BdfU U{};
-    double r[6][6];
+    // Loop nests below run with the SUMMATION index outermost: every accumulator still receives its terms in the
+    // reference's order, but consecutive instructions belong to different accumulators (a lone wave waits 8.5 cycles for
+    // a dependent f64 result and can issue an independent one after 5.5).
+    double r[6][6], fm[6];
 #pragma unroll
-    for (int m = 1; m < 6; ++m) {
-        const double fm = factor * (double)m;
-        r[0][m] = 1.0;
+    for (int m = 1; m < 6; ++m) { fm[m] = factor * (double)m; r[0][m] = 1.0; }
 #pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            const double num = (double)k - 1.0 - fm;
+    for (int k = 1; k < 6; ++k) {
+#pragma unroll
+        for (int m = 1; m < 6; ++m) {
+            const double num = (double)k - 1.0 - fm[m];
             const double quot = k == 3 ? ivp_div_small_const<3>(num) : (k == 5 ? ivp_div_small_const<5>(num) : num / (double)k);
             r[k][m] = r[k - 1][m] * quot;
         }
@@ -234,29 +237,33 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
     for (int k = 1; k < 6; ++k) keep[k] = k <= order ? 1.0 : 0.0;
     double ru[6][6];
 #pragma unroll
-    for (int k = 1; k < 6; ++k) {
+    for (int k = 1; k < 6; ++k)
 #pragma unroll
-        for (int row = 1; row < 6; ++row) {
-            double acc = r[k][1] * U.v[1][row];
+        for (int row = 1; row < 6; ++row) ru[k][row] = r[k][1] * U.v[1][row];
 #pragma unroll
-            for (int m = 2; m < 6; ++m)
-                if (m <= row) acc = acc + r[k][m] * U.v[m][row];
-            ru[k][row] = acc * keep[k];
-        }
-    }
+    for (int m = 2; m < 6; ++m)
+#pragma unroll
+        for (int k = 1; k < 6; ++k)
+#pragma unroll
+            for (int row = 1; row < 6; ++row)
+                if (m <= row) ru[k][row] = ru[k][row] + r[k][m] * U.v[m][row];
+#pragma unroll
+    for (int k = 1; k < 6; ++k)
+#pragma unroll
+        for (int row = 1; row < 6; ++row) ru[k][row] = ru[k][row] * keep[k];
     double scratch[6][N];
 #pragma unroll
     for (int c = 0; c < N; ++c) scratch[0][c] = 0.0 + 1.0 * d[0][c];
 #pragma unroll
-    for (int row = 1; row < 6; ++row) {
+    for (int row = 1; row < 6; ++row)
 #pragma unroll
-        for (int c = 0; c < N; ++c) {
-            double acc = 0.0;
+        for (int c = 0; c < N; ++c) scratch[row][c] = 0.0;
 #pragma unroll
-            for (int k = 1; k < 6; ++k) acc = acc + ru[k][row] * d[k][c];
-            scratch[row][c] = acc;
-        }
-    }
+    for (int k = 1; k < 6; ++k)
+#pragma unroll
+        for (int row = 1; row < 6; ++row)
+#pragma unroll
+            for (int c = 0; c < N; ++c) scratch[row][c] = scratch[row][c] + ru[k][row] * d[k][c];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
         if (i <= order) {
