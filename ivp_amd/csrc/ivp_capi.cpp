@@ -301,11 +301,12 @@ int enqueue_round(ivp_ctx *ctx)
     // A wave pays for the union of its lanes' control flow on every attempt, and (measured, MI355X) a wave that has its
     // CU to itself runs this branch-heavy kernel fastest: 10.95 ms with 64 lanes per wave (157 waves), 10.5 ms with 40
     // (250 waves), but 13.7-16.8 ms with 313-625 waves and 11.2 ms with 1000 -- so the active set is spread over at most
-    // one wave per CU, never thinner than 8 lanes.
+    // one wave per CU -- down to a single trajectory per wave (256 trajectories: 4.9 ms with one lane per wave, 6.6 with
+    // two, 9.6 with eight: the fewer lanes, the fewer phases a wave runs on behalf of some other lane).
     uint32_t lpw = 0;
     if (P.method == IVP_BDF && !P.group && !P.jit) {
         const uint32_t cus = 256u;
-        const uint32_t want = tune().bdf_lpw > 0 ? (uint32_t)tune().bdf_lpw : std::max(8u, (lanes + cus - 1u) / cus);
+        const uint32_t want = tune().bdf_lpw > 0 ? (uint32_t)tune().bdf_lpw : std::max(1u, (lanes + cus - 1u) / cus);
         lpw = std::min(64u, want);
     }
     for (int r = 0; r < launches_per_sync; ++r, ++P.c) {
