@@ -20,7 +20,8 @@ objects come from a separate instrumented pass of the same K steps; "wall_ms_wit
 copy of the results into pinned host memory after every solve.
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (HBM view, as the contract asks),
-"roofline_fp64" (the resource that actually binds this kernel: FP64 VALU issue) and "cpu_baseline"
+"roofline_fp64" (counted FP64 flops), "roofline_issue" (the resource that actually binds the stepping kernel:
+vector-instruction issue, from the committed SQ-counter profile) and "cpu_baseline"
 (the CPU oracle, i.e. the C restatement of the reference algorithm, timed on this host's cores).
 """
 import argparse
@@ -225,6 +226,28 @@ def main():
                               "): PMC counters of a separate profiled run of this command, not of this process"
             except Exception:
                 traffic = None
+        # VALU issue view of the dominant kernel: the thread-per-trajectory stepping kernel is bound by vector-instruction
+        # issue (one wave64 FP64 instruction per 4 cycles per SIMD at best), not by bytes or by counted flops (strict mode
+        # spends separate multiply and add instructions, 11 on a division, 18 on a square root).  Instructions per launch
+        # come from the committed SQ-counter profile of this command (profiles/r02_sq_counters_<workload>.json,
+        # SQ_INSTS_VALU, tools/profile_sq.sh), the launch duration is this run's.
+        issue = None
+        sqf = os.path.join(ROOT, "profiles", f"r02_sq_counters_{args.workload}.json")
+        chunk_launches = launches - coop_launches
+        chunk_ms = (kern_ms - coop_ms) / max(chunk_launches, 1)
+        if os.path.exists(sqf) and world == 1 and B == wl["B"] and chunk_ms > 0:
+            try:
+                sq = json.load(open(sqf))
+                ent = next(v for k, v in sq.items() if "chunk_kernel_t" in k and "coop" not in k)
+                valu = float(ent["mean_per_dispatch"]["SQ_INSTS_VALU"])
+                peak = 256 * 4 * 2.4e9 / 4.0   # SIMDs x (clock / 4 cycles per wave64 instruction), at the 2.4 GHz peak clock
+                issue = {"bound": "valu_issue", "kernel": "chunk_kernel_t", "achieved": valu / (chunk_ms * 1e-3), "peak": peak,
+                         "unit": "wave-instructions/s", "frac": valu / (chunk_ms * 1e-3) / peak, "valu_instructions_per_launch": valu,
+                         "avg_launch_ms": chunk_ms,
+                         "source": f"profiles/r02_sq_counters_{args.workload}.json (SQ_INSTS_VALU per launch, separate rocprofv3 --pmc "
+                                   "run of this command) / this run's launch duration"}
+            except Exception:
+                issue = None
         res = {
             "metric": wl["metric"],
             "value": value,
@@ -278,6 +301,7 @@ def main():
                 "frac": (tflops / FP64_PEAK_TFLOPS) if tflops is not None else None, "flop_per_attempt": flop_per_attempt,
                 "attempts_per_launch": attempts_per_launch,
             },
+            "roofline_issue": issue,
         }
         if weak is not None:
             res["weak"] = weak
