@@ -304,7 +304,7 @@ int enqueue_round(ivp_ctx *ctx)
     // one wave per CU -- down to a single trajectory per wave (256 trajectories: 4.9 ms with one lane per wave, 6.6 with
     // two, 9.6 with eight: the fewer lanes, the fewer phases a wave runs on behalf of some other lane).
     uint32_t lpw = 0;
-    if (P.method == IVP_BDF && !P.group && !P.jit) {
+    if (P.method == IVP_BDF && !P.group) {   // built-in and hiprtc right-hand sides alike
         const uint32_t cus = 256u;
         const uint32_t want = tune().bdf_lpw > 0 ? (uint32_t)tune().bdf_lpw : std::max(1u, (lanes + cus - 1u) / cus);
         lpw = std::min(64u, want);

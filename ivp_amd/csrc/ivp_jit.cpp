@@ -275,6 +275,7 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool 
         m = it->second;
     }
     unsigned grid = (lanes + IVP_WAVE - 1) / IVP_WAVE;
+    if (what == IVP_LAUNCH_CHUNK && a.lpw && r->n <= IVP_MAX_N) grid = (lanes + a.lpw - 1) / a.lpw;   // thin waves (ivp_kargs.h)
     if (r->n > IVP_MAX_N) {   // large n: a group of G lanes per trajectory, 64 / G trajectories per wave
         const unsigned per_wave = IVP_WAVE / (unsigned)ivp_group_width(r->n);
         grid = (lanes + per_wave - 1) / per_wave;
