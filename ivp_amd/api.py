@@ -304,11 +304,20 @@ class DeviceIVP(IVP):
         self.n_params = len(self._params)
         self._events = list(events)
         self._ctx = ctx or default_context()
-        h = C.c_void_p()
-        rc = self._ctx.lib.ivp_rhs_compile_ex(self._ctx.handle, source.encode(), self.n, self.n_params,
-                                              len(self._events), 1 if jac else 0, C.byref(h))
-        if rc != 0:
-            raise ConfigError(rc, self._ctx.last_error())
+        # One compiled record per distinct (source, dimensions): the record owns the hiprtc modules (one per device,
+        # method and mode, built on first use), none of which depends on the parameter VALUES or the event settings, so
+        # a second DeviceIVP with the same text -- pyfront.solve_ivp builds one per call, as the reference's Python
+        # front end wraps its callable per call -- reuses them instead of compiling again.  Records live as long as the
+        # process (a few hundred bytes of host state plus the loaded code objects).
+        key = (source, self.n, self.n_params, len(self._events), bool(jac))
+        h = _rhs_records.get(key)
+        if h is None:
+            h = C.c_void_p()
+            rc = self._ctx.lib.ivp_rhs_compile_ex(self._ctx.handle, source.encode(), self.n, self.n_params,
+                                                  len(self._events), 1 if jac else 0, C.byref(h))
+            if rc != 0:
+                raise ConfigError(rc, self._ctx.last_error())
+            _rhs_records[key] = h
         self.handle = h
 
     def params(self):
@@ -320,13 +329,8 @@ class DeviceIVP(IVP):
     def event_config(self, index):
         return self._events[index]
 
-    def __del__(self):
-        try:
-            if getattr(self, "handle", None):
-                self._ctx.lib.ivp_rhs_free(self.handle)
-                self.handle = None
-        except Exception:
-            pass
+
+_rhs_records: dict = {}   # (source, n, n_params, n_events, jac) -> ivp_rhs_compile_ex handle
 
 
 # ------------------------------------------------------------------------------------------------
