@@ -179,7 +179,8 @@ def main():
     # trajectories end AT t_end with StepSizeTooSmall -- the reference's stagnation guard `(x + 0.1 |h|) == x` firing on a clamped
     # last step of a few ulp (bdf.rs:308-328), reproduced bit for bit by the oracle (tests/test_gpu_parity.py compares the status words).
     codes, counts = torch.unique(out.status, return_counts=True)
-    status_counts = {ivp_amd.Status(int(c)).name: int(k) for c, k in zip(codes.tolist(), counts.tolist())}
+    names = {int(v): v.name for v in ivp_amd.Status}
+    status_counts = {names.get(int(c), str(int(c))): int(k) for c, k in zip(codes.tolist(), counts.tolist())}
     nstep_rank = float(out.nstep.sum().item())
     nrej_rank = float(out.nrejct.sum().item())
     elapsed, total_acc = reduce_max_sum(el, acc_rank)
