@@ -115,8 +115,42 @@ struct BdfG {
                 mult[c] = 0.0;
                 if (i > k && i < NT) { mult[c] = -a[(size_t)k * NT + i] * t; a[(size_t)k * NT + i] = mult[c]; }
             }
+            // The trailing columns are independent of each other for a fixed k: JB of them are in flight at once (all
+            // their loads are issued before the first dependent instruction), which is what a lone wavefront working out
+            // of L2 needs -- one column at a time it waits a full memory round trip per column, ~n^2/2 times per LU.
+            constexpr int JB = 4;
+            int j = k + 1;
 #pragma unroll 1
-            for (int j = k + 1; j < NT; ++j) {
+            for (; j + JB <= NT; j += JB) {
+                double tj[JB], akj[JB], cur[JB][C];
+#pragma unroll
+                for (int b = 0; b < JB; ++b) {
+                    const double *col = a + (size_t)(j + b) * NT;
+                    tj[b] = col[m]; akj[b] = col[k];   // read before anything in this column is written
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const int i = gi(c);
+                        cur[b][c] = (i > k && i < NT && i != m) ? col[i] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < JB; ++b) {
+                    double *col = a + (size_t)(j + b) * NT;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const int i = gi(c);
+                        if (i > k && i < NT) {
+                            double v = (i == m) ? akj[b] : cur[b][c];   // row m receives row k's entry (the swap)
+                            if (tj[b] != 0.0) v += mult[c] * tj[b];
+                            col[i] = v;
+                        } else if (i == k) {
+                            col[i] = tj[b];
+                        }
+                    }
+                }
+            }
+#pragma unroll 1
+            for (; j < NT; ++j) {
                 double *col = a + (size_t)j * NT;
                 const double tj = col[m], akj = col[k];   // read before anything in this column is written
 #pragma unroll
@@ -146,34 +180,60 @@ struct BdfG {
         for (int c = 0; c < C; ++c) if (own(c)) b[gi(c)] = bl[c];
         __syncthreads();
         if (NT == 1) { if (gl() == 0) b[0] /= a[0]; __syncthreads(); bl[0] = b[0]; return; }
+        // each of the 2n pivot steps needs one column of the factors from memory: the next step's column (and pivot index)
+        // is fetched while the current step runs, so that the steps do not each start with a memory round trip
+        double cnext[C];
+        int mnext = (int)piv[0];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = (i > 0 && i < NT) ? a[i] : 0.0; }
 #pragma unroll 1
         for (int k = 0; k < NT - 1; ++k) {
-            const int m = (int)piv[k];
+            const int m = mnext;
+            double ccur[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) ccur[c] = cnext[c];
+            if (k + 1 < NT - 1) {
+                mnext = (int)piv[k + 1];
+                const double *ncol = a + (size_t)(k + 1) * NT;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = (i > k + 1 && i < NT) ? ncol[i] : 0.0; }
+            }
             const double t = b[m], bk_old = b[k];
             __syncthreads();
             if (gl() == 0) { b[m] = bk_old; b[k] = t; }
-            const double *col = a + (size_t)k * NT;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = gi(c);
                 if (i > k && i < NT) {
                     const double bi = (i == m) ? bk_old : b[i];
-                    b[i] = bi + col[i] * t;
+                    b[i] = bi + ccur[c] * t;
                 }
             }
             __syncthreads();
         }
+        double dnext = a[(size_t)(NT - 1) * NT + (NT - 1)];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = i < NT - 1 ? a[(size_t)(NT - 1) * NT + i] : 0.0; }
 #pragma unroll 1
         for (int kb = 1; kb < NT; ++kb) {
             const int k = NT - kb;
-            const double *col = a + (size_t)k * NT;
-            const double bk = b[k] / col[k];
+            double ccur[C];
+            const double dcur = dnext;
+#pragma unroll
+            for (int c = 0; c < C; ++c) ccur[c] = cnext[c];
+            if (k - 1 >= 1) {
+                const double *ncol = a + (size_t)(k - 1) * NT;
+                dnext = ncol[k - 1];
+#pragma unroll
+                for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = i < k - 1 ? ncol[i] : 0.0; }
+            }
+            const double bk = b[k] / dcur;
             __syncthreads();
             if (gl() == 0) b[k] = bk;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = gi(c);
-                if (i < k) b[i] += col[i] * -bk;
+                if (i < k) b[i] += ccur[c] * -bk;
             }
             __syncthreads();
         }
