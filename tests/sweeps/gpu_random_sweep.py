@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Offline randomised differential sweep on the GPU: tests/test_differential_random_cpu.random_case() for a range of
 seeds, the product path (default policy and, for DOPRI5 / DOP853, the lane-cooperative kernels) against the oracle, bit
-for bit.  Usage (on the GPU box, from the repo root):  python tools/gpu_random_sweep.py FIRST_SEED COUNT [report.json]
+for bit.  Usage (on the GPU box, from the repo root):  python tests/sweeps/gpu_random_sweep.py FIRST_SEED COUNT [report.json]
 Prints a progress line every 500 seeds; exits non-zero on the first mismatch (the assertion names the seed)."""
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests.common import gpu_batch  # noqa: E402
 from tests.test_differential_random_cpu import compare, random_case  # noqa: E402
