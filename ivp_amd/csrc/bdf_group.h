@@ -295,6 +295,19 @@ __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32
             } else if (a.t_log != nullptr) {
                 so_push_log<M_BDF, C, P, MAP>(a, j, L, L.x0, y);
             }
+            if (a.collect_dense && a.max_log > 0) {  // ContinuousOutput::constant, BDF layout (cont.rs:44-51)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (!MAP::own(c)) continue;
+                    const size_t g = (size_t)MAP::gi(c) * 7;
+                    a.seg_cont[(g + 0) * B + j] = y[c];
+                    for (int s7 = 1; s7 < 6; ++s7) a.seg_cont[(g + s7) * B + j] = 0.0;
+                    a.seg_cont[(g + 6) * B + j] = 1.0;
+                }
+                a.seg_xold[j] = L.x0;
+                a.seg_h[j] = 1e-15;
+                L.n_seg = 1;
+            }
         }
         store_so();
         a.x[j] = L.x0; a.h[j] = 0.0; a.flags[j] = 0; a.status[j] = 0;

@@ -155,8 +155,6 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     if (prob->n != n || prob->n_params != p)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "problem dims (n=%d,p=%d) do not match rhs (n=%d,p=%d)", prob->n, prob->n_params, n, p);
     if (n < 1 || n > IVP_MAX_GROUP_N || p > IVP_MAX_P) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
-    if (n > IVP_MAX_N && opt->method == IVP_BDF && opt->dense_output)   // wave-per-trajectory BDF (bdf_group.h)
-        return fail(ctx, IVP_ERR_BAD_ARGUMENT, "n = %d > %d: BDF does not collect dense-output segments for large-n problems (t_eval / step log are available)", n, IVP_MAX_N);
     if (B == 0 || B > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "batch size %zu out of range", B);
     if (opt->method == IVP_RADAU)
         return fail(ctx, IVP_ERR_UNSUPPORTED_METHOD, "method %d (RADAU) is not on the accelerated path", opt->method);

@@ -720,9 +720,15 @@ IVP_HD void so_collect_dense(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, doubl
     if (a.collect_dense && x != xold && cont != nullptr && h != 0.0) {
         if (L.n_seg < a.max_log) {
             const size_t k = L.n_seg;
+            if (M == M_BDF) {   // per-state blocks [D0, D1..D5, order] (cont.rs:44-51): local (state i, slot s) -> global state
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (MAP::own(c % N)) a.seg_cont[(k * NCT + (size_t)(c / N) * MAP::NT + MAP::gi(c % N)) * B + j] = cont[c];
+                for (int c = 0; c < NC; ++c)
+                    if (MAP::own(c / 7)) a.seg_cont[(k * NCT + (size_t)MAP::gi(c / 7) * 7 + (size_t)(c % 7)) * B + j] = cont[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (MAP::own(c % N)) a.seg_cont[(k * NCT + (size_t)(c / N) * MAP::NT + MAP::gi(c % N)) * B + j] = cont[c];
+            }
             a.seg_xold[k * B + j] = ixold;
             a.seg_h[k * B + j] = h;
         }

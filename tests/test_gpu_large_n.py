@@ -319,8 +319,31 @@ def test_bdf_heat1d256_stiff_equals_the_oracle():
     assert np.array_equal(got["n_filled"], ref["n_filled"]) and np.array_equal(got["y_eval"][:9], ref["y_eval"][:9])
 
 
-def test_bdf_large_n_rejects_dense_output():
+def test_bdf_large_n_dense_output_equals_the_oracle():
+    """Dense-output segments of the wave-per-trajectory BDF (per-state blocks [D0, D1..D5, order], cont.rs:44-51): step
+    record, interpolant and counters of a stiff 256-cell heat equation and of the N = 100 decay system, bit for bit."""
     import ivp_amd
-    y0, p, t0, t1 = _decay_batch(2)
-    with pytest.raises(ivp_amd.ConfigError):
-        ivp_amd.solve_ivp_batch(ivp_amd.LinearDecay100(), t0, t1, y0, None, ivp_amd.Options(method="BDF", dense_output=True, max_log=16))
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    x = np.linspace(0.0, 1.0, 258)[1:-1]
+    y0 = np.sin(np.pi * x) + 0.05 * rng.standard_normal(256)
+    s = ivp_amd.solve_ivp(ivp_amd.Heat1D256(800.0), 0.0, 0.05, y0, ivp_amd.Options(method="BDF", rtol=1e-5, atol=1e-8, dense_output=True))
+    o = O.solve_ivp("heat1d256", 0.0, 0.05, list(y0), params=[800.0], method="BDF", rtol=1e-5, atol=1e-8, dense_output=True, detpow=True)
+    assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
+    assert (s.nfev, s.njev, s.nlu, s.naccpt, s.nrejct) == (o.nfev, o.njev, o.nlu, o.naccpt, o.nrejct)
+    assert s.sol_span() == o.sol_span()
+    for tq in (0.0, 1e-4, 0.0123, 0.04999, 0.05):
+        assert np.array_equal(s.sol(tq), o.sol(tq))
+    y1 = np.linspace(0.5, 1.5, 100)
+    s = ivp_amd.solve_ivp(ivp_amd.LinearDecay100(), 2.0, 0.5, y1, ivp_amd.Options(method="BDF", rtol=1e-6, atol=1e-9, dense_output=True, t_eval=[2.0, 1.5, 1.0, 0.5]))
+    o = O.solve_ivp("linear_decay100", 2.0, 0.5, list(y1), method="BDF", rtol=1e-6, atol=1e-9, dense_output=True, t_eval=[2.0, 1.5, 1.0, 0.5], detpow=True)
+    assert np.array_equal(s.t, o.t) and np.array_equal(s.y, o.y)
+    for tq in (2.0, 1.77, 0.9, 0.5):
+        assert np.array_equal(s.sol(tq), o.sol(tq))
+    # a zero-length interval inside a batch: the constant interpolant (cont.rs:44-51)
+    yb = np.stack([y1, y1 * 2.0], axis=1)
+    r = ivp_amd.solve_ivp_batch(ivp_amd.LinearDecay100(), np.array([1.0, 1.0]), np.array([1.0, 1.2]), yb, None,
+                                ivp_amd.Options(method="BDF", dense_output=True, max_log=64))
+    assert int(r.n_seg[0]) == 1 and float(r.seg_h[0, 0]) == 1e-15 and float(r.seg_xold[0, 0]) == 1.0
+    blk = np.asarray(r.seg_cont[0, :, 0]).reshape(100, 7)
+    assert np.array_equal(blk[:, 0], y1) and (blk[:, 1:6] == 0.0).all() and (blk[:, 6] == 1.0).all()
