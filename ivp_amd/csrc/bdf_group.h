@@ -115,38 +115,83 @@ struct BdfG {
                 mult[c] = 0.0;
                 if (i > k && i < NT) { mult[c] = -a[(size_t)k * NT + i] * t; a[(size_t)k * NT + i] = mult[c]; }
             }
-            // The trailing columns are independent of each other for a fixed k: JB of them are in flight at once (all
-            // their loads are issued before the first dependent instruction), which is what a lone wavefront working out
-            // of L2 needs -- one column at a time it waits a full memory round trip per column, ~n^2/2 times per LU.
+            // The trailing columns are independent of each other for a fixed k.  A lone wavefront working out of L2 pays a
+            // full memory round trip for whatever it waits on, and on this architecture one counter covers loads AND
+            // stores: blocks of JB columns are therefore double-buffered -- the loads of the next block are issued before
+            // the current block is updated and stored, so the wave only ever waits for loads that are a block old.
             constexpr int JB = 4;
-            int j = k + 1;
-#pragma unroll 1
-            for (; j + JB <= NT; j += JB) {
-                double tj[JB], akj[JB], cur[JB][C];
+            struct Blk { double tj[JB], akj[JB], cur[JB][C]; };
+            // Branch-free per element: a 64-row chunk that lies entirely above the pivot row is skipped by a SCALAR test
+            // (k is wave-uniform); inside the chunk that holds row k the rows above it are written back unchanged.  What
+            // a row does -- receive row k's entry (the swap), take the update, become U[k][j] -- are selects on masks
+            // that depend on the row only, so they are formed once per pivot, not once per element: per-element exec-mask
+            // branches were 40 % of this kernel's instruction stream (SQ_INSTS_SALU + SQ_INSTS_BRANCH vs SQ_INSTS_VALU).
+            bool is_m[C], below[C], is_k[C], in_range[C];
 #pragma unroll
-                for (int b = 0; b < JB; ++b) {
-                    const double *col = a + (size_t)(j + b) * NT;
-                    tj[b] = col[m]; akj[b] = col[k];   // read before anything in this column is written
+            for (int c = 0; c < C; ++c) {
+                const int i = gi(c);
+                is_m[c] = i == m; below[c] = i > k; is_k[c] = i == k; in_range[c] = i < NT;
+            }
+            auto fetch = [&](int jb, Blk &q) {
+                const double *col0 = a + (size_t)jb * NT;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const int i = gi(c);
-                        cur[b][c] = (i > k && i < NT && i != m) ? col[i] : 0.0;
+                for (int b = 0; b < JB; ++b) { q.tj[b] = col0[(size_t)b * NT + m]; q.akj[b] = col0[(size_t)b * NT + k]; }   // read before anything in these columns is written
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (G * c + (G - 1) < k) continue;                        // whole chunk above the pivot row (scalar test)
+                    const double *row = col0 + gi(c);
+                    if ((c + 1) * G <= NT || in_range[c]) {
+#pragma unroll
+                        for (int b = 0; b < JB; ++b) q.cur[b][c] = row[(size_t)b * NT];
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < JB; ++b) q.cur[b][c] = 0.0;
                     }
                 }
+            };
+            auto finish = [&](int jb, const Blk &q) {
+                double *col0 = a + (size_t)jb * NT;
+                bool upd[JB];
 #pragma unroll
-                for (int b = 0; b < JB; ++b) {
-                    double *col = a + (size_t)(j + b) * NT;
+                for (int b = 0; b < JB; ++b) upd[b] = q.tj[b] != 0.0;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const int i = gi(c);
-                        if (i > k && i < NT) {
-                            double v = (i == m) ? akj[b] : cur[b][c];   // row m receives row k's entry (the swap)
-                            if (tj[b] != 0.0) v += mult[c] * tj[b];
-                            col[i] = v;
-                        } else if (i == k) {
-                            col[i] = tj[b];
-                        }
+                for (int c = 0; c < C; ++c) {
+                    if (G * c + (G - 1) < k) continue;
+                    double out[JB];
+#pragma unroll
+                    for (int b = 0; b < JB; ++b) {
+                        const double v = is_m[c] ? q.akj[b] : q.cur[b][c];   // row m receives row k's entry (the swap)
+                        const double w = v + mult[c] * q.tj[b];
+                        const double v2 = (upd[b] && below[c]) ? w : v;
+                        out[b] = is_k[c] ? q.tj[b] : v2;
                     }
+                    if ((c + 1) * G <= NT || in_range[c]) {
+                        double *row = col0 + gi(c);
+#pragma unroll
+                        for (int b = 0; b < JB; ++b) row[(size_t)b * NT] = out[b];
+                    }
+                }
+            };
+            int j = k + 1;
+            if (j + JB <= NT) {
+                Blk p, q;
+                fetch(j, p);
+#pragma unroll 1
+                while (j + 3 * JB <= NT) {   // two blocks per trip: the buffers swap roles without register copies
+                    fetch(j + JB, q);
+                    finish(j, p);
+                    fetch(j + 2 * JB, p);
+                    finish(j + JB, q);
+                    j += 2 * JB;
+                }
+                if (j + 2 * JB <= NT) {
+                    fetch(j + JB, q);
+                    finish(j, p);
+                    finish(j + JB, q);
+                    j += 2 * JB;
+                } else {
+                    finish(j, p);
+                    j += JB;
                 }
             }
 #pragma unroll 1
