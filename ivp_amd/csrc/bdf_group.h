@@ -115,13 +115,17 @@ struct BdfG {
                 mult[c] = 0.0;
                 if (i > k && i < NT) { mult[c] = -a[(size_t)k * NT + i] * t; a[(size_t)k * NT + i] = mult[c]; }
             }
-            // The trailing columns are independent of each other for a fixed k.  A lone wavefront working out of L2 pays a
-            // full memory round trip for whatever it waits on, and on this architecture one counter covers loads AND
-            // stores: blocks of JB columns are therefore double-buffered -- the loads of the next block are issued before
-            // the current block is updated and stored, so the wave only ever waits for loads that are a block old.
+            // Trailing update.  A column j > k changes only if its pivot-row entry t_j = a[m][j] is non-zero (the reference
+            // guards the update with `t != 0`, lu.rs:88-104) or if the row exchange moves two different values; for a
+            // banded or sparse Jacobian -- the method-of-lines systems this path exists for -- that is a handful of columns
+            // per pivot instead of n - k.  One strided load per G columns finds them (lane <-> column), a ballot turns
+            // them into a bit mask, and only flagged columns are read, updated and written, JB at a time (their loads
+            // are all issued before the first dependent instruction: a lone wavefront working out of L2 pays a full
+            // memory round trip for whatever it waits on).  Skipped columns are exactly those the reference leaves
+            // bit-for-bit unchanged; a dense matrix flags every column and costs two extra loads per 64 columns.
             constexpr int JB = 4;
             struct Blk { double tj[JB], akj[JB], cur[JB][C]; };
-            // Branch-free per element: a 64-row chunk that lies entirely above the pivot row is skipped by a SCALAR test
+            // Branch-free per element: a G-row chunk that lies entirely above the pivot row is skipped by a SCALAR test
             // (k is wave-uniform); inside the chunk that holds row k the rows above it are written back unchanged.  What
             // a row does -- receive row k's entry (the swap), take the update, become U[k][j] -- are selects on masks
             // that depend on the row only, so they are formed once per pivot, not once per element: per-element exec-mask
@@ -132,82 +136,60 @@ struct BdfG {
                 const int i = gi(c);
                 is_m[c] = i == m; below[c] = i > k; is_k[c] = i == k; in_range[c] = i < NT;
             }
-            auto fetch = [&](int jb, Blk &q) {
-                const double *col0 = a + (size_t)jb * NT;
+            auto fetch = [&](const int (&jc)[JB], const bool (&act)[JB], Blk &q) {
 #pragma unroll
-                for (int b = 0; b < JB; ++b) { q.tj[b] = col0[(size_t)b * NT + m]; q.akj[b] = col0[(size_t)b * NT + k]; }   // read before anything in these columns is written
+                for (int b = 0; b < JB; ++b) {   // read before anything in these columns is written
+                    q.tj[b] = 0.0; q.akj[b] = 0.0;
+                    if (act[b]) { const double *col = a + (size_t)jc[b] * NT; q.tj[b] = col[m]; q.akj[b] = col[k]; }
+                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (G * c + (G - 1) < k) continue;                        // whole chunk above the pivot row (scalar test)
-                    const double *row = col0 + gi(c);
-                    if ((c + 1) * G <= NT || in_range[c]) {
 #pragma unroll
-                        for (int b = 0; b < JB; ++b) q.cur[b][c] = row[(size_t)b * NT];
-                    } else {
-#pragma unroll
-                        for (int b = 0; b < JB; ++b) q.cur[b][c] = 0.0;
+                    for (int b = 0; b < JB; ++b) {
+                        q.cur[b][c] = 0.0;
+                        if (act[b] && ((c + 1) * G <= NT || in_range[c])) q.cur[b][c] = a[(size_t)jc[b] * NT + gi(c)];
                     }
                 }
             };
-            auto finish = [&](int jb, const Blk &q) {
-                double *col0 = a + (size_t)jb * NT;
+            auto finish = [&](const int (&jc)[JB], const bool (&act)[JB], const Blk &q) {
                 bool upd[JB];
 #pragma unroll
                 for (int b = 0; b < JB; ++b) upd[b] = q.tj[b] != 0.0;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (G * c + (G - 1) < k) continue;
-                    double out[JB];
 #pragma unroll
                     for (int b = 0; b < JB; ++b) {
                         const double v = is_m[c] ? q.akj[b] : q.cur[b][c];   // row m receives row k's entry (the swap)
                         const double w = v + mult[c] * q.tj[b];
                         const double v2 = (upd[b] && below[c]) ? w : v;
-                        out[b] = is_k[c] ? q.tj[b] : v2;
-                    }
-                    if ((c + 1) * G <= NT || in_range[c]) {
-                        double *row = col0 + gi(c);
-#pragma unroll
-                        for (int b = 0; b < JB; ++b) row[(size_t)b * NT] = out[b];
+                        const double out = is_k[c] ? q.tj[b] : v2;
+                        if (act[b] && ((c + 1) * G <= NT || in_range[c])) a[(size_t)jc[b] * NT + gi(c)] = out;
                     }
                 }
             };
-            int j = k + 1;
-            if (j + JB <= NT) {
-                Blk p, q;
-                fetch(j, p);
 #pragma unroll 1
-                while (j + 3 * JB <= NT) {   // two blocks per trip: the buffers swap roles without register copies
-                    fetch(j + JB, q);
-                    finish(j, p);
-                    fetch(j + 2 * JB, p);
-                    finish(j + JB, q);
-                    j += 2 * JB;
-                }
-                if (j + 2 * JB <= NT) {
-                    fetch(j + JB, q);
-                    finish(j, p);
-                    finish(j + JB, q);
-                    j += 2 * JB;
-                } else {
-                    finish(j, p);
-                    j += JB;
-                }
-            }
+            for (int j0 = k + 1; j0 < NT; j0 += G) {
+                const int jj = j0 + gl();
+                double tjv = 0.0, akv = 0.0;
+                if (jj < NT) { tjv = a[(size_t)jj * NT + m]; akv = a[(size_t)jj * NT + k]; }
+                const bool need = jj < NT && (tjv != 0.0 || (m != k && d2u(tjv) != d2u(akv)));
+                unsigned long long todo = __ballot(need);
+                if (G < IVP_WAVE) todo = (todo >> wl0()) & ((1ull << (G & 63)) - 1ull);   // this group's columns
 #pragma unroll 1
-            for (; j < NT; ++j) {
-                double *col = a + (size_t)j * NT;
-                const double tj = col[m], akj = col[k];   // read before anything in this column is written
+                while (__any(todo != 0ull)) {
+                    int jc[JB];
+                    bool act[JB];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const int i = gi(c);
-                    if (i > k && i < NT) {
-                        double cur = (i == m) ? akj : col[i];   // row m receives row k's entry (the swap)
-                        if (tj != 0.0) cur += mult[c] * tj;
-                        col[i] = cur;
-                    } else if (i == k) {
-                        col[i] = tj;
+                    for (int b = 0; b < JB; ++b) {
+                        act[b] = todo != 0ull;
+                        jc[b] = j0 + (act[b] ? __ffsll((long long)todo) - 1 : 0);
+                        todo &= todo - 1ull;
                     }
+                    Blk q;
+                    fetch(jc, act, q);
+                    finish(jc, act, q);
                 }
             }
             __syncthreads();   // column k+1 is complete before the next pivot search reads it
