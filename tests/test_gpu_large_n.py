@@ -347,3 +347,42 @@ def test_bdf_large_n_dense_output_equals_the_oracle():
     assert int(r.n_seg[0]) == 1 and float(r.seg_h[0, 0]) == 1e-15 and float(r.seg_xold[0, 0]) == 1.0
     blk = np.asarray(r.seg_cont[0, :, 0]).reshape(100, 7)
     assert np.array_equal(blk[:, 0], y1) and (blk[:, 1:6] == 0.0).all() and (blk[:, 6] == 1.0).all()
+
+
+@pytest.mark.parametrize("n", [12, 24])
+def test_bdf_small_groups_dense_jacobian_equals_the_oracle(n):
+    """Wave-per-trajectory BDF with SEVERAL trajectories per wavefront (n = 12: groups of 16 lanes, n = 24: groups of 32):
+    a dense, differently scaled linear system per trajectory, so that the groups of one wave pivot differently and flag
+    different trailing columns in `lu_decomp`; every trajectory equals the oracle driven by the same formula."""
+    import ivp_amd
+    from oracle import oracle as O
+    src = f"""
+__device__ double ode_comp(int i, double t, const double* y, const double* p)
+{{
+    double s = 0.0;
+    for (int j = 0; j < {n}; ++j) s += ((double)((i * 7 + j * 13) % 11 - 5) / 4.0 - (i == j ? ((i & 1) ? 0.25 : 6.0) : 0.0)) * y[j];
+    return p[0] * s + (double)(i % 3 - 1) * 0.5;
+}}
+"""
+    A = [[((i * 7 + j * 13) % 11 - 5) / 4.0 - ((0.25 if i & 1 else 6.0) if i == j else 0.0) for j in range(n)] for i in range(n)]
+
+    def fun(t, y, p):
+        out = []
+        for i in range(n):
+            s = 0.0
+            for j in range(n):
+                s += A[i][j] * float(y[j])
+            out.append(float(p[0]) * s + float(i % 3 - 1) * 0.5)
+        return out
+
+    B = 7
+    rng = np.random.default_rng(n)
+    y0 = rng.standard_normal((n, B))
+    scale = np.array([[1.0, 40.0, 0.3, 12.0, 7.0, 25.0, 2.5]])   # odd rows are not diagonally dominant: I - cJ needs row exchanges
+    f = ivp_amd.DeviceIVP(src, n=n, params=(1.0,))
+    r = ivp_amd.solve_ivp_batch(f, 0.0, 0.25, y0, scale, ivp_amd.Options(method="BDF", rtol=1e-6, atol=1e-9))
+    for b in range(B):
+        o = O.solve_ivp(fun, 0.0, 0.25, list(y0[:, b]), params=[float(scale[0, b])], method="BDF", rtol=1e-6, atol=1e-9, detpow=True)
+        assert int(r.status[b]) == int(o.status)
+        assert (int(r.nfev[b]), int(r.njev[b]), int(r.nlu[b]), int(r.naccpt[b]), int(r.nrejct[b])) == (o.nfev, o.njev, o.nlu, o.naccpt, o.nrejct), b
+        assert np.array_equal(np.asarray(r.y_end)[:, b], o.y[-1]), b
