@@ -490,7 +490,7 @@ template <class R, bool FULL>
 IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R::N, R::P> &L)
 {
     KC_SCOPE_KZ(L.kz)
-    constexpr int N = R::N, P = R::P;
+    constexpr int N = R::N;
     constexpr BdfTables T{};
     constexpr double EPS = 2.220446049250313e-16, MIN_POSITIVE = 2.2250738585072014e-308;
     constexpr int newton_maxiter = 4;
