@@ -70,6 +70,39 @@ def test_result_object_and_argument_checks():   # result.rs:60-99, solve.rs:150-
         solve_ivp(api.ExponentialDecay(0.5), (0, 0), [1.0], args=(1.0,))
 
 
+def test_device_source_assembly(monkeypatch):
+    """What pyfront hands to DeviceIVP: the ode body wrapped, one `events` function from the Event expressions with the
+    reference's attribute semantics (solve.rs:246-289: `terminal` only as a bool, `direction` truncated to its sign), a
+    constant Jacobian written out row-major, `args` as parameter values; the Jacobian is dropped for explicit methods."""
+    from ivp_amd import pyfront
+    seen = {}
+
+    class Recorder(api.IVP):
+        def __init__(self, source, n, params=(), ctx=None, events=(), jac=False):
+            seen.update(source=source, n=n, params=params, events=list(events), jac=jac)
+            raise api.ConfigError(-100, "recorded")
+
+    monkeypatch.setattr(api, "DeviceIVP", Recorder)
+    evs = [Event("y[0]", direction=-1), Event("y[1] - p[0]", terminal=True, direction=2.9), Event("x - 3", terminal=1)]
+    with pytest.raises(api.ConfigError):
+        solve_ivp("dydx[0] = y[1]; dydx[1] = -p[0] * y[0];", (0, 1), [1.0, 0.0], method="BDF", events=evs, args=(4,),
+                  jac=np.array([[0, 1], [-4, 0]]))
+    assert seen["n"] == 2 and seen["params"] == (4.0,) and seen["jac"] is True
+    src = seen["source"]
+    assert "__device__ void ode(double x, const double* y, double* dydx, const double* p)" in src
+    assert "g[0] = (y[0]);" in src and "g[1] = (y[1] - p[0]);" in src and "g[2] = (x - 3);" in src
+    assert "j[0] = 0.0;" in src and "j[1] = 1.0;" in src and "j[2] = -4.0;" in src and "j[3] = 0.0;" in src
+    cfg = seen["events"]
+    assert (cfg[0].direction, cfg[0].terminal_count) == (api.Direction.Negative, None)
+    assert (cfg[1].direction, cfg[1].terminal_count) == (api.Direction.Positive, 1)
+    assert (cfg[2].direction, cfg[2].terminal_count) == (api.Direction.All, None)      # terminal = 1 is not a bool
+    with pytest.raises(api.ConfigError):
+        solve_ivp("dydx[0] = -y[0];", (0, 1), [1.0], method="RK45", jac="j[0] = -1;")
+    assert seen["jac"] is False and "void jac" not in seen["source"]
+    with pytest.raises(ValueError):
+        solve_ivp("dydx[0] = -y[0];", (0, 1), [1.0], method="BDF", jac=np.zeros((2, 2)))
+
+
 # ---- the path proper ------------------------------------------------------------------------------------------------
 @gpu
 @pytest.mark.parametrize("method", METHODS)
