@@ -337,7 +337,8 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
  * User-defined right-hand side: the device-side `impl IVP for T { fn ode(..) }` (src/ivp.rs:29).
  * `ode_source` is HIP device code defining
  *     __device__ void ode(double x, const double* y, double* dydx, const double* p);
- * for state dimension n <= 8 and n_params <= 4 parameters; it is compiled with hiprtc for the context's
+ * for state dimension n <= 8 and n_params <= 16 parameters (the fields of the user's struct, one value of each per
+ * trajectory); it is compiled with hiprtc for the context's
  * device and instantiates the same stepping kernels as the built-ins.  Free with ivp_rhs_free().
  * For 8 < n <= 512 (wave-per-trajectory kernels, see IVP_RHS_LINEAR_DECAY_100) the snippet defines the
  * component form instead -- y points at the whole state, the function returns dy_i/dx:

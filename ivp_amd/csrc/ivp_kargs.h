@@ -5,7 +5,7 @@
 #endif
 
 #define IVP_MAX_N 8        // largest state dimension a thread-per-trajectory kernel keeps in VGPRs
-#define IVP_MAX_P 4
+#define IVP_MAX_P 16
 #define IVP_WAVE 64        // CDNA wavefront
 #define IVP_RUNNING (-1)   // status[] sentinel while a trajectory is still being integrated
 

@@ -329,3 +329,25 @@ def test_builtin_problem_and_failure_status():   # an IVP instance as `fun`; sta
     assert res.status == 1 and res.t_events[0].size == 1 and res.y_events[0].shape == (1, 2)
     res = solve_ivp(api.VanDerPol(1.0), (0, 100), [2.0, 0.0], max_steps=5)
     assert res.status == -1 and not res.success and res.message == "NeedLargerNMax"
+
+
+@gpu
+def test_nine_args():
+    """`args` longer than the four values of round 1 (the fields of the user's struct are per-trajectory parameters, up to
+    16 of them): a 3 x 3 linear system whose matrix arrives through `args`, against expm and, bit for bit, the oracle."""
+    from scipy.linalg import expm
+    from oracle import oracle as O
+    A = np.array([[-0.5, 2.0, 0.1], [-2.0, -0.3, 0.4], [0.2, -0.1, -1.5]])
+    src = ("dydx[0] = p[0] * y[0] + p[1] * y[1] + p[2] * y[2];"
+           "dydx[1] = p[3] * y[0] + p[4] * y[1] + p[5] * y[2];"
+           "dydx[2] = p[6] * y[0] + p[7] * y[1] + p[8] * y[2];")
+    y0 = [1.0, -0.5, 0.25]
+    res = solve_ivp(src, (0, 3), y0, method="DOP853", args=tuple(A.ravel()), rtol=1e-10, atol=1e-12)
+    assert res.success
+    assert_allclose(res.y[:, -1], expm(3.0 * A) @ np.array(y0), rtol=1e-8, atol=1e-10)
+
+    def fun(t, y, p):
+        return [p[0] * y[0] + p[1] * y[1] + p[2] * y[2], p[3] * y[0] + p[4] * y[1] + p[5] * y[2], p[6] * y[0] + p[7] * y[1] + p[8] * y[2]]
+
+    ref = O.solve_ivp(fun, 0.0, 3.0, y0, params=list(A.ravel()), method="DOP853", rtol=1e-10, atol=1e-12, detpow=True)
+    assert np.array_equal(res.t, ref.t) and np.array_equal(res.y.T, ref.y) and res.nfev == ref.nfev
