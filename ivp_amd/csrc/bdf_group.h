@@ -98,11 +98,38 @@ struct BdfG {
         __syncthreads();
 #pragma unroll 1
         for (int k = 0; k < NT - 1; ++k) {
-            const double akk = a[(size_t)k * NT + k];
+            // One memory round trip brings everything the pivot step needs from column k: the diagonal entry (the same
+            // address in every lane) and this lane's rows.  The pivot search carries the signed entry along with
+            // (|entry|, row), and the multipliers are formed from the values already in registers -- the three further
+            // dependent loads of the plain formulation (pivot value, swapped column) were a third of a pivot's latency.
+            const double *colk_p = a + (size_t)k * NT;
+            const double akk = colk_p[k];
+            double colk[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = gi(c);
+                colk[c] = (i >= k && i < NT) ? colk_p[i] : 0.0;
+            }
+            double lv = -1.0, sv = 0.0;   // first row >= k attaining max |a[row][k]| (NaNs never win)
+            int li = NT;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = gi(c);
+                if (i >= k && i < NT) {
+                    const double v = fabs(colk[c]);
+                    if (v > lv) { lv = v; li = i; sv = colk[c]; }
+                }
+            }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(lv, o), os = __shfl_xor(sv, o);
+                const int oi = __shfl_xor(li, o);
+                if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; sv = os; }
+            }
             int m = k;
-            if (akk == akk) { const int r = pivot_row(a, k); m = r < NT ? r : k; }   // |a[k][k]| NaN: every `>` is false
+            double pivot = akk;
+            if (akk == akk && li < NT) { m = li; pivot = sv; }   // |a[k][k]| NaN: every `>` of the reference's scan is false
             if (gl() == 0) piv[k] = (uint32_t)m;
-            const double pivot = a[(size_t)k * NT + m];
             if (pivot == 0.0) return false;
             __syncthreads();   // everyone has read column k before the swap
             if (gl() == 0 && m != k) { a[(size_t)k * NT + m] = akk; a[(size_t)k * NT + k] = pivot; }
@@ -113,7 +140,7 @@ struct BdfG {
             for (int c = 0; c < C; ++c) {
                 const int i = gi(c);
                 mult[c] = 0.0;
-                if (i > k && i < NT) { mult[c] = -a[(size_t)k * NT + i] * t; a[(size_t)k * NT + i] = mult[c]; }
+                if (i > k && i < NT) { mult[c] = -((i == m) ? akk : colk[c]) * t; a[(size_t)k * NT + i] = mult[c]; }   // row m holds row k's entry after the swap
             }
             // Trailing update.  A column j > k changes only if its pivot-row entry t_j = a[m][j] is non-zero (the reference
             // guards the update with `t != 0`, lu.rs:88-104) or if the row exchange moves two different values; for a
@@ -169,11 +196,24 @@ struct BdfG {
                     }
                 }
             };
+            // the pivot-row entries of ALL trailing columns first (one round trip for up to 8 strided loads), then segment
+            // by segment; processing a segment only writes that segment's columns
+            constexpr int SEG = (NT + G - 1) / G;
+            double tjs[SEG], aks[SEG];
+#pragma unroll
+            for (int sg = 0; sg < SEG; ++sg) {
+                const int jj = k + 1 + sg * G + gl();
+                tjs[sg] = 0.0; aks[sg] = 0.0;
+                if (jj < NT) { tjs[sg] = a[(size_t)jj * NT + m]; aks[sg] = a[(size_t)jj * NT + k]; }
+            }
 #pragma unroll 1
-            for (int j0 = k + 1; j0 < NT; j0 += G) {
+            for (int sg = 0; sg < SEG; ++sg) {
+                const int j0 = k + 1 + sg * G;
+                if (j0 >= NT) break;
                 const int jj = j0 + gl();
-                double tjv = 0.0, akv = 0.0;
-                if (jj < NT) { tjv = a[(size_t)jj * NT + m]; akv = a[(size_t)jj * NT + k]; }
+                double tjv = tjs[0], akv = aks[0];   // select chain instead of a run-time register index
+#pragma unroll
+                for (int q = 1; q < SEG; ++q) { tjv = sg == q ? tjs[q] : tjv; akv = sg == q ? aks[q] : akv; }
                 const bool need = jj < NT && (tjv != 0.0 || (m != k && d2u(tjv) != d2u(akv)));
                 unsigned long long todo = __ballot(need);
                 if (G < IVP_WAVE) todo = (todo >> wl0()) & ((1ull << (G & 63)) - 1ull);   // this group's columns
