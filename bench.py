@@ -82,7 +82,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=100_000, help="trajectories in the whole batch (BASELINE C2 / C4: 100000)")
-    ap.add_argument("--fp", choices=["strict", "fast"], default="strict")
+    ap.add_argument("--fp", choices=["strict", "fma", "fast"], default="strict",
+                    help="arithmetic mode of the kernels: strict (headline: the reference's IEEE operation sequence) or fma "
+                         "(the defined FMA mode, bit-comparable with oracle/liboracle_fma.so; 'fast' is its older name)")
     ap.add_argument("--chunk", type=int, default=0, help="step attempts per launch (0 = library default)")
     ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
                     help="c2 = BASELINE headline (default; with --gpus N > 1 it is C4: the same batch sharded); "
@@ -117,7 +119,9 @@ def main():
     from ivp_amd import workloads as W
     from ivp_amd.distributed import ResultArena, run_steps, shard_bounds
 
-    fp = ivp_amd.FpMode.FAST if args.fp == "fast" else ivp_amd.FpMode.STRICT
+    if args.fp == "fast":
+        args.fp = "fma"
+    fp = ivp_amd.FpMode.FMA if args.fp == "fma" else ivp_amd.FpMode.STRICT
     wl = WORKLOADS[args.workload]
     B = args.batch if args.workload == "c2" or args.batch != 100_000 else wl["B"]
     prob = getattr(ivp_amd, wl["problem"])()
@@ -313,7 +317,7 @@ def main():
         single = dist is None
         y0d, pd = torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev)
         if args.fp == "strict" and not args.no_fast and single and args.workload == "c2":   # single process only (it synchronises)
-            res["fast_fp_mode"] = fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, barrier_sync)
+            res["fma_fp_mode"] = fma_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, barrier_sync)
         if not args.no_fast and single and args.workload == "c2":
             res["pipelined"] = pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp, args)
         if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
@@ -328,10 +332,11 @@ def main():
         dist.destroy_process_group()
 
 
-def fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all):
-    """Secondary, informational: the same workload with the FAST floating-point kernels (FMA contraction, shared
-    reciprocals); results differ from the strict ones at the 1e-16-per-operation level (tests state the tolerance)."""
-    opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=ivp_amd.FpMode.FAST, chunk_attempts=args.chunk)
+def fma_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all):
+    """Secondary, informational: the same workload in the FMA arithmetic mode (explicit fused multiply-adds at the marked
+    sites, one reciprocal per primary in the right-hand side; bit-comparable with oracle/liboracle_fma.so, identical in
+    every kernel variant -- tests/test_fma_mode.py); differs from strict at the 1e-16-per-operation level."""
+    opts = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, fp_mode=ivp_amd.FpMode.FMA, chunk_attempts=args.chunk)
     out = None
     for _ in range(max(2, args.warmup)):
         out = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, ctx, out)
@@ -343,7 +348,8 @@ def fast_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all):
     sync_all()
     dt = time.perf_counter() - t
     acc = float(out.naccpt.sum().item())
-    return {"value": acc * k / dt, "unit": "steps/s", "ms_per_step": dt / k * 1e3, "steps": k, "this_rank_only": True}
+    return {"value": acc * k / dt, "unit": "steps/s", "ms_per_step": dt / k * 1e3, "steps": k, "this_rank_only": True,
+            "fp_mode": "fma", "oracle": "oracle/liboracle_fma.so (bit-exact, tests/test_fma_mode.py)"}
 
 
 def pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp_mode, args, streams=4):

@@ -114,8 +114,15 @@ typedef struct {
 typedef enum {
     IVP_FP_STRICT = 0, /* no FMA contraction, reference expression order: bit-comparable with a CPU
                           restatement of the reference (Rust never contracts a*b+c) */
-    IVP_FP_FAST = 1    /* FMA contraction and reciprocal sharing inside the RHS: ~1e-16 relative
-                          differences per operation, faster */
+    IVP_FP_FMA = 1,    /* the FMA arithmetic mode: the same operation sequence with the multiply-add sites of the stage
+                          combinations, error estimates, dense coefficients, interpolants and tolerance scales as single
+                          fused operations, and the built-in right-hand sides in their FMA form (one reciprocal per
+                          denominator).  A DEFINED arithmetic (written out in the kernel source, compiled without
+                          compiler contraction): results are identical in every kernel variant and for every batch
+                          size, and bit-comparable with the oracle's FMA build (oracle/liboracle_fma.so).  Differs from
+                          STRICT at the 1e-16-per-operation level; a hiprtc right-hand side is evaluated as written
+                          (call fma() yourself where you want it) */
+    IVP_FP_FAST = IVP_FP_FMA   /* ABI v3 name */
 } ivp_fp_mode_t;
 
 /* Mirrors `struct Options` (src/solve/options.rs:75-123) field by field for the fields the explicit

@@ -68,8 +68,11 @@ class Status(enum.IntEnum):
 
 
 class FpMode(enum.IntEnum):
+    """``ivp_fp_mode_t``: STRICT = the reference's IEEE operation sequence; FMA = the same sequence with the marked
+    multiply-add sites fused (a defined arithmetic with its own oracle build; identical bits in every kernel variant)."""
     STRICT = 0
-    FAST = 1
+    FMA = 1
+    FAST = 1   # older name of FMA
 
 
 class IvpError(Exception):

@@ -447,6 +447,14 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
     const double hmax = fabs(a.has_max_step ? a.max_step : fabs(L.xend - L.x0));
     R::ode(L.x0, y, f0, L.p);
     double jac[N][N];
+    if constexpr (HasJac<R>::v) {
+        // the reference hands f.jac() a zero-initialised persistent Matrix (bdf.rs:152): an override that fills only
+        // its non-zero entries leaves zeros elsewhere; later calls see the previous Jacobian (S.jac persists)
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c < N; ++c) jac[r][c] = 0.0;
+    }
     bdf_eval_jac<R>(L.x0, y, L.p, jac);
     double h_abs;
     if (a.has_first_step) {
@@ -476,7 +484,7 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
 #pragma unroll
         for (int c = 0; c < N; ++c) { a.bdf_jac[(size_t)(r * N + c) * B + j] = jac[r][c]; a.bdf_lu[(size_t)(r * N + c) * B + j] = 0.0; }
     L.x = L.x0;
-    if (FULL) (void)solout_full<M_BDF, R>(a, j, L, L.x0, L.x0, y, y, nullptr, 0.0, L.x0);
+    if (FULL) (void)solout_full<M_BDF, R>(a, j, L, L.x0, L.x0, y, (const double *)y, (const double *)nullptr, 0.0, L.x0);
     store_so();
     a.nfev[j] = 1; a.njev[j] = 1;
     a.x[j] = L.x0; a.h[j] = h_abs;

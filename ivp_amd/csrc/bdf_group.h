@@ -416,7 +416,7 @@ __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32
         for (int k = 2; k < 8; ++k) a.bdf_d[((size_t)k * NT + g) * B + j] = 0.0;
     }
     L.x = L.x0;
-    if (FULL) (void)solout_full<M_BDF, GR>(a, j, L, L.x0, L.x0, y, y, nullptr, 0.0, L.x0);
+    if (FULL) (void)solout_full<M_BDF, GR>(a, j, L, L.x0, L.x0, y, (const double *)y, (const double *)nullptr, 0.0, L.x0);
     store_so();
     a.nfev[j] = 1; a.njev[j] = 1;
     a.x[j] = L.x0; a.h[j] = h_abs;

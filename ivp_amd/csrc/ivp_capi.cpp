@@ -269,22 +269,19 @@ int enqueue_round(ivp_ctx *ctx)
     const bool profile = P.profile != 0;
     const bool fits_one_wave = (size_t)lanes * (P.group ? (P.jit ? (uint32_t)ivp_group_width(P.n) : (uint32_t)IVP_WAVE) : 1u) <= kOneWavePerSimd;
     // problems whose stragglers may be handed to the lane-cooperative kernels by a speculative launch (see below)
-    const bool spec_ok = P.coop_ok && P.variant == 0 && P.adaptive && P.n >= 4 && P.fp_mode == IVP_FP_STRICT && !P.jit;
+    const bool spec_ok = P.coop_ok && P.variant == 0 && P.adaptive && P.n >= 4 && !P.jit;
     // kernel variant: 1 = lean registers (coefficients re-materialised per use), 2 = coefficients resident in
-    // registers, 3 = lane-cooperative.  Strict results are bit-identical in all of them, so in strict mode the choice
-    // follows the shrinking active set: resident once at most two waves per SIMD are left to run, cooperative for the
-    // tail.  Fast-mode FMA fusion differs between the variants, so there the choice must not depend on anything but the
-    // problem itself -- not on the batch size, not on what else is in the batch: resident for n >= 4, lean below
-    // (where the register footprint is small and occupancy is what pays), cooperative only on request (variant 3).
-    const bool fast = P.fp_mode == IVP_FP_FAST;
+    // registers, 3 = lane-cooperative.  Results are bit-identical in all of them, in BOTH arithmetic modes (strict: the
+    // reference's operation sequence; FMA: the same sequence with the IVP_MA sites fused, written out in the source and
+    // compiled without contraction), so the choice follows the shrinking active set: resident once at most two waves
+    // per SIMD are left to run, cooperative for the tail.
     const bool use_hoist = !P.has_settings &&   // run-time controller fields exist in the lean builds only
-                           (P.variant == 2 ||
-                            (P.variant == 0 && (fast ? P.n >= 4 : (size_t)lanes <= 2 * (size_t)kOneWavePerSimd)));
+                           (P.variant == 2 || (P.variant == 0 && (size_t)lanes <= 2 * (size_t)kOneWavePerSimd));
     // eight lanes per trajectory pay off once the cooperative waves fit two per SIMD, and only for systems
     // with enough components to share out (measured: break-even at n = 3, a loss at n = 2)
     const size_t coop_cap = kCoopCapLanes;
     const bool use_coop = P.coop_ok && (P.variant == 3 ||
-                                        (P.variant == 0 && P.adaptive && P.n >= 4 && !fast && (size_t)lanes * 8u <= coop_cap));
+                                        (P.variant == 0 && P.adaptive && P.n >= 4 && (size_t)lanes * 8u <= coop_cap));
     // Long chunks (one launch per poll) once compaction cannot help any more: in the cooperative kernels, and for
     // problems without a cooperative kernel when the active set fits one wave per SIMD.  A set that will still be
     // handed to the cooperative kernels keeps short chunks + the speculative hand-over whatever its size: an attempt
@@ -721,8 +718,8 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.jit = prob->rhs_id == IVP_RHS_JIT;
     P.has_settings = opt->has_settings != 0;
     // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for problems with
-    // n <= 8.  Strict results are bit-identical to the thread-per-trajectory kernels, so in strict mode
-    // the loop switches to them for the latency-bound tail; fast mode only on request (variant 3).
+    // n <= 8.  Results are bit-identical to the thread-per-trajectory kernels in both arithmetic modes, so the loop
+    // switches to them for the latency-bound tail.
     P.coop_ok = !group && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
     P.variant = (opt->variant == 3 && !P.coop_ok) ? 0 : opt->variant;
     P.chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : tune().bulk_chunk;

@@ -172,7 +172,7 @@ int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitM
     }
     const std::string arch = "--offload-arch=" + r.arch;
     std::vector<const char *> opts = {arch.c_str(), "-O3", "-std=c++17"};
-    opts.push_back(fp_mode == IVP_FP_FAST ? "-ffp-contract=fast" : "-ffp-contract=off");
+    opts.push_back("-ffp-contract=off");   // both arithmetic modes: the FMA mode's fused operations are written out (IVP_MA)
     opts.push_back(fp_mode == IVP_FP_FAST ? "-DIVP_FAST=1" : "-DIVP_FAST=0");
     const hiprtcResult cr = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;

@@ -139,6 +139,19 @@ __device__ __forceinline__ double RhsCr3bp::ode_coop(double, double ys, const do
     const double X = quad_bcast<0>(pos), Y = quad_bcast<1>(pos), Z = quad_bcast<2>(pos);
     const double sw = dpp_f64<0xE1, 0xF>(0.0, ys);   // quad_perm:[1,0,2,3]: vy for the vx' lane, vx for the vy' lane
     const double w = (X + (hi ? -1.0 : -0.0)) + mu; // lower quad: a = x + mu; upper quad: b = x - 1.0 + mu
+#if IVP_FAST
+    // FMA form (RhsCr3bp::ode under IVP_FAST, expression for expression): g = coefficient / r^3 per primary, the upper quad
+    // fetches the first primary's g from the lane four below and fuses both attractions into its linear part
+    const double d = fma(Z, Z, fma(Y, Y, w * w));
+    const double r = sqrt(d);
+    const double g = (hi ? mu : 1.0 - mu) / (d * r);
+    const double g1 = lo_to_hi(g, g);
+    const double q2 = i == 0u ? w : pos;
+    const double q1 = i == 0u ? X + mu : pos;
+    double lin = fma(i == 0u ? 2.0 : -2.0, sw, pos);
+    lin = i == 2u ? -0.0 : lin;
+    const double acc = fma(-g, q2, fma(-g1, q1, lin));
+#else
     const double r = sqrt(w * w + Y * Y + Z * Z);
     const double r3 = r * r * r;
     const double q = i == 0u ? w : pos;
@@ -147,6 +160,7 @@ __device__ __forceinline__ double RhsCr3bp::ode_coop(double, double ys, const do
     double lin = pos + (i == 0u ? 2.0 : -2.0) * sw;
     lin = i == 2u ? -0.0 : lin;
     const double acc = (lin - T1) - T;
+#endif
     return hi_to_lo(acc, ys);                   // position lanes: d(pos)/dt = the velocity four lanes above
 }
 

@@ -12,8 +12,13 @@
 // Floating-point contract: in the STRICT build (-ffp-contract=off) every expression keeps the
 // reference's left-to-right association (SURVEY.md section 7 "FP / semantics notes"), so the result is
 // the same IEEE-754 operation sequence as the Rust crate evaluates; only the step-controller
-// power function differs (ivp_pow below instead of libm pow).  The FAST build lets the compiler
-// contract a*b+c and uses reciprocal sharing inside the right-hand sides.
+// power function differs (ivp_pow below instead of libm pow).  The FMA build (IVP_FAST = 1, ivp_options_t.fp_mode =
+// IVP_FP_FMA) is a DEFINED arithmetic as well, not "whatever the compiler contracts": it is compiled with
+// -ffp-contract=off too, and every fused multiply-add is spelled out through IVP_MA / IVP_MS / ivp_lc below (the
+// multiply-add sites of the stage combinations, error estimates, dense coefficients, interpolants, tolerance scales
+// and of the built-in right-hand sides, whose FMA forms also share one reciprocal per primary / denominator).  The
+// same sites are fused in oracle/ivp_oracle.c's ORC_FMA build, so FMA-mode results are bit-comparable with
+// liboracle_fma.so and identical in every kernel variant (lean, resident, lane-cooperative, wave-per-trajectory).
 //
 // Reference citations are file:line in Ryan-D-Gast/ivp 0.5.1.
 #pragma once
@@ -78,7 +83,25 @@
 #define IVP_OPAQUE_V(v) ((void)0)
 #endif
 
+// The multiply-add sites.  STRICT: two IEEE operations in the reference's association; FMA: one fused operation.
+//   IVP_MA(acc, a, b) = acc + a * b        IVP_MS(acc, a, b) = acc - a * b        IVP_MB(a, b, c) = a * b - c
+//   IVP_LC(c1, k1, c2, k2, ...) = ((c1 * k1 + c2 * k2) + c3 * k3) + ...   (the reference's left-to-right sums)
+#if IVP_FAST
+#define IVP_MA(acc, a, b) fma((a), (b), (acc))
+#define IVP_MS(acc, a, b) fma(-(a), (b), (acc))
+#define IVP_MB(a, b, c) fma((a), (b), -(c))
+#else
+#define IVP_MA(acc, a, b) ((acc) + (a) * (b))
+#define IVP_MS(acc, a, b) ((acc) - (a) * (b))
+#define IVP_MB(a, b, c) ((a) * (b) - (c))
+#endif
+#define IVP_LC(c1, k1, ...) IVP_NS::ivp_lc((c1) * (k1), __VA_ARGS__)
+
 namespace IVP_NS {
+
+IVP_HD double ivp_lc(double acc) { return acc; }
+template <class... Ts>
+IVP_HD double ivp_lc(double acc, double c, double k, Ts... rest) { return ivp_lc(IVP_MA(acc, c, k), rest...); }
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -318,7 +341,7 @@ struct RhsVdp {      // benches/benchmark.py:22-27
     static IVP_HD void ode(double, const double *y, double *d, const double *p)
     {
         d[0] = y[1];
-        d[1] = p[0] * (1.0 - y[0] * y[0]) * y[1] - y[0];
+        d[1] = IVP_MB(p[0] * IVP_MS(1.0, y[0], y[0]), y[1], y[0]);   // p0 * (1 - y0 * y0) * y1 - y0
     }
 };
 struct RhsCr3bp {    // examples/cr3bp.rs:23-36
@@ -330,16 +353,16 @@ struct RhsCr3bp {    // examples/cr3bp.rs:23-36
         const double a = x + mu;
         const double b = x - 1.0 + mu;
 #if IVP_FAST
-        // reciprocal sharing: one division per primary instead of three
-        const double d1 = a * a + y * y + z * z;
-        const double d2 = b * b + y * y + z * z;
+        // FMA form (oracle: rhs_cr3bp under ORC_FMA): one division per primary instead of three, every a * b + c fused
+        const double d1 = fma(z, z, fma(y, y, a * a));
+        const double d2 = fma(z, z, fma(y, y, b * b));
         const double r1 = sqrt(d1), r2 = sqrt(d2);
         const double g1 = (1.0 - mu) / (d1 * r1);
         const double g2 = mu / (d2 * r2);
         d[0] = vx; d[1] = vy; d[2] = vz;
-        d[3] = x + 2.0 * vy - g1 * a - g2 * b;
-        d[4] = y - 2.0 * vx - g1 * y - g2 * y;
-        d[5] = -g1 * z - g2 * z;
+        d[3] = fma(-g2, b, fma(-g1, a, fma(2.0, vy, x)));
+        d[4] = fma(-g2, y, fma(-g1, y, fma(-2.0, vx, y)));
+        d[5] = fma(-g2, z, fma(-g1, z, -0.0));
 #else
         const double r1 = sqrt(a * a + y * y + z * z);
         const double r2 = sqrt(b * b + y * y + z * z);
@@ -370,8 +393,8 @@ struct RhsLorenz {   // benches/benchmark.py:30-37
     static IVP_HD void ode(double, const double *s, double *d, const double *p)
     {
         d[0] = p[0] * (s[1] - s[0]);
-        d[1] = s[0] * (p[1] - s[2]) - s[1];
-        d[2] = s[0] * s[1] - p[2] * s[2];
+        d[1] = IVP_MB(s[0], p[1] - s[2], s[1]);     // s0 * (p1 - s2) - s1
+        d[2] = IVP_MS(s[0] * s[1], p[2], s[2]);     // s0 * s1 - p2 * s2
     }
 };
 struct RhsZero {     // tests/ivp.rs:11-19
@@ -383,7 +406,7 @@ struct RhsRational { // tests/test_helpers.py:23-25
     static IVP_HD void ode(double t, const double *y, double *d, const double *)
     {
         d[0] = y[1] / t;
-        d[1] = y[1] * (y[0] + 2.0 * y[1] - 1.0) / (t * (y[0] - 1.0));
+        d[1] = y[1] * (IVP_MA(y[0], 2.0, y[1]) - 1.0) / (t * (y[0] - 1.0));
     }
 };
 struct RhsExp2 {     // tests/ivp.rs:291-298
@@ -395,7 +418,7 @@ struct RhsLinear {   // tests/test_helpers.py:11-12
     enum { N = 2, P = 0, NE = 0 };
     static IVP_HD void ode(double, const double *y, double *d, const double *)
     {
-        d[0] = -y[0] - 5.0 * y[1];
+        d[0] = IVP_MS(-y[0], 5.0, y[1]);
         d[1] = y[0] + y[1];
     }
 };
@@ -404,8 +427,8 @@ struct RhsRobertson {   // tests/test_ivp.py:327-333
     static IVP_HD void ode(double, const double *s, double *d, const double *)
     {
         const double x = s[0], y = s[1], z = s[2];
-        d[0] = -0.04 * x + 1e4 * y * z;
-        d[1] = 0.04 * x - 1e4 * y * z - 3e7 * y * y;
+        d[0] = IVP_MA(-0.04 * x, 1e4 * y, z);                       // -0.04 x + 1e4 y z
+        d[1] = IVP_MS(IVP_MS(0.04 * x, 1e4 * y, z), 3e7 * y, y);    // 0.04 x - 1e4 y z - 3e7 y y
         d[2] = 3e7 * y * y;
     }
 };
@@ -415,7 +438,7 @@ struct RhsRobertsonJac : RhsRobertson {
     {
         const double y = s[1], z = s[2];
         j[0][0] = -0.04;  j[0][1] = 1e4 * z;              j[0][2] = 1e4 * y;
-        j[1][0] = 0.04;   j[1][1] = -1e4 * z - 6e7 * y;   j[1][2] = -1e4 * y;
+        j[1][0] = 0.04;   j[1][1] = IVP_MS(-1e4 * z, 6e7, y);   j[1][2] = -1e4 * y;
         j[2][0] = 0.0;    j[2][1] = 6e7 * y;              j[2][2] = 0.0;
     }
 };
@@ -424,7 +447,7 @@ struct RhsVdpEps {   // examples/van_der_pol.rs:9-14
     static IVP_HD void ode(double, const double *y, double *d, const double *p)
     {
         d[0] = y[1];
-        d[1] = ((1.0 - y[0] * y[0]) * y[1] - y[0]) / p[0];
+        d[1] = IVP_MB(IVP_MS(1.0, y[0], y[0]), y[1], y[0]) / p[0];   // ((1 - y0 y0) y1 - y0) / eps
     }
 };
 
@@ -440,7 +463,7 @@ struct RhsBall {     // examples/bouncing_ball.rs:5-31  p = {gravity, drag}
     {
         const double vy = s[1];
         d[0] = vy;
-        d[1] = -p[0] - p[1] * vy * fabs(vy);
+        d[1] = IVP_MS(-p[0], p[1] * vy, fabs(vy));   // -g - drag vy |vy|
     }
     static IVP_HD void events(double, const double *y, double *g, const double *) { g[0] = y[0]; }
 };
@@ -454,7 +477,7 @@ struct RhsRationalEv {   // tests/test_ivp.py:345-353
     static IVP_HD void ode(double t, const double *y, double *d, const double *)
     {
         d[0] = y[1] / t;
-        d[1] = y[1] * (y[0] + 2.0 * y[1] - 1.0) / (t * (y[0] - 1.0));
+        d[1] = y[1] * (IVP_MA(y[0], 2.0, y[1]) - 1.0) / (t * (y[0] - 1.0));
     }
     static IVP_HD void events(double t, const double *y, double *g, const double *)
     {
@@ -597,14 +620,54 @@ IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Where a step's dense-output coefficients live while the device DefaultSolOut consumes them.
+// DOPRI5 / RK23 / RK4 / BDF: a VGPR array.  DOP853: 8 blocks x N components on top of 10 stage vectors do not fit the
+// register file (8 x 6 x 2 = 96 VGPRs for CR3BP: 256 VGPRs, occupancy 1 and 400 B of scratch per lane), so the block is
+// STAGED THROUGH LDS: NC doubles per lane, laid out [coefficient][lane] (a wave's access to one coefficient is one
+// conflict-free 512-byte row; every lane reads only what it wrote, so there is no barrier), 4 KB x N per wave.
+// The consumers (interpolate, so_sample, so_events, so_collect_dense) are templates over the container: anything with
+// operator[] -- a plain pointer / array, or ContStage.  On the host (tests/host_emul) ContStage is a plain array.
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+struct ContStage {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double *b;
+    __device__ __forceinline__ ContStage()
+    {
+        __shared__ double ivp_cont_lds[NC * IVP_WAVE];
+        b = ivp_cont_lds + threadIdx.x;
+    }
+    __device__ __forceinline__ double operator[](int c) const { return b[c * IVP_WAVE]; }
+    __device__ __forceinline__ void set(int c, double v) const { b[c * IVP_WAVE] = v; }
+#else
+    mutable double s[NC];
+    double operator[](int c) const { return s[c]; }
+    void set(int c, double v) const { s[c] = v; }
+#endif
+};
+template <int NC>
+struct ContRegs {   // the same interface on a register array
+    mutable double s[NC];
+    IVP_HD double operator[](int c) const { return s[c]; }
+    IVP_HD void set(int c, double v) const { s[c] = v; }
+};
+template <bool B, class T, class F> struct ivp_cond { using type = T; };
+template <class T, class F> struct ivp_cond<false, T, F> { using type = F; };
+IVP_HD bool ivp_isnull(const double *p) { return p == nullptr; }
+template <int NC>
+IVP_HD bool ivp_isnull(const ContStage<NC> &) { return false; }
+template <int NC>
+IVP_HD bool ivp_isnull(const ContRegs<NC> &) { return false; }
+
+// ------------------------------------------------------------------------------------------------
 // Dense-output polynomials (dopri5.rs:467-478, dop853.rs:659-670, rk23.rs:313-321)
 // ------------------------------------------------------------------------------------------------
 enum { M_RK23 = 0, M_DOPRI5 = 1, M_DOP853 = 2, M_RK4 = 3, M_RADAU = 4, M_BDF = 5 };   // Method order, options.rs:14-27
 template <int M> struct NCoef { enum { v = (M == M_DOPRI5) ? 5 : (M == M_DOP853) ? 8 : (M == M_BDF) ? 7 : 4 }; };
 
 // BDF dense output (bdf.rs:618-656); cont is per-state blocks [D0, D1..D5, order]
-template <int N>
-IVP_HD void bdf_interpolate(double xi, double *yi, const double *cont, double xold, double h)
+template <int N, class CP>
+IVP_HD void bdf_interpolate(double xi, double *yi, const CP &cont, double xold, double h)
 {
     if (h == 0.0) return;
     double ordf = rint(cont[6]);   // order is an exact small integer: round() == rint()
@@ -631,8 +694,8 @@ IVP_HD void bdf_interpolate(double xi, double *yi, const double *cont, double xo
     }
 }
 
-template <int M, int N>
-IVP_HD void interpolate(double xi, double *yi, const double *cont, double xold, double h)
+template <int M, int N, class CP>
+IVP_HD void interpolate(double xi, double *yi, const CP &cont, double xold, double h)
 {
     if constexpr (M == M_BDF) {
         bdf_interpolate<N>(xi, yi, cont, xold, h);
@@ -641,14 +704,14 @@ IVP_HD void interpolate(double xi, double *yi, const double *cont, double xold, 
         const double theta1 = 1.0 - theta;
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            yi[i] = cont[i] + theta * (cont[N + i] + theta1 * (cont[2 * N + i] + theta * (cont[3 * N + i] + theta1 * cont[4 * N + i])));
+            yi[i] = IVP_MA(cont[i], theta, IVP_MA(cont[N + i], theta1, IVP_MA(cont[2 * N + i], theta, IVP_MA(cont[3 * N + i], theta1, cont[4 * N + i]))));
     } else if constexpr (M == M_DOP853) {
         const double s = (xi - xold) / h;
         const double s1 = 1.0 - s;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double conpar = cont[4 * N + i] + s * (cont[5 * N + i] + s1 * (cont[6 * N + i] + s * cont[7 * N + i]));
-            yi[i] = cont[i] + s * (cont[N + i] + s1 * (cont[2 * N + i] + s * (cont[3 * N + i] + s1 * conpar)));
+            const double conpar = IVP_MA(cont[4 * N + i], s, IVP_MA(cont[5 * N + i], s1, IVP_MA(cont[6 * N + i], s, cont[7 * N + i])));
+            yi[i] = IVP_MA(cont[i], s, IVP_MA(cont[N + i], s1, IVP_MA(cont[2 * N + i], s, IVP_MA(cont[3 * N + i], s1, conpar))));
         }
     } else if constexpr (M == M_RK4) {   // rk4.rs:229-244
         const double t = (xi - xold) / h;
@@ -660,14 +723,14 @@ IVP_HD void interpolate(double xi, double *yi, const double *cont, double xold, 
         const double h11 = t3 - t2;
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            yi[i] = h00 * cont[i] + h10 * h * cont[N + i] + h01 * cont[3 * N + i] + h11 * h * cont[2 * N + i];
+            yi[i] = IVP_LC(h00, cont[i], h10 * h, cont[N + i], h01, cont[3 * N + i], h11 * h, cont[2 * N + i]);
     } else {
         const double xc = (xi - xold) / h;
         const double x2 = xc * xc;
         const double x3 = x2 * xc;
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            yi[i] = cont[i] + h * (cont[N + i] * xc + cont[2 * N + i] * x2 + cont[3 * N + i] * x3);
+            yi[i] = IVP_MA(cont[i], h, IVP_LC(cont[N + i], xc, cont[2 * N + i], x2, cont[3 * N + i], x3));
     }
 }
 
@@ -709,15 +772,15 @@ IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, 
     L.t_last = t;
 }
 
-template <int M, int N, int P, class MAP = IdMap<N>>
+template <int M, int N, int P, class MAP = IdMap<N>, class CP>
 IVP_HD void so_collect_dense(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
-                             const double *cont, double h, double ixold)
+                             const CP &cont, double h, double ixold)
 {
     constexpr int NC = NCoef<M>::v * N;
     constexpr int NCT = NCoef<M>::v * MAP::NT;   // coefficient blocks are [coef][component] (cont.rs:16-28)
     const size_t B = a.B;
     // dense collection, solout.rs:141-146
-    if (a.collect_dense && x != xold && cont != nullptr && h != 0.0) {
+    if (a.collect_dense && x != xold && !ivp_isnull(cont) && h != 0.0) {
         if (L.n_seg < a.max_log) {
             const size_t k = L.n_seg;
             if (M == M_BDF) {   // per-state blocks [D0, D1..D5, order] (cont.rs:44-51): local (state i, slot s) -> global state
@@ -739,9 +802,9 @@ IVP_HD void so_collect_dense(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, doubl
 // t_eval sampling / accepted-step recording (solout.rs:344-428). `xold` is the callback's first argument,
 // `ixold`/`h` the interpolant's own anchor (StepInterpolant.xold/.h): identical for the RK methods, different for
 // BDF (bdf.rs:518-519).
-template <int M, int N, int P, class MAP = IdMap<N>>
+template <int M, int N, int P, class MAP = IdMap<N>, class CP>
 IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold, double x,
-                      const double *y, const double *cont, double h, double ixold)
+                      const double *y, const CP &cont, double h, double ixold)
 {
     const double tol = 1e-12;
     (void)tol;
@@ -771,7 +834,7 @@ IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold,
                 const double direction = rs_signum(x - xold);
                 const double target = L.x0 + direction * a.first_step;
                 if (direction * (x - target) >= -tol) {
-                    if (cont != nullptr) {
+                    if (!ivp_isnull(cont)) {
                         interpolate<M, N>(target, yi, cont, ixold, h);
                         so_push_log<M, N, P, MAP>(a, j, L, target, yi);
                         L.flags |= IVP_F_FIRSTOUT;
@@ -789,16 +852,16 @@ IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold,
 // Event detection (solout.rs:158-331): zero crossings of R::events between the previous and the current accepted
 // point, refined with Brent's method on the step interpolant (xtol 2e-12, rtol eps, <= 100 iterations), processed
 // in chronological order; a terminal event appends its point to the output and interrupts the integration.
-template <int M, class R>
+template <int M, class R, class YP, class CP>
 IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
-                      const double *y, const double *yold, const double *cont, double h, double ixold)
+                      const double *y, const YP &yold, const CP &cont, double h, double ixold)
 {
     constexpr int N = R::N, P = R::P, NE = R::NE > 0 ? R::NE : 1;
     using MAP = typename OutMap<R>::type;
     const size_t B = a.B;
     double g_curr[NE];
     R::events(x, y, g_curr, L.p);
-    if (cont == nullptr) {   // initial callback: DefaultSolOut.yold is still empty (solout.rs:163-164)
+    if (ivp_isnull(cont)) {   // initial callback: DefaultSolOut.yold is still empty (solout.rs:163-164)
 #pragma unroll
         for (int i = 0; i < NE; ++i) a.prev_event[(size_t)i * B + j] = g_curr[i];
         return false;
@@ -920,9 +983,9 @@ IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double
 }
 
 // DefaultSolOut::solout on the device. Returns true for ControlFlag::Interrupt (terminal event).
-template <int M, class R>
+template <int M, class R, class YP, class CP>
 IVP_HD bool solout_full(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
-                        const double *y, const double *yold, const double *cont, double h, double ixold)
+                        const double *y, const YP &yold, const CP &cont, double h, double ixold)
 {
     using MAP = typename OutMap<R>::type;
     so_collect_dense<M, R::N, R::P, MAP>(a, j, L, xold, x, cont, h, ixold);
@@ -958,7 +1021,7 @@ IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg,
     double t_dnf[N], t_dny[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fabs(y[i]);
+        const double sk = IVP_MA(NormOps<R>::atol(a, i), NormOps<R>::rtol(a, i), fabs(y[i]));
         t_dnf[i] = (f0[i] / sk) * (f0[i] / sk);
         t_dny[i] = (y[i] / sk) * (y[i] / sk);
     }
@@ -970,12 +1033,12 @@ IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg,
     h = fabs(h) * rs_signum(posneg);
     double y1[N], f1[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * f0[i];
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, f0[i]);
     R::ode(x + h, y1, f1, p);
     double t_der2[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fabs(y[i]);
+        const double sk = IVP_MA(NormOps<R>::atol(a, i), NormOps<R>::rtol(a, i), fabs(y[i]));
         const double df = (f1[i] - f0[i]) / sk;
         t_der2[i] = df * df;
     }
@@ -1081,7 +1144,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         nfev += 2;  // f(x0, y0) and hinit's Euler probe
         L.h = hinit<R>(a, L.x, L.y, L.posneg, L.k1, L.p, M == M_DOPRI5 ? 5 : (M == M_DOP853 ? 8 : 3), L.hmax);
     }
-    if (FULL) (void)solout_full<M, R>(a, j, L, L.x, L.x, L.y, L.y, nullptr, 0.0, L.x);
+    if (FULL) (void)solout_full<M, R>(a, j, L, L.x, L.x, L.y, (const double *)L.y, (const double *)nullptr, 0.0, L.x);
 
 #pragma unroll
     for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, L.k1[c]); }
@@ -1170,33 +1233,33 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     double k2[N], k3[N], k4[N], k5[N], k6[N], y1[N];
 { const double cA21 = KC(A21);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * cA21 * k1[i];
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h * cA21, k1[i]);
 }
     R::ode(x + KC(C2) * h, y1, k2, p);
 { const double cA31 = KC(A31), cA32 = KC(A32);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA31 * k1[i] + cA32 * k2[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA31, k1[i], cA32, k2[i]));
 }
     R::ode(x + KC(C3) * h, y1, k3, p);
 { const double cA41 = KC(A41), cA42 = KC(A42), cA43 = KC(A43);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA41 * k1[i] + cA42 * k2[i] + cA43 * k3[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA41, k1[i], cA42, k2[i], cA43, k3[i]));
 }
     R::ode(x + KC(C4) * h, y1, k4, p);
 { const double cA51 = KC(A51), cA52 = KC(A52), cA53 = KC(A53), cA54 = KC(A54);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA51 * k1[i] + cA52 * k2[i] + cA53 * k3[i] + cA54 * k4[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA51, k1[i], cA52, k2[i], cA53, k3[i], cA54, k4[i]));
 }
     R::ode(x + KC(C5) * h, y1, k5, p);
 { const double cA61 = KC(A61), cA62 = KC(A62), cA63 = KC(A63), cA64 = KC(A64), cA65 = KC(A65);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA61 * k1[i] + cA62 * k2[i] + cA63 * k3[i] + cA64 * k4[i] + cA65 * k5[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA61, k1[i], cA62, k2[i], cA63, k3[i], cA64, k4[i], cA65, k5[i]));
 }
     const double xph = x + h;
     R::ode(xph, y1, k6, p);
 { const double cA71 = KC(A71), cA73 = KC(A73), cA74 = KC(A74), cA75 = KC(A75), cA76 = KC(A76);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA71 * k1[i] + cA73 * k3[i] + cA74 * k4[i] + cA75 * k5[i] + cA76 * k6[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA71, k1[i], cA73, k3[i], cA74, k4[i], cA75, k5[i], cA76, k6[i]));
 }
     R::ode(xph, y1, k2, p);  // k7 -> k2 (FSAL)
     L.d_nfev += 6;
@@ -1206,18 +1269,18 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 { const double cD1 = KC(D1), cD3 = KC(D3), cD4 = KC(D4), cD5 = KC(D5), cD6 = KC(D6), cD7 = KC(D7);
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            cont[4 * N + i] = h * (cD1 * k1[i] + cD3 * k3[i] + cD4 * k4[i] + cD5 * k5[i] + cD6 * k6[i] + cD7 * k2[i]);
+            cont[4 * N + i] = h * IVP_LC(cD1, k1[i], cD3, k3[i], cD4, k4[i], cD5, k5[i], cD6, k6[i], cD7, k2[i]);
 }
     }
 { const double cE1 = KC(E1), cE3 = KC(E3), cE4 = KC(E4), cE5 = KC(E5), cE6 = KC(E6), cE7 = KC(E7);
 #pragma unroll
     for (int i = 0; i < N; ++i)
-        k4[i] = (cE1 * k1[i] + cE3 * k3[i] + cE4 * k4[i] + cE5 * k5[i] + cE6 * k6[i] + cE7 * k2[i]) * h;
+        k4[i] = IVP_LC(cE1, k1[i], cE3, k3[i], cE4, k4[i], cE5, k5[i], cE6, k6[i], cE7, k2[i]) * h;
 }
     double t_err[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fmax(fabs(y[i]), fabs(y1[i]));
+        const double sk = IVP_MA(NormOps<R>::atol(a, i), NormOps<R>::rtol(a, i), fmax(fabs(y[i]), fabs(y1[i])));
         t_err[i] = (k4[i] / sk) * (k4[i] / sk);
     }
     double err = NormOps<R>::sum(t_err);
@@ -1240,7 +1303,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const double d1 = k2[i] - k6[i];
-                const double ysti = y[i] + h * (cA61 * k1[i] + cA62 * k2[i] + cA63 * k3[i] + cA64 * k4[i] + cA65 * k5[i]);
+                const double ysti = IVP_MA(y[i], h, IVP_LC(cA61, k1[i], cA62, k2[i], cA63, k3[i], cA64, k4[i], cA65, k5[i]));
                 const double d2 = y1[i] - ysti;
                 t_num[i] = d1 * d1;
                 t_den[i] = d2 * d2;
@@ -1254,11 +1317,11 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const double ydiff = y1[i] - y[i];
-                const double bspl = h * k1[i] - ydiff;
+                const double bspl = IVP_MB(h, k1[i], ydiff);
                 cont[i] = y[i];
                 cont[N + i] = ydiff;
                 cont[2 * N + i] = bspl;
-                cont[3 * N + i] = -h * k2[i] + ydiff - bspl;
+                cont[3 * N + i] = IVP_MA(ydiff, -h, k2[i]) - bspl;   // -h k7 + ydiff - bspl
             }
         }
 #pragma unroll
@@ -1363,63 +1426,63 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     double k2[N], k3[N], k4[N], k5[N], k6[N], k7[N], k8[N], k9[N], k10[N], y1[N];
 { const double cA21 = KC(A21);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * cA21 * k1[i];
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h * cA21, k1[i]);
 }
     R::ode(x + KC(C2) * h, y1, k2, p);
 { const double cA31 = KC(A31), cA32 = KC(A32);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA31 * k1[i] + cA32 * k2[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA31, k1[i], cA32, k2[i]));
 }
     R::ode(x + KC(C3) * h, y1, k3, p);
 { const double cA41 = KC(A41), cA43 = KC(A43);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA41 * k1[i] + cA43 * k3[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA41, k1[i], cA43, k3[i]));
 }
     R::ode(x + KC(C4) * h, y1, k4, p);
 { const double cA51 = KC(A51), cA53 = KC(A53), cA54 = KC(A54);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA51 * k1[i] + cA53 * k3[i] + cA54 * k4[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA51, k1[i], cA53, k3[i], cA54, k4[i]));
 }
     R::ode(x + KC(C5) * h, y1, k5, p);
 { const double cA61 = KC(A61), cA64 = KC(A64), cA65 = KC(A65);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA61 * k1[i] + cA64 * k4[i] + cA65 * k5[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA61, k1[i], cA64, k4[i], cA65, k5[i]));
 }
     R::ode(x + KC(C6) * h, y1, k6, p);
 { const double cA71 = KC(A71), cA74 = KC(A74), cA75 = KC(A75), cA76 = KC(A76);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA71 * k1[i] + cA74 * k4[i] + cA75 * k5[i] + cA76 * k6[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA71, k1[i], cA74, k4[i], cA75, k5[i], cA76, k6[i]));
 }
     R::ode(x + KC(C7) * h, y1, k7, p);
 { const double cA81 = KC(A81), cA84 = KC(A84), cA85 = KC(A85), cA86 = KC(A86), cA87 = KC(A87);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = y[i] + h * (cA81 * k1[i] + cA84 * k4[i] + cA85 * k5[i] + cA86 * k6[i] + cA87 * k7[i]);
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA81, k1[i], cA84, k4[i], cA85, k5[i], cA86, k6[i], cA87, k7[i]));
 }
     R::ode(x + KC(C8) * h, y1, k8, p);
 { const double cA91 = KC(A91), cA94 = KC(A94), cA95 = KC(A95), cA96 = KC(A96), cA97 = KC(A97), cA98 = KC(A98);
 #pragma unroll
     for (int i = 0; i < N; ++i)
-        y1[i] = y[i] + h * (cA91 * k1[i] + cA94 * k4[i] + cA95 * k5[i] + cA96 * k6[i] + cA97 * k7[i] + cA98 * k8[i]);
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA91, k1[i], cA94, k4[i], cA95, k5[i], cA96, k6[i], cA97, k7[i], cA98, k8[i]));
 }
     R::ode(x + KC(C9) * h, y1, k9, p);
 { const double cA101 = KC(A101), cA104 = KC(A104), cA105 = KC(A105), cA106 = KC(A106), cA107 = KC(A107), cA108 = KC(A108), cA109 = KC(A109);
 #pragma unroll
     for (int i = 0; i < N; ++i)
-        y1[i] = y[i] + h * (cA101 * k1[i] + cA104 * k4[i] + cA105 * k5[i] + cA106 * k6[i] + cA107 * k7[i] + cA108 * k8[i] + cA109 * k9[i]);
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA101, k1[i], cA104, k4[i], cA105, k5[i], cA106, k6[i], cA107, k7[i], cA108, k8[i], cA109, k9[i]));
 }
     R::ode(x + KC(C10) * h, y1, k10, p);
 { const double cA111 = KC(A111), cA114 = KC(A114), cA115 = KC(A115), cA116 = KC(A116), cA117 = KC(A117), cA118 = KC(A118), cA119 = KC(A119), cA1110 = KC(A1110);
 #pragma unroll
     for (int i = 0; i < N; ++i)
-        y1[i] = y[i] + h * (cA111 * k1[i] + cA114 * k4[i] + cA115 * k5[i] + cA116 * k6[i] + cA117 * k7[i] + cA118 * k8[i] + cA119 * k9[i] + cA1110 * k10[i]);
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA111, k1[i], cA114, k4[i], cA115, k5[i], cA116, k6[i], cA117, k7[i], cA118, k8[i], cA119, k9[i], cA1110, k10[i]));
 }
     R::ode(x + KC(C11) * h, y1, k2, p);
     const double xph = x + h;
 { const double cA121 = KC(A121), cA124 = KC(A124), cA125 = KC(A125), cA126 = KC(A126), cA127 = KC(A127), cA128 = KC(A128), cA129 = KC(A129), cA1210 = KC(A1210), cA1211 = KC(A1211);
 #pragma unroll
     for (int i = 0; i < N; ++i)
-        y1[i] = y[i] + h * (cA121 * k1[i] + cA124 * k4[i] + cA125 * k5[i] + cA126 * k6[i] + cA127 * k7[i] + cA128 * k8[i] + cA129 * k9[i]
-                            + cA1210 * k10[i] + cA1211 * k2[i]);
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA121, k1[i], cA124, k4[i], cA125, k5[i], cA126, k6[i], cA127, k7[i], cA128, k8[i], cA129, k9[i],
+                                       cA1210, k10[i], cA1211, k2[i]));
 }
     R::ode(xph, y1, k3, p);
     L.d_nfev += 11;
@@ -1427,26 +1490,26 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 { const double cB1 = KC(B1), cB6 = KC(B6), cB7 = KC(B7), cB8 = KC(B8), cB9 = KC(B9), cB10 = KC(B10), cB11 = KC(B11), cB12 = KC(B12);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        k4[i] = cB1 * k1[i] + cB6 * k6[i] + cB7 * k7[i] + cB8 * k8[i] + cB9 * k9[i] + cB10 * k10[i] + cB11 * k2[i] + cB12 * k3[i];
-        k5[i] = y[i] + h * k4[i];
+        k4[i] = IVP_LC(cB1, k1[i], cB6, k6[i], cB7, k7[i], cB8, k8[i], cB9, k9[i], cB10, k10[i], cB11, k2[i], cB12, k3[i]);
+        k5[i] = IVP_MA(y[i], h, k4[i]);
     }
 }
     double t_err[N], t_err2[N];
 { const double cBH1 = KC(BH1), cBH2 = KC(BH2), cBH3 = KC(BH3), cER1 = KC(ER1), cER6 = KC(ER6), cER7 = KC(ER7), cER8 = KC(ER8), cER9 = KC(ER9), cER10 = KC(ER10), cER11 = KC(ER11), cER12 = KC(ER12);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double sk = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fmax(fabs(y[i]), fabs(k5[i]));
-        double erri = k4[i] - cBH1 * k1[i] - cBH2 * k9[i] - cBH3 * k3[i];
+        const double sk = IVP_MA(NormOps<R>::atol(a, i), NormOps<R>::rtol(a, i), fmax(fabs(y[i]), fabs(k5[i])));
+        double erri = IVP_MS(IVP_MS(IVP_MS(k4[i], cBH1, k1[i]), cBH2, k9[i]), cBH3, k3[i]);
         double q = erri / sk;
         t_err2[i] = q * q;
-        erri = cER1 * k1[i] + cER6 * k6[i] + cER7 * k7[i] + cER8 * k8[i] + cER9 * k9[i] + cER10 * k10[i] + cER11 * k2[i] + cER12 * k3[i];
+        erri = IVP_LC(cER1, k1[i], cER6, k6[i], cER7, k7[i], cER8, k8[i], cER9, k9[i], cER10, k10[i], cER11, k2[i], cER12, k3[i]);
         q = erri / sk;
         t_err[i] = q * q;
     }
 }
     double err = NormOps<R>::sum(t_err);
     const double err2 = NormOps<R>::sum(t_err2);
-    double deno = err + 0.01 * err2;
+    double deno = IVP_MA(err, 0.01, err2);
     if (deno <= 0.0) deno = 1.0;
     err = fabs(h) * err * sqrt(1.0 / ((double)NormOps<R>::NT * deno));
 
@@ -1481,49 +1544,50 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         // coefficients feed nothing but the interpolant, so the kernel evaluates them only when
         // this step's interpolant is actually consumed, and always counts the 3 evaluations.
         L.d_nfev += 3;
-        double cont[FULL ? 8 * N : 1];
+        // the 8 x N dense block: staged through LDS when a lane holds more than one component (see ContStage)
+        typename ivp_cond<(FULL && N >= 2), ContStage<8 * N>, ContRegs<(FULL ? 8 * N : 1)>>::type cont;
         const bool need_dense = FULL && (R::NE > 0 || so_needs_dense<N, P>(a, L, x, xph));
         if (FULL && need_dense) {
 { const double cD41 = KC(D41), cD46 = KC(D46), cD47 = KC(D47), cD48 = KC(D48), cD49 = KC(D49), cD410 = KC(D410), cD411 = KC(D411), cD412 = KC(D412), cD51 = KC(D51), cD56 = KC(D56), cD57 = KC(D57), cD58 = KC(D58), cD59 = KC(D59), cD510 = KC(D510), cD511 = KC(D511), cD512 = KC(D512), cD61 = KC(D61), cD66 = KC(D66), cD67 = KC(D67), cD68 = KC(D68), cD69 = KC(D69), cD610 = KC(D610), cD611 = KC(D611), cD612 = KC(D612), cD71 = KC(D71), cD76 = KC(D76), cD77 = KC(D77), cD78 = KC(D78), cD79 = KC(D79), cD710 = KC(D710), cD711 = KC(D711), cD712 = KC(D712);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                cont[i] = y[i];
+                cont.set(i, y[i]);
                 const double ydiff = k5[i] - y[i];
-                cont[N + i] = ydiff;
-                const double bspl = h * k1[i] - ydiff;
-                cont[2 * N + i] = bspl;
-                cont[3 * N + i] = ydiff - h * k4[i] - bspl;
-                cont[4 * N + i] = cD41 * k1[i] + cD46 * k6[i] + cD47 * k7[i] + cD48 * k8[i] + cD49 * k9[i] + cD410 * k10[i] + cD411 * k2[i] + cD412 * k3[i];
-                cont[5 * N + i] = cD51 * k1[i] + cD56 * k6[i] + cD57 * k7[i] + cD58 * k8[i] + cD59 * k9[i] + cD510 * k10[i] + cD511 * k2[i] + cD512 * k3[i];
-                cont[6 * N + i] = cD61 * k1[i] + cD66 * k6[i] + cD67 * k7[i] + cD68 * k8[i] + cD69 * k9[i] + cD610 * k10[i] + cD611 * k2[i] + cD612 * k3[i];
-                cont[7 * N + i] = cD71 * k1[i] + cD76 * k6[i] + cD77 * k7[i] + cD78 * k8[i] + cD79 * k9[i] + cD710 * k10[i] + cD711 * k2[i] + cD712 * k3[i];
+                cont.set(N + i, ydiff);
+                const double bspl = IVP_MB(h, k1[i], ydiff);
+                cont.set(2 * N + i, bspl);
+                cont.set(3 * N + i, IVP_MS(ydiff, h, k4[i]) - bspl);
+                cont.set(4 * N + i, IVP_LC(cD41, k1[i], cD46, k6[i], cD47, k7[i], cD48, k8[i], cD49, k9[i], cD410, k10[i], cD411, k2[i], cD412, k3[i]));
+                cont.set(5 * N + i, IVP_LC(cD51, k1[i], cD56, k6[i], cD57, k7[i], cD58, k8[i], cD59, k9[i], cD510, k10[i], cD511, k2[i], cD512, k3[i]));
+                cont.set(6 * N + i, IVP_LC(cD61, k1[i], cD66, k6[i], cD67, k7[i], cD68, k8[i], cD69, k9[i], cD610, k10[i], cD611, k2[i], cD612, k3[i]));
+                cont.set(7 * N + i, IVP_LC(cD71, k1[i], cD76, k6[i], cD77, k7[i], cD78, k8[i], cD79, k9[i], cD710, k10[i], cD711, k2[i], cD712, k3[i]));
             }
 }
 { const double cA141 = KC(A141), cA147 = KC(A147), cA148 = KC(A148), cA149 = KC(A149), cA1410 = KC(A1410), cA1411 = KC(A1411), cA1412 = KC(A1412), cA1413 = KC(A1413);
 #pragma unroll
             for (int i = 0; i < N; ++i)
-                y1[i] = y[i] + h * (cA141 * k1[i] + cA147 * k7[i] + cA148 * k8[i] + cA149 * k9[i] + cA1410 * k10[i] + cA1411 * k2[i] + cA1412 * k3[i] + cA1413 * k4[i]);
+                y1[i] = IVP_MA(y[i], h, IVP_LC(cA141, k1[i], cA147, k7[i], cA148, k8[i], cA149, k9[i], cA1410, k10[i], cA1411, k2[i], cA1412, k3[i], cA1413, k4[i]));
 }
             R::ode(x + KC(C14) * h, y1, k10, p);
 { const double cA151 = KC(A151), cA156 = KC(A156), cA157 = KC(A157), cA158 = KC(A158), cA1511 = KC(A1511), cA1512 = KC(A1512), cA1513 = KC(A1513), cA1514 = KC(A1514);
 #pragma unroll
             for (int i = 0; i < N; ++i)
-                y1[i] = y[i] + h * (cA151 * k1[i] + cA156 * k6[i] + cA157 * k7[i] + cA158 * k8[i] + cA1511 * k2[i] + cA1512 * k3[i] + cA1513 * k4[i] + cA1514 * k10[i]);
+                y1[i] = IVP_MA(y[i], h, IVP_LC(cA151, k1[i], cA156, k6[i], cA157, k7[i], cA158, k8[i], cA1511, k2[i], cA1512, k3[i], cA1513, k4[i], cA1514, k10[i]));
 }
             R::ode(x + KC(C15) * h, y1, k2, p);
 { const double cA161 = KC(A161), cA166 = KC(A166), cA167 = KC(A167), cA168 = KC(A168), cA169 = KC(A169), cA1613 = KC(A1613), cA1614 = KC(A1614), cA1615 = KC(A1615);
 #pragma unroll
             for (int i = 0; i < N; ++i)
-                y1[i] = y[i] + h * (cA161 * k1[i] + cA166 * k6[i] + cA167 * k7[i] + cA168 * k8[i] + cA169 * k9[i] + cA1613 * k4[i] + cA1614 * k10[i] + cA1615 * k2[i]);
+                y1[i] = IVP_MA(y[i], h, IVP_LC(cA161, k1[i], cA166, k6[i], cA167, k7[i], cA168, k8[i], cA169, k9[i], cA1613, k4[i], cA1614, k10[i], cA1615, k2[i]));
 }
             R::ode(x + KC(C16) * h, y1, k3, p);
 { const double cD413 = KC(D413), cD414 = KC(D414), cD415 = KC(D415), cD416 = KC(D416), cD513 = KC(D513), cD514 = KC(D514), cD515 = KC(D515), cD516 = KC(D516), cD613 = KC(D613), cD614 = KC(D614), cD615 = KC(D615), cD616 = KC(D616), cD713 = KC(D713), cD714 = KC(D714), cD715 = KC(D715), cD716 = KC(D716);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                cont[4 * N + i] = h * (cont[4 * N + i] + cD413 * k4[i] + cD414 * k10[i] + cD415 * k2[i] + cD416 * k3[i]);
-                cont[5 * N + i] = h * (cont[5 * N + i] + cD513 * k4[i] + cD514 * k10[i] + cD515 * k2[i] + cD516 * k3[i]);
-                cont[6 * N + i] = h * (cont[6 * N + i] + cD613 * k4[i] + cD614 * k10[i] + cD615 * k2[i] + cD616 * k3[i]);
-                cont[7 * N + i] = h * (cont[7 * N + i] + cD713 * k4[i] + cD714 * k10[i] + cD715 * k2[i] + cD716 * k3[i]);
+                cont.set(4 * N + i, h * IVP_NS::ivp_lc(cont[4 * N + i], cD413, k4[i], cD414, k10[i], cD415, k2[i], cD416, k3[i]));
+                cont.set(5 * N + i, h * IVP_NS::ivp_lc(cont[5 * N + i], cD513, k4[i], cD514, k10[i], cD515, k2[i], cD516, k3[i]));
+                cont.set(6 * N + i, h * IVP_NS::ivp_lc(cont[6 * N + i], cD613, k4[i], cD614, k10[i], cD615, k2[i], cD616, k3[i]));
+                cont.set(7 * N + i, h * IVP_NS::ivp_lc(cont[7 * N + i], cD713, k4[i], cD714, k10[i], cD715, k2[i], cD716, k3[i]));
             }
 }
         }
@@ -1532,8 +1596,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         L.x = xph;
         if (FULL) {
             // `cont` is passed even when its dense rows were not computed (need_dense false): every reader is guarded
-            // by exactly the conditions so_needs_dense() tests, and a pointer selected at run time (cont or nullptr)
-            // would force the whole array out of registers into scratch memory
+            // by exactly the conditions so_needs_dense() tests
             if (solout_full<M_DOP853, R>(a, j, L, x, xph, L.y, cont, cont, h, x)) { L.h = h; L.status = 1; return false; }
         }
         if (last) { L.h = hnew; L.status = 0; return false; }
@@ -1576,28 +1639,28 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     double k2[N], k3[N], k4[N], yt[N], ye[N];
 { const double cA21 = KC(A21);
 #pragma unroll
-    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * cA21 * k1[i];
+    for (int i = 0; i < N; ++i) yt[i] = IVP_MA(y[i], h * cA21, k1[i]);
 }
     R::ode(x + KC(C2) * h, yt, k2, p);
 { const double cA32 = KC(A32);
 #pragma unroll
-    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * cA32 * k2[i];
+    for (int i = 0; i < N; ++i) yt[i] = IVP_MA(y[i], h * cA32, k2[i]);
 }
     R::ode(x + KC(C3) * h, yt, k3, p);
 { const double cB1 = KC(B1), cB2 = KC(B2), cB3 = KC(B3);
 #pragma unroll
-    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * (cB1 * k1[i] + cB2 * k2[i] + cB3 * k3[i]);
+    for (int i = 0; i < N; ++i) yt[i] = IVP_MA(y[i], h, IVP_LC(cB1, k1[i], cB2, k2[i], cB3, k3[i]));
 }
     R::ode(x + h, yt, k4, p);
     L.d_nfev += 3;
 { const double cE1 = KC(E1), cE2 = KC(E2), cE3 = KC(E3), cE4 = KC(E4);
 #pragma unroll
-    for (int i = 0; i < N; ++i) ye[i] = h * (cE1 * k1[i] + cE2 * k2[i] + cE3 * k3[i] + cE4 * k4[i]);
+    for (int i = 0; i < N; ++i) ye[i] = h * IVP_LC(cE1, k1[i], cE2, k2[i], cE3, k3[i], cE4, k4[i]);
 }
     double t_err[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const double tl = NormOps<R>::atol(a, i) + NormOps<R>::rtol(a, i) * fmax(fabs(yt[i]), fabs(y[i]));
+        const double tl = IVP_MA(NormOps<R>::atol(a, i), NormOps<R>::rtol(a, i), fmax(fabs(yt[i]), fabs(y[i])));
         const double q = ye[i] / tl;
         t_err[i] = q * q;
     }
@@ -1615,8 +1678,8 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
             for (int i = 0; i < N; ++i) {
                 cont[i] = y[i];
                 cont[N + i] = k1[i];
-                cont[2 * N + i] = cD21 * k1[i] + cD22 * k2[i] + cD23 * k3[i] + cD24 * k4[i];
-                cont[3 * N + i] = cD31 * k1[i] + cD32 * k2[i] + cD33 * k3[i] + cD34 * k4[i];
+                cont[2 * N + i] = IVP_LC(cD21, k1[i], cD22, k2[i], cD23, k3[i], cD24, k4[i]);
+                cont[3 * N + i] = IVP_LC(cD31, k1[i], cD32, k2[i], cD33, k3[i], cD34, k4[i]);
             }
 }
 #pragma unroll
@@ -1667,13 +1730,13 @@ IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     const double *y = L.y, *k1 = L.k1, *p = L.p;
     double k2[N], k3[N], k4[N], yt[N], yold[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * A21 * k1[i];
+    for (int i = 0; i < N; ++i) yt[i] = IVP_MA(y[i], h * A21, k1[i]);
     R::ode(x + C2 * h, yt, k2, p);
 #pragma unroll
-    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * A32 * k2[i];
+    for (int i = 0; i < N; ++i) yt[i] = IVP_MA(y[i], h * A32, k2[i]);
     R::ode(x + C3 * h, yt, k3, p);
 #pragma unroll
-    for (int i = 0; i < N; ++i) yt[i] = y[i] + h * 1.0 * k3[i];
+    for (int i = 0; i < N; ++i) yt[i] = IVP_MA(y[i], h * 1.0, k3[i]);
     R::ode(x + 1.0 * h, yt, k4, p);
     const double xnew = x + h;
     {
@@ -1681,7 +1744,7 @@ IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             yold[i] = y[i];
-            L.y[i] = y[i] + h * (cB1 * k1[i] + cB2 * k2[i] + cB3 * k3[i] + cB4 * k4[i]);
+            L.y[i] = IVP_MA(y[i], h, IVP_LC(cB1, k1[i], cB2, k2[i], cB3, k3[i], cB4, k4[i]));
         }
     }
     R::ode(xnew, L.y, L.k1, p);

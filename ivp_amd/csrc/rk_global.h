@@ -67,10 +67,12 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
     }
 }
 
+// Occupancy hint: two waves per SIMD (256 VGPRs) for the lean build, except where the live set cannot fit them without
+// scratch: BDF, and DOP853 with the device DefaultSolOut on systems of 5+ components (10 stage vectors + the SolOut state).
 // CTL = true: controller fields from IvpKArgs.ctl_* (a direct method call with non-default struct fields);
 // CTL = false keeps them compile-time constants, which is the path solve_ivp() takes.
 template <int M, class R, bool FULL, bool CTL = false>
-__global__ __launch_bounds__(IVP_WAVE, (M == M_BDF) ? 1 : IVP_MIN_WAVES) void chunk_kernel_t(const IvpKArgs a)
+__global__ __launch_bounds__(IVP_WAVE, (M == M_BDF || (M == M_DOP853 && FULL && R::N >= 5)) ? 1 : IVP_MIN_WAVES) void chunk_kernel_t(const IvpKArgs a)
 {
     chunk_kernel_body<M, R, FULL, CTL>(a);
 }

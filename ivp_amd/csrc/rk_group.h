@@ -40,7 +40,7 @@ struct RhsHeat1D256 {        // method-of-lines heat equation, Dirichlet ends: y
     {
         const double left = i > 0 ? y[i - 1] : 0.0;
         const double right = i < N - 1 ? y[i + 1] : 0.0;
-        return p[0] * (left - 2.0 * y[i] + right);
+        return p[0] * (IVP_MS(left, 2.0, y[i]) + right);
     }
 };
 

@@ -6,6 +6,13 @@
  * every expression below keeps the reference's left-to-right association so that the
  * arithmetic is the same IEEE-754 operation sequence.
  *
+ * Third build, -DORC_FMA -DORC_DETPOW (liboracle_fma.so): the checker of the kernels' FMA arithmetic mode
+ * (ivp_options_t.fp_mode = IVP_FP_FMA).  That mode is a defined arithmetic: the multiply-add sites marked MA / MS / MB /
+ * LCn below -- stage combinations, error estimates, dense coefficients, interpolants, tolerance scales, the built-in
+ * right-hand sides (which there also share one reciprocal per primary) -- are single fused operations, everything else
+ * is unchanged, and norms of systems with n > 8 are summed in the wave-per-trajectory kernels' order (orc_sum).  The
+ * same sites are fused in ivp_amd/csrc/rk_core.h (IVP_MA / IVP_MS / IVP_MB / IVP_LC), still without compiler contraction.
+ *
  * Citations are file:line in the reference tree.
  */
 #include "ivp_oracle.h"
@@ -21,6 +28,54 @@
 /* ------------------------------------------------------------------------------------------
  * Step-controller power function
  * ---------------------------------------------------------------------------------------- */
+
+/* the multiply-add sites: two IEEE operations in the reference's association, or one fused operation (ORC_FMA) */
+#ifdef ORC_FMA
+#define MA(acc, a, b) fma((a), (b), (acc))     /* acc + a * b */
+#define MS(acc, a, b) fma(-(a), (b), (acc))    /* acc - a * b */
+#define MB(a, b, c) fma((a), (b), -(c))        /* a * b - c   */
+#else
+#define MA(acc, a, b) ((acc) + (a) * (b))
+#define MS(acc, a, b) ((acc) - (a) * (b))
+#define MB(a, b, c) ((a) * (b) - (c))
+#endif
+/* ((c1 k1 + c2 k2) + c3 k3) + ... : the reference's left-to-right sums of products */
+#define LC2(c1, k1, c2, k2) MA((c1) * (k1), c2, k2)
+#define LC3(c1, k1, c2, k2, c3, k3) MA(LC2(c1, k1, c2, k2), c3, k3)
+#define LC4(c1, k1, c2, k2, c3, k3, c4, k4) MA(LC3(c1, k1, c2, k2, c3, k3), c4, k4)
+#define LC5(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5) MA(LC4(c1, k1, c2, k2, c3, k3, c4, k4), c5, k5)
+#define LC6(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6) MA(LC5(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5), c6, k6)
+#define LC7(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6, c7, k7) MA(LC6(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6), c7, k7)
+#define LC8(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6, c7, k7, c8, k8) \
+    MA(LC7(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6, c7, k7), c8, k8)
+#define LC9(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6, c7, k7, c8, k8, c9, k9) \
+    MA(LC8(c1, k1, c2, k2, c3, k3, c4, k4, c5, k5, c6, k6, c7, k7, c8, k8), c9, k9)
+
+/* Sum of the n terms of a weighted norm.  Reference: left to right (dopri5.rs:343-347).  ORC_FMA build, n > 8: the
+ * order of the wave-per-trajectory kernels' FMA build (ivp_amd/csrc/rk_group.h, NormOps<GroupRhs>::sum): lane l of a
+ * group of G lanes adds its terms l, l + G, ... starting from 0.0, then log2 G butterfly steps
+ * part += shfl_xor(part, o), o = G/2 .. 1; G = 16 / 32 / 64 for n <= 16 / <= 32 / larger (ivp_group_width). */
+static double orc_sum(const double *t, int n)
+{
+#ifdef ORC_FMA
+    if (n > 8) {
+        const int G = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
+        double part[64], nxt[64];
+        for (int l = 0; l < G; l++) {
+            part[l] = 0.0;
+            for (int i = l; i < n; i += G) part[l] += t[i];
+        }
+        for (int o = G / 2; o > 0; o >>= 1) {
+            for (int l = 0; l < G; l++) nxt[l] = part[l] + part[l ^ o];
+            memcpy(part, nxt, sizeof(double) * (size_t)G);
+        }
+        return part[0];
+    }
+#endif
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += t[i];
+    return s;
+}
 
 static inline uint64_t d2bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 static inline double bits2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
@@ -118,6 +173,12 @@ int orc_uses_detpow(void) { return 0; }
 static inline double orc_pow_small_int(double x, int n) { return pow(x, (double)n); }   /* the reference's own call */
 #endif
 
+#ifdef ORC_FMA
+int orc_uses_fma(void) { return 1; }
+#else
+int orc_uses_fma(void) { return 0; }
+#endif
+
 /* Rust f64::signum: 1.0 for +0.0 and positives, -1.0 for -0.0 and negatives, NaN for NaN. */
 static inline double rs_signum(double v) { return v != v ? v : copysign(1.0, v); }
 
@@ -141,7 +202,7 @@ static void rhs_vdp(double x, const double *y, double *d, const double *p)
     (void)x;
     double mu = p[0];
     d[0] = y[1];
-    d[1] = mu * (1.0 - y[0] * y[0]) * y[1] - y[0];
+    d[1] = MB(mu * MS(1.0, y[0], y[0]), y[1], y[0]);   /* mu * (1 - y0 * y0) * y1 - y0 */
 }
 static void rhs_cr3bp(double t, const double *s, double *d, const double *p)
 {   /* examples/cr3bp.rs:24-35 */
@@ -150,6 +211,20 @@ static void rhs_cr3bp(double t, const double *s, double *d, const double *p)
     double x = s[0], y = s[1], z = s[2], vx = s[3], vy = s[4], vz = s[5];
     double a = x + mu;
     double b = x - 1.0 + mu;
+#ifdef ORC_FMA
+    /* FMA form (RhsCr3bp::ode under IVP_FAST in rk_core.h): one division per primary, every a * b + c fused */
+    double d1 = fma(z, z, fma(y, y, a * a));
+    double d2 = fma(z, z, fma(y, y, b * b));
+    double r1 = sqrt(d1), r2 = sqrt(d2);
+    double g1 = (1.0 - mu) / (d1 * r1);
+    double g2 = mu / (d2 * r2);
+    d[0] = vx;
+    d[1] = vy;
+    d[2] = vz;
+    d[3] = fma(-g2, b, fma(-g1, a, fma(2.0, vy, x)));
+    d[4] = fma(-g2, y, fma(-g1, y, fma(-2.0, vx, y)));
+    d[5] = fma(-g2, z, fma(-g1, z, -0.0));
+#else
     double r1 = sqrt(a * a + y * y + z * z);
     double r2 = sqrt(b * b + y * y + z * z);
     double r13 = r1 * r1 * r1; /* powi(3) */
@@ -160,6 +235,7 @@ static void rhs_cr3bp(double t, const double *s, double *d, const double *p)
     d[3] = x + 2.0 * vy - (1.0 - mu) * (x + mu) / r13 - mu * (x - 1.0 + mu) / r23;
     d[4] = y - 2.0 * vx - (1.0 - mu) * y / r13 - mu * y / r23;
     d[5] = -(1.0 - mu) * z / r13 - mu * z / r23;
+#endif
 }
 static void rhs_lorenz(double t, const double *s, double *d, const double *p)
 {   /* benches/benchmark.py:30-37 */
@@ -167,8 +243,8 @@ static void rhs_lorenz(double t, const double *s, double *d, const double *p)
     double sigma = p[0], rho = p[1], beta = p[2];
     double x = s[0], y = s[1], z = s[2];
     d[0] = sigma * (y - x);
-    d[1] = x * (rho - z) - y;
-    d[2] = x * y - beta * z;
+    d[1] = MB(x, rho - z, y);        /* x * (rho - z) - y */
+    d[2] = MS(x * y, beta, z);       /* x * y - beta * z */
 }
 static void rhs_zero(double t, const double *s, double *d, const double *p)
 {   /* tests/ivp.rs:14-18 */
@@ -179,7 +255,7 @@ static void rhs_rational(double t, const double *y, double *d, const double *p)
 {   /* tests/test_helpers.py:23-25 */
     (void)p;
     d[0] = y[1] / t;
-    d[1] = y[1] * (y[0] + 2.0 * y[1] - 1.0) / (t * (y[0] - 1.0));
+    d[1] = y[1] * (MA(y[0], 2.0, y[1]) - 1.0) / (t * (y[0] - 1.0));
 }
 static void rhs_exp2(double t, const double *y, double *d, const double *p)
 {   /* tests/ivp.rs:293-297 */
@@ -191,22 +267,22 @@ static void rhs_exp2(double t, const double *y, double *d, const double *p)
 static void rhs_linear(double t, const double *y, double *d, const double *p)
 {   /* tests/test_helpers.py:11-12 */
     (void)t; (void)p;
-    d[0] = -y[0] - 5.0 * y[1];
+    d[0] = MS(-y[0], 5.0, y[1]);
     d[1] = y[0] + y[1];
 }
 static void rhs_robertson(double t, const double *s, double *d, const double *p)
 {   /* tests/test_ivp.py:327-333 */
     (void)t; (void)p;
     double x = s[0], y = s[1], z = s[2];
-    d[0] = -0.04 * x + 1e4 * y * z;
-    d[1] = 0.04 * x - 1e4 * y * z - 3e7 * y * y;
+    d[0] = MA(-0.04 * x, 1e4 * y, z);                  /* -0.04 x + 1e4 y z */
+    d[1] = MS(MS(0.04 * x, 1e4 * y, z), 3e7 * y, y);   /* 0.04 x - 1e4 y z - 3e7 y y */
     d[2] = 3e7 * y * y;
 }
 static void rhs_vdp_eps(double t, const double *y, double *d, const double *p)
 {   /* examples/van_der_pol.rs:9-14 */
     (void)t;
     d[0] = y[1];
-    d[1] = ((1.0 - y[0] * y[0]) * y[1] - y[0]) / p[0];
+    d[1] = MB(MS(1.0, y[0], y[0]), y[1], y[0]) / p[0];   /* ((1 - y0 y0) y1 - y0) / eps */
 }
 
 static void rhs_ball(double t, const double *s, double *d, const double *p)
@@ -214,7 +290,7 @@ static void rhs_ball(double t, const double *s, double *d, const double *p)
     (void)t;
     double vy = s[1];
     d[0] = vy;
-    d[1] = -p[0] - p[1] * vy * fabs(vy);
+    d[1] = MS(-p[0], p[1] * vy, fabs(vy));   /* -g - drag vy |vy| */
 }
 static void rhs_cannon(double t, const double *y, double *d, const double *p)
 {   /* tests/test_ivp.py:153-154 */
@@ -233,7 +309,7 @@ static void rhs_heat1d256(double t, const double *y, double *d, const double *p)
     for (int i = 0; i < 256; i++) {
         double left = i > 0 ? y[i - 1] : 0.0;
         double right = i < 255 ? y[i + 1] : 0.0;
-        d[i] = p[0] * (left - 2.0 * y[i] + right);
+        d[i] = p[0] * (MS(left, 2.0, y[i]) + right);
     }
 }
 /* event functions: trait IVP::events (src/ivp.rs:31-40) */
@@ -264,7 +340,7 @@ static void jac_robertson(double t, const double *s, double *j, const double *p)
     (void)t; (void)p;
     const double y = s[1], z = s[2];
     j[0] = -0.04;  j[1] = 1e4 * z;              j[2] = 1e4 * y;
-    j[3] = 0.04;   j[4] = -1e4 * z - 6e7 * y;   j[5] = -1e4 * y;
+    j[3] = 0.04;   j[4] = MS(-1e4 * z, 6e7, y);   j[5] = -1e4 * y;
     j[6] = 0.0;    j[7] = 6e7 * y;              j[8] = 0.0;
 }
 orc_jac_fn orc_builtin_jac(int rhs_id) { return rhs_id == ORC_RHS_ROBERTSON_JAC ? jac_robertson : NULL; }
@@ -299,9 +375,7 @@ static void interp_dopri5(double xi, double *yi, const double *cont, int n, doub
     double theta = (xi - xold) / h;
     double theta1 = 1.0 - theta;
     for (int i = 0; i < n; i++) {
-        yi[i] = cont[i]
-              + theta * (cont[n + i]
-                         + theta1 * (cont[2 * n + i] + theta * (cont[3 * n + i] + theta1 * cont[4 * n + i])));
+        yi[i] = MA(cont[i], theta, MA(cont[n + i], theta1, MA(cont[2 * n + i], theta, MA(cont[3 * n + i], theta1, cont[4 * n + i]))));
     }
 }
 static void interp_dop853(double xi, double *yi, const double *cont, int n, double xold, double h)
@@ -309,8 +383,8 @@ static void interp_dop853(double xi, double *yi, const double *cont, int n, doub
     double s = (xi - xold) / h;
     double s1 = 1.0 - s;
     for (int i = 0; i < n; i++) {
-        double conpar = cont[4 * n + i] + s * (cont[5 * n + i] + s1 * (cont[6 * n + i] + s * cont[7 * n + i]));
-        yi[i] = cont[i] + s * (cont[n + i] + s1 * (cont[2 * n + i] + s * (cont[3 * n + i] + s1 * conpar)));
+        double conpar = MA(cont[4 * n + i], s, MA(cont[5 * n + i], s1, MA(cont[6 * n + i], s, cont[7 * n + i])));
+        yi[i] = MA(cont[i], s, MA(cont[n + i], s1, MA(cont[2 * n + i], s, MA(cont[3 * n + i], s1, conpar))));
     }
 }
 static void interp_rk23(double xi, double *yi, const double *cont, int n, double xold, double h)
@@ -319,7 +393,7 @@ static void interp_rk23(double xi, double *yi, const double *cont, int n, double
     double x2 = xc * xc;
     double x3 = x2 * xc;
     for (int i = 0; i < n; i++) {
-        yi[i] = cont[i] + h * (cont[n + i] * xc + cont[2 * n + i] * x2 + cont[3 * n + i] * x3);
+        yi[i] = MA(cont[i], h, LC3(cont[n + i], xc, cont[2 * n + i], x2, cont[3 * n + i], x3));
     }
 }
 static void interp_rk4(double xi, double *yi, const double *cont, int n, double xold, double h)
@@ -332,7 +406,7 @@ static void interp_rk4(double xi, double *yi, const double *cont, int n, double 
     double h01 = -2.0 * t3 + 3.0 * t2;
     double h11 = t3 - t2;
     for (int i = 0; i < n; i++)
-        yi[i] = h00 * cont[i] + h10 * h * cont[n + i] + h01 * cont[3 * n + i] + h11 * h * cont[2 * n + i];
+        yi[i] = LC4(h00, cont[i], h10 * h, cont[n + i], h01, cont[3 * n + i], h11 * h, cont[2 * n + i]);
 }
 static void interp_bdf(double xi, double *yi, const double *cont, int n, double xold, double h)
 {   /* bdf.rs:618-656; cont is per-state blocks [D0, D1..D5, order] */
@@ -595,27 +669,28 @@ static double hinit(orc_ode_fn f, const double *p, int n, double x, const double
                     const double *f0, double *f1, double *y1, int iord, double hmax,
                     const tol_t *atol, const tol_t *rtol)
 {
-    double dnf = 0.0, dny = 0.0;
+    double t_a[ORC_MAX_N], t_b[ORC_MAX_N];
     for (int i = 0; i < n; i++) {
-        double sk = tol_at(atol, i) + tol_at(rtol, i) * fabs(y[i]);
-        dnf += (f0[i] / sk) * (f0[i] / sk);
-        dny += (y[i] / sk) * (y[i] / sk);
+        double sk = MA(tol_at(atol, i), tol_at(rtol, i), fabs(y[i]));
+        t_a[i] = (f0[i] / sk) * (f0[i] / sk);
+        t_b[i] = (y[i] / sk) * (y[i] / sk);
     }
+    double dnf = orc_sum(t_a, n), dny = orc_sum(t_b, n);
     double h;
     if (dnf <= 1e-10 || dny <= 1e-10) h = 1.0e-6;
     else h = sqrt(dny / dnf) * 0.01;
     if (h > fabs(hmax)) h = fabs(hmax);
     h = fabs(h) * rs_signum(posneg);
 
-    for (int i = 0; i < n; i++) y1[i] = y[i] + h * f0[i];
+    for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, f0[i]);
     f(x + h, y1, f1, p);
 
-    double der2 = 0.0;
     for (int i = 0; i < n; i++) {
-        double sk = tol_at(atol, i) + tol_at(rtol, i) * fabs(y[i]);
+        double sk = MA(tol_at(atol, i), tol_at(rtol, i), fabs(y[i]));
         double df = (f1[i] - f0[i]) / sk;
-        der2 += df * df;
+        t_a[i] = df * df;
     }
+    double der2 = orc_sum(t_a, n);
     der2 = sqrt(der2) / fabs(h);
     double der12 = fmax(fabs(der2), sqrt(dnf));
     double h1;
@@ -668,9 +743,9 @@ static int dopri5_solve(orc_ode_fn f, const double *p, int n, double x0, const d
     if (nstiff == 0) return ORC_ERR_MUST_BE_POSITIVE;
 
     double x = x0;
-    double *w = (double *)malloc((size_t)n * (8 + 5) * sizeof(double));
+    double *w = (double *)malloc((size_t)n * (8 + 5 + 2) * sizeof(double));
     double *y = w, *k1 = w + n, *k2 = w + 2 * n, *k3 = w + 3 * n, *k4 = w + 4 * n, *k5 = w + 5 * n,
-           *k6 = w + 6 * n, *y1 = w + 7 * n, *cont = w + 8 * n;
+           *k6 = w + 6 * n, *y1 = w + 7 * n, *cont = w + 8 * n, *t_a = w + 13 * n, *t_b = w + 14 * n;
     memcpy(y, y0, (size_t)n * sizeof(double));
     memset(k1, 0, (size_t)n * 12 * sizeof(double));
 
@@ -702,35 +777,36 @@ static int dopri5_solve(orc_ode_fn f, const double *p, int n, double x0, const d
         nstep += 1;
         attempts += 1;
 
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * A21 * k1[i];
+        /* dopri5.rs:287-325; stage 2 is y + (h * A21) * k1, later stages y + h * (sum in source order) */
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h * A21, k1[i]);
         f(x + C2 * h, y1, k2, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A31 * k1[i] + A32 * k2[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC2(A31, k1[i], A32, k2[i]));
         f(x + C3 * h, y1, k3, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC3(A41, k1[i], A42, k2[i], A43, k3[i]));
         f(x + C4 * h, y1, k4, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC4(A51, k1[i], A52, k2[i], A53, k3[i], A54, k4[i]));
         f(x + C5 * h, y1, k5, p);
         for (int i = 0; i < n; i++)
-            y1[i] = y[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]);
+            y1[i] = MA(y[i], h, LC5(A61, k1[i], A62, k2[i], A63, k3[i], A64, k4[i], A65, k5[i]));
         double xph = x + h;
         f(xph, y1, k6, p);
         for (int i = 0; i < n; i++)
-            y1[i] = y[i] + h * (A71 * k1[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+            y1[i] = MA(y[i], h, LC5(A71, k1[i], A73, k3[i], A74, k4[i], A75, k5[i], A76, k6[i]));
         f(xph, y1, k2, p);
         nfev += 6;
 
         /* dense block 4 (always: struct default dense_output = true, dopri5.rs:329-334) */
         for (int i = 0; i < n; i++)
-            cont[4 * n + i] = h * (D1 * k1[i] + D3 * k3[i] + D4 * k4[i] + D5 * k5[i] + D6 * k6[i] + D7 * k2[i]);
+            cont[4 * n + i] = h * LC6(D1, k1[i], D3, k3[i], D4, k4[i], D5, k5[i], D6, k6[i], D7, k2[i]);
 
         for (int i = 0; i < n; i++)
-            k4[i] = (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k2[i]) * h;
+            k4[i] = LC6(E1, k1[i], E3, k3[i], E4, k4[i], E5, k5[i], E6, k6[i], E7, k2[i]) * h;
 
-        double err = 0.0;
         for (int i = 0; i < n; i++) {
-            double sk = tol_at(atol, i) + tol_at(rtol, i) * fmax(fabs(y[i]), fabs(y1[i]));
-            err += (k4[i] / sk) * (k4[i] / sk);
+            double sk = MA(tol_at(atol, i), tol_at(rtol, i), fmax(fabs(y[i]), fabs(y1[i])));
+            t_a[i] = (k4[i] / sk) * (k4[i] / sk);
         }
+        double err = orc_sum(t_a, n);
         err = sqrt(err / (double)n);
 
         double fac11 = ORC_POW(err, expo1);
@@ -743,14 +819,14 @@ static int dopri5_solve(orc_ode_fn f, const double *p, int n, double x0, const d
             naccpt += 1;
 
             if ((naccpt % nstiff == 0) || (iasti > 0)) { /* dopri5.rs:364-391 */
-                double stnum = 0.0, stden = 0.0;
                 for (int i = 0; i < n; i++) {
                     double d1 = k2[i] - k6[i];
-                    double ysti = y[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]);
+                    double ysti = MA(y[i], h, LC5(A61, k1[i], A62, k2[i], A63, k3[i], A64, k4[i], A65, k5[i]));
                     double d2 = y1[i] - ysti;
-                    stnum += d1 * d1;
-                    stden += d2 * d2;
+                    t_a[i] = d1 * d1;
+                    t_b[i] = d2 * d2;
                 }
+                double stnum = orc_sum(t_a, n), stden = orc_sum(t_b, n);
                 if (stden > 0.0) hlamb = fabs(h) * sqrt(stnum / stden);
                 if (hlamb > 3.25) {
                     nonstiff = 0;
@@ -764,11 +840,11 @@ static int dopri5_solve(orc_ode_fn f, const double *p, int n, double x0, const d
 
             for (int i = 0; i < n; i++) { /* dopri5.rs:394-403 */
                 double ydiff = y1[i] - y[i];
-                double bspl = h * k1[i] - ydiff;
+                double bspl = MB(h, k1[i], ydiff);
                 cont[i] = y[i];
                 cont[n + i] = ydiff;
                 cont[2 * n + i] = bspl;
-                cont[3 * n + i] = -h * k2[i] + ydiff - bspl;
+                cont[3 * n + i] = MA(ydiff, -h, k2[i]) - bspl;   /* -h k7 + ydiff - bspl */
             }
 
             memcpy(k1, k2, (size_t)n * sizeof(double));
@@ -901,10 +977,10 @@ static int dop853_solve(orc_ode_fn f, const double *p, int n, double x0, const d
     if (nstiff == 0) return ORC_ERR_MUST_BE_POSITIVE;
 
     double x = x0;
-    double *w = (double *)malloc((size_t)n * (12 + 8) * sizeof(double));
+    double *w = (double *)malloc((size_t)n * (12 + 8 + 2) * sizeof(double));
     double *y = w, *y1 = w + n, *k1 = w + 2 * n, *k2 = w + 3 * n, *k3 = w + 4 * n, *k4 = w + 5 * n,
            *k5 = w + 6 * n, *k6 = w + 7 * n, *k7 = w + 8 * n, *k8 = w + 9 * n, *k9 = w + 10 * n,
-           *k10 = w + 11 * n, *cont = w + 12 * n;
+           *k10 = w + 11 * n, *cont = w + 12 * n, *t_a = w + 20 * n, *t_b = w + 21 * n;
     memcpy(y, y0, (size_t)n * sizeof(double));
     memset(y1, 0, (size_t)n * 19 * sizeof(double));
 
@@ -935,57 +1011,56 @@ static int dop853_solve(orc_ode_fn f, const double *p, int n, double x0, const d
         nstep += 1;
         attempts += 1;
 
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * A21 * k1[i];
+        /* dop853.rs:293-390 */
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h * A21, k1[i]);
         f(x + C2 * h, y1, k2, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A31 * k1[i] + A32 * k2[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC2(A31, k1[i], A32, k2[i]));
         f(x + C3 * h, y1, k3, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A41 * k1[i] + A43 * k3[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC2(A41, k1[i], A43, k3[i]));
         f(x + C4 * h, y1, k4, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A51 * k1[i] + A53 * k3[i] + A54 * k4[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC3(A51, k1[i], A53, k3[i], A54, k4[i]));
         f(x + C5 * h, y1, k5, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A61 * k1[i] + A64 * k4[i] + A65 * k5[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC3(A61, k1[i], A64, k4[i], A65, k5[i]));
         f(x + C6 * h, y1, k6, p);
-        for (int i = 0; i < n; i++) y1[i] = y[i] + h * (A71 * k1[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+        for (int i = 0; i < n; i++) y1[i] = MA(y[i], h, LC4(A71, k1[i], A74, k4[i], A75, k5[i], A76, k6[i]));
         f(x + C7 * h, y1, k7, p);
         for (int i = 0; i < n; i++)
-            y1[i] = y[i] + h * (A81 * k1[i] + A84 * k4[i] + A85 * k5[i] + A86 * k6[i] + A87 * k7[i]);
+            y1[i] = MA(y[i], h, LC5(A81, k1[i], A84, k4[i], A85, k5[i], A86, k6[i], A87, k7[i]));
         f(x + C8 * h, y1, k8, p);
         for (int i = 0; i < n; i++)
-            y1[i] = y[i] + h * (A91 * k1[i] + A94 * k4[i] + A95 * k5[i] + A96 * k6[i] + A97 * k7[i] + A98 * k8[i]);
+            y1[i] = MA(y[i], h, LC6(A91, k1[i], A94, k4[i], A95, k5[i], A96, k6[i], A97, k7[i], A98, k8[i]));
         f(x + C9 * h, y1, k9, p);
         for (int i = 0; i < n; i++)
-            y1[i] = y[i] + h * (A101 * k1[i] + A104 * k4[i] + A105 * k5[i] + A106 * k6[i] + A107 * k7[i]
-                                + A108 * k8[i] + A109 * k9[i]);
+            y1[i] = MA(y[i], h, LC7(A101, k1[i], A104, k4[i], A105, k5[i], A106, k6[i], A107, k7[i],
+                                    A108, k8[i], A109, k9[i]));
         f(x + C10 * h, y1, k10, p);
         for (int i = 0; i < n; i++)
-            y1[i] = y[i] + h * (A111 * k1[i] + A114 * k4[i] + A115 * k5[i] + A116 * k6[i] + A117 * k7[i]
-                                + A118 * k8[i] + A119 * k9[i] + A1110 * k10[i]);
+            y1[i] = MA(y[i], h, LC8(A111, k1[i], A114, k4[i], A115, k5[i], A116, k6[i], A117, k7[i],
+                                    A118, k8[i], A119, k9[i], A1110, k10[i]));
         f(x + C11 * h, y1, k2, p);
         double xph = x + h;
         for (int i = 0; i < n; i++)
-            y1[i] = y[i] + h * (A121 * k1[i] + A124 * k4[i] + A125 * k5[i] + A126 * k6[i] + A127 * k7[i]
-                                + A128 * k8[i] + A129 * k9[i] + A1210 * k10[i] + A1211 * k2[i]);
+            y1[i] = MA(y[i], h, LC9(A121, k1[i], A124, k4[i], A125, k5[i], A126, k6[i], A127, k7[i],
+                                    A128, k8[i], A129, k9[i], A1210, k10[i], A1211, k2[i]));
         f(xph, y1, k3, p);
         nfev += 11;
 
         for (int i = 0; i < n; i++) {
-            k4[i] = B1 * k1[i] + B6 * k6[i] + B7 * k7[i] + B8 * k8[i] + B9 * k9[i] + B10 * k10[i]
-                  + B11 * k2[i] + B12 * k3[i];
-            k5[i] = y[i] + h * k4[i];
+            k4[i] = LC8(B1, k1[i], B6, k6[i], B7, k7[i], B8, k8[i], B9, k9[i], B10, k10[i], B11, k2[i], B12, k3[i]);
+            k5[i] = MA(y[i], h, k4[i]);
         }
 
-        double err = 0.0, err2 = 0.0;
         for (int i = 0; i < n; i++) {
-            double sk = tol_at(atol, i) + tol_at(rtol, i) * fmax(fabs(y[i]), fabs(k5[i]));
-            double erri = k4[i] - BH1 * k1[i] - BH2 * k9[i] - BH3 * k3[i];
+            double sk = MA(tol_at(atol, i), tol_at(rtol, i), fmax(fabs(y[i]), fabs(k5[i])));
+            double erri = MS(MS(MS(k4[i], BH1, k1[i]), BH2, k9[i]), BH3, k3[i]);
             double q = erri / sk;
-            err2 += q * q; /* powi(2) */
-            erri = ER1 * k1[i] + ER6 * k6[i] + ER7 * k7[i] + ER8 * k8[i] + ER9 * k9[i] + ER10 * k10[i]
-                 + ER11 * k2[i] + ER12 * k3[i];
+            t_b[i] = q * q; /* powi(2) */
+            erri = LC8(ER1, k1[i], ER6, k6[i], ER7, k7[i], ER8, k8[i], ER9, k9[i], ER10, k10[i], ER11, k2[i], ER12, k3[i]);
             q = erri / sk;
-            err += q * q;
+            t_a[i] = q * q;
         }
-        double deno = err + 0.01 * err2;
+        double err = orc_sum(t_a, n), err2 = orc_sum(t_b, n);
+        double deno = MA(err, 0.01, err2);
         if (deno <= 0.0) deno = 1.0;
         err = fabs(h) * err * sqrt(1.0 / ((double)n * deno));
 
@@ -1001,13 +1076,13 @@ static int dop853_solve(orc_ode_fn f, const double *p, int n, double x0, const d
             nfev += 1;
 
             if ((naccpt % nstiff == 0) || (iasti > 0)) { /* dop853.rs:447-472 */
-                double stnum = 0.0, stden = 0.0;
                 for (int i = 0; i < n; i++) {
                     double d1 = k4[i] - k3[i];
                     double d2 = k5[i] - y1[i];
-                    stnum += d1 * d1;
-                    stden += d2 * d2;
+                    t_a[i] = d1 * d1;
+                    t_b[i] = d2 * d2;
                 }
+                double stnum = orc_sum(t_a, n), stden = orc_sum(t_b, n);
                 if (stden > 0.0) hlamb = fabs(h) * sqrt(stnum / stden);
                 if (hlamb > 6.1) {
                     nonstiff = 0;
@@ -1024,36 +1099,36 @@ static int dop853_solve(orc_ode_fn f, const double *p, int n, double x0, const d
                 cont[i] = y[i];
                 double ydiff = k5[i] - y[i];
                 cont[n + i] = ydiff;
-                double bspl = h * k1[i] - ydiff;
+                double bspl = MB(h, k1[i], ydiff);
                 cont[2 * n + i] = bspl;
-                cont[3 * n + i] = ydiff - h * k4[i] - bspl;
-                cont[4 * n + i] = D41 * k1[i] + D46 * k6[i] + D47 * k7[i] + D48 * k8[i] + D49 * k9[i]
-                                + D410 * k10[i] + D411 * k2[i] + D412 * k3[i];
-                cont[5 * n + i] = D51 * k1[i] + D56 * k6[i] + D57 * k7[i] + D58 * k8[i] + D59 * k9[i]
-                                + D510 * k10[i] + D511 * k2[i] + D512 * k3[i];
-                cont[6 * n + i] = D61 * k1[i] + D66 * k6[i] + D67 * k7[i] + D68 * k8[i] + D69 * k9[i]
-                                + D610 * k10[i] + D611 * k2[i] + D612 * k3[i];
-                cont[7 * n + i] = D71 * k1[i] + D76 * k6[i] + D77 * k7[i] + D78 * k8[i] + D79 * k9[i]
-                                + D710 * k10[i] + D711 * k2[i] + D712 * k3[i];
+                cont[3 * n + i] = MS(ydiff, h, k4[i]) - bspl;
+                cont[4 * n + i] = LC8(D41, k1[i], D46, k6[i], D47, k7[i], D48, k8[i], D49, k9[i],
+                                      D410, k10[i], D411, k2[i], D412, k3[i]);
+                cont[5 * n + i] = LC8(D51, k1[i], D56, k6[i], D57, k7[i], D58, k8[i], D59, k9[i],
+                                      D510, k10[i], D511, k2[i], D512, k3[i]);
+                cont[6 * n + i] = LC8(D61, k1[i], D66, k6[i], D67, k7[i], D68, k8[i], D69, k9[i],
+                                      D610, k10[i], D611, k2[i], D612, k3[i]);
+                cont[7 * n + i] = LC8(D71, k1[i], D76, k6[i], D77, k7[i], D78, k8[i], D79, k9[i],
+                                      D710, k10[i], D711, k2[i], D712, k3[i]);
             }
             for (int i = 0; i < n; i++)
-                y1[i] = y[i] + h * (A141 * k1[i] + A147 * k7[i] + A148 * k8[i] + A149 * k9[i] + A1410 * k10[i]
-                                    + A1411 * k2[i] + A1412 * k3[i] + A1413 * k4[i]);
+                y1[i] = MA(y[i], h, LC8(A141, k1[i], A147, k7[i], A148, k8[i], A149, k9[i], A1410, k10[i],
+                                        A1411, k2[i], A1412, k3[i], A1413, k4[i]));
             f(x + C14 * h, y1, k10, p);
             for (int i = 0; i < n; i++)
-                y1[i] = y[i] + h * (A151 * k1[i] + A156 * k6[i] + A157 * k7[i] + A158 * k8[i] + A1511 * k2[i]
-                                    + A1512 * k3[i] + A1513 * k4[i] + A1514 * k10[i]);
+                y1[i] = MA(y[i], h, LC8(A151, k1[i], A156, k6[i], A157, k7[i], A158, k8[i], A1511, k2[i],
+                                        A1512, k3[i], A1513, k4[i], A1514, k10[i]));
             f(x + C15 * h, y1, k2, p);
             for (int i = 0; i < n; i++)
-                y1[i] = y[i] + h * (A161 * k1[i] + A166 * k6[i] + A167 * k7[i] + A168 * k8[i] + A169 * k9[i]
-                                    + A1613 * k4[i] + A1614 * k10[i] + A1615 * k2[i]);
+                y1[i] = MA(y[i], h, LC8(A161, k1[i], A166, k6[i], A167, k7[i], A168, k8[i], A169, k9[i],
+                                        A1613, k4[i], A1614, k10[i], A1615, k2[i]));
             f(x + C16 * h, y1, k3, p);
             nfev += 3;
             for (int i = 0; i < n; i++) {
-                cont[4 * n + i] = h * (cont[4 * n + i] + D413 * k4[i] + D414 * k10[i] + D415 * k2[i] + D416 * k3[i]);
-                cont[5 * n + i] = h * (cont[5 * n + i] + D513 * k4[i] + D514 * k10[i] + D515 * k2[i] + D516 * k3[i]);
-                cont[6 * n + i] = h * (cont[6 * n + i] + D613 * k4[i] + D614 * k10[i] + D615 * k2[i] + D616 * k3[i]);
-                cont[7 * n + i] = h * (cont[7 * n + i] + D713 * k4[i] + D714 * k10[i] + D715 * k2[i] + D716 * k3[i]);
+                cont[4 * n + i] = h * MA(MA(MA(MA(cont[4 * n + i], D413, k4[i]), D414, k10[i]), D415, k2[i]), D416, k3[i]);
+                cont[5 * n + i] = h * MA(MA(MA(MA(cont[5 * n + i], D513, k4[i]), D514, k10[i]), D515, k2[i]), D516, k3[i]);
+                cont[6 * n + i] = h * MA(MA(MA(MA(cont[6 * n + i], D613, k4[i]), D614, k10[i]), D615, k2[i]), D616, k3[i]);
+                cont[7 * n + i] = h * MA(MA(MA(MA(cont[7 * n + i], D713, k4[i]), D714, k10[i]), D715, k2[i]), D716, k3[i]);
             }
 
             memcpy(k1, k4, (size_t)n * sizeof(double));
@@ -1109,9 +1184,9 @@ static int rk23_solve(orc_ode_fn f, const double *p, int n, double x0, const dou
 
     double x = x0;
     const double hmax = opt->has_max_step ? fabs(opt->max_step) : fabs(xend - x); /* rk23.rs:135 */
-    double *w = (double *)malloc((size_t)n * (7 + 4) * sizeof(double));
+    double *w = (double *)malloc((size_t)n * (7 + 4 + 1) * sizeof(double));
     double *y = w, *k1 = w + n, *k2 = w + 2 * n, *k3 = w + 3 * n, *k4 = w + 4 * n, *yt = w + 5 * n,
-           *ye = w + 6 * n, *cont = w + 7 * n;
+           *ye = w + 6 * n, *cont = w + 7 * n, *t_a = w + 11 * n;
     memcpy(y, y0, (size_t)n * sizeof(double));
     memset(k1, 0, (size_t)n * 10 * sizeof(double));
     uint64_t nfev = 0, nstep = 0, naccpt = 0, nrejct = 0, attempts = 0;
@@ -1133,21 +1208,22 @@ static int rk23_solve(orc_ode_fn f, const double *p, int n, double x0, const dou
         attempts += 1;
         if ((x + h - xend) * posneg > 0.0) h = xend - x;
 
-        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A21 * k1[i];
+        /* rk23.rs:201-234 */
+        for (int i = 0; i < n; i++) yt[i] = MA(y[i], h * A21, k1[i]);
         f(x + C2 * h, yt, k2, p);
-        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A32 * k2[i];
+        for (int i = 0; i < n; i++) yt[i] = MA(y[i], h * A32, k2[i]);
         f(x + C3 * h, yt, k3, p);
-        for (int i = 0; i < n; i++) yt[i] = y[i] + h * (B1 * k1[i] + B2 * k2[i] + B3 * k3[i]);
+        for (int i = 0; i < n; i++) yt[i] = MA(y[i], h, LC3(B1, k1[i], B2, k2[i], B3, k3[i]));
         f(x + h, yt, k4, p);
         nfev += 3;
 
-        for (int i = 0; i < n; i++) ye[i] = h * (E1 * k1[i] + E2 * k2[i] + E3 * k3[i] + E4 * k4[i]);
-        double err = 0.0;
+        for (int i = 0; i < n; i++) ye[i] = h * LC4(E1, k1[i], E2, k2[i], E3, k3[i], E4, k4[i]);
         for (int i = 0; i < n; i++) {
-            double tol = tol_at(atol, i) + tol_at(rtol, i) * fmax(fabs(yt[i]), fabs(y[i]));
+            double tol = MA(tol_at(atol, i), tol_at(rtol, i), fmax(fabs(yt[i]), fabs(y[i])));
             double q = ye[i] / tol;
-            err += q * q;
+            t_a[i] = q * q;
         }
+        double err = orc_sum(t_a, n);
         err = sqrt(err / (double)n);
 
         if (err <= 1.0) {
@@ -1162,8 +1238,8 @@ static int rk23_solve(orc_ode_fn f, const double *p, int n, double x0, const dou
             memcpy(cont, ye, (size_t)n * sizeof(double));
             for (int i = 0; i < n; i++) {
                 cont[n + i] = k1[i];
-                cont[2 * n + i] = D21 * k1[i] + D22 * k2[i] + D23 * k3[i] + D24 * k4[i];
-                cont[3 * n + i] = D31 * k1[i] + D32 * k2[i] + D33 * k3[i] + D34 * k4[i];
+                cont[2 * n + i] = LC4(D21, k1[i], D22, k2[i], D23, k3[i], D24, k4[i]);
+                cont[3 * n + i] = LC4(D31, k1[i], D32, k2[i], D33, k3[i], D34, k4[i]);
             }
             if (so_call(so, xold, x, y, cont, h)) { status = ORC_USER_INTERRUPT; break; }   /* rk23.rs:266-269 */
             memcpy(k1, k4, (size_t)n * sizeof(double)); /* ControlFlag::Continue arm, rk23.rs:281-284 */
@@ -1216,17 +1292,17 @@ static int rk4_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
         int last = 0;
         if ((x + 1.01 * h - xend) * rs_signum(h) > 0.0) last = 1;
 
-        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A21 * k1[i];
+        for (int i = 0; i < n; i++) yt[i] = MA(y[i], h * A21, k1[i]);
         f(x + C2 * h, yt, k2, p);
-        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A32 * k2[i];
+        for (int i = 0; i < n; i++) yt[i] = MA(y[i], h * A32, k2[i]);
         f(x + C3 * h, yt, k3, p);
-        for (int i = 0; i < n; i++) yt[i] = y[i] + h * A43 * k3[i];
+        for (int i = 0; i < n; i++) yt[i] = MA(y[i], h * A43, k3[i]);
         f(x + C4 * h, yt, k4, p);
 
         xold = x;
         memcpy(yt, y, (size_t)n * sizeof(double));
         x += h;
-        for (int i = 0; i < n; i++) y[i] += h * (B1 * k1[i] + B2 * k2[i] + B3 * k3[i] + B4 * k4[i]);
+        for (int i = 0; i < n; i++) y[i] = MA(y[i], h, LC4(B1, k1[i], B2, k2[i], B3, k3[i], B4, k4[i]));
         f(x, y, k1, p);
         nfev += 4;
         nstep += 1;
@@ -1325,13 +1401,13 @@ static void eval_jac(const orc_options *opt, orc_ode_fn f, const double *p, int 
 #define BDF_MAXO 5
 static double wrms_scaled(const double *v, const double *scale, int n)
 {   /* bdf.rs:659-667 */
-    double sum = 0.0;
+    double t[ORC_MAX_N];
     for (int i = 0; i < n; i++) {
         double denom = scale[i] == 0.0 ? 2.220446049250313e-16 : scale[i];
         double ratio = v[i] / denom;
-        sum += ratio * ratio;
+        t[i] = ratio * ratio;
     }
-    return sqrt(sum / (double)n);
+    return sqrt(orc_sum(t, n) / (double)n);
 }
 static void compute_r(int order, double factor, double r[6][6])
 {   /* bdf.rs:694-713 */

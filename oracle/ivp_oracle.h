@@ -190,6 +190,7 @@ int64_t orc_batch_solve(int rhs_id, size_t B, const double *y0, const double *pa
  * strict-FP GPU path comparable BIT FOR BIT (see tests/test_parity_bitexact.py). */
 double orc_detpow(double x, double e);
 int orc_uses_detpow(void);
+int orc_uses_fma(void);      /* 1 in liboracle_fma.so: the multiply-add sites are fused (the kernels' FMA arithmetic mode) */
 
 #ifdef __cplusplus
 }

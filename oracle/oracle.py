@@ -71,21 +71,26 @@ _ODE_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_dou
 _libs = {}
 
 
+_LIBS = ("liboracle.so", "liboracle_detpow.so", "liboracle_fma.so")
+
+
 def build(force: bool = False) -> None:
-    """Compile the oracle's two shared objects (gcc only)."""
-    need = force or not all(os.path.exists(os.path.join(_HERE, f))
-                            for f in ("liboracle.so", "liboracle_detpow.so"))
+    """Compile the oracle's three shared objects (gcc only)."""
+    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in _LIBS)
     if not need:
         src = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ivp_oracle.c", "ivp_oracle.h", "Makefile"))
-        need = any(os.path.getmtime(os.path.join(_HERE, f)) < src for f in ("liboracle.so", "liboracle_detpow.so"))
+        need = any(os.path.getmtime(os.path.join(_HERE, f)) < src for f in _LIBS)
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
 
 
-def lib(detpow: bool = False):
-    key = bool(detpow)
+def lib(detpow: bool = False, fma: bool = False):
+    """liboracle.so (libm pow: the faithful restatement), liboracle_detpow.so (portable pow: bit-comparable with the
+    kernels' strict mode) or liboracle_fma.so (portable pow + the fused multiply-add sites of the kernels' FMA mode)."""
+    detpow = bool(detpow or fma)
+    key = (detpow, bool(fma))
     if key not in _libs:
-        path = os.path.join(_HERE, "liboracle_detpow.so" if detpow else "liboracle.so")
+        path = os.path.join(_HERE, "liboracle_fma.so" if fma else ("liboracle_detpow.so" if detpow else "liboracle.so"))
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
@@ -112,7 +117,8 @@ def lib(detpow: bool = False):
             C.POINTER(_Options), C.c_int,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        assert L.orc_uses_detpow() == int(detpow)
+        L.orc_uses_fma.restype = C.c_int
+        assert L.orc_uses_detpow() == int(detpow) and L.orc_uses_fma() == int(bool(fma))
         _libs[key] = L
     return _libs[key]
 
@@ -225,10 +231,10 @@ class OracleSolution:
 
 
 def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Sequence[float] = (),
-              detpow: bool = False, events=None, n_events: int = 0, jac=None, **options) -> OracleSolution:
+              detpow: bool = False, fma: bool = False, events=None, n_events: int = 0, jac=None, **options) -> OracleSolution:
     """One reference-style ``solve_ivp`` call.  ``fun`` is a built-in RHS name (see ``RHS``) or a
     Python callable ``f(x, y, p) -> dydx`` (slow; small cases only)."""
-    L = lib(detpow)
+    L = lib(detpow, fma)
     y0a = np.ascontiguousarray(y0, dtype=np.float64)
     pa = np.ascontiguousarray(params if len(params) else [0.0], dtype=np.float64)
     n = y0a.size
@@ -298,9 +304,9 @@ def solve_ivp(fun, x0: float, xend: float, y0: Sequence[float], *, params: Seque
 
 
 def solve_batch(rhs: str, y0: np.ndarray, params: Optional[np.ndarray], t0, t1, *, threads: int = 1,
-                detpow: bool = False, **options) -> dict:
+                detpow: bool = False, fma: bool = False, **options) -> dict:
     """B back-to-back reference-style solves. ``y0`` is SoA ``[n, B]``, ``params`` ``[p, B]``."""
-    L = lib(detpow)
+    L = lib(detpow, fma)
     rid = RHS[rhs]
     n, npar = RHS_DIMS[rid]
     y0 = np.ascontiguousarray(y0, dtype=np.float64)

@@ -227,7 +227,7 @@ EVENT_CASES += [
 ]
 
 
-def check_events_against_oracle(solve, case, exact=True):
+def check_events_against_oracle(solve, case, exact=True, fma=False):
     """Events, outputs and statistics of a 3-trajectory batch vs one oracle solve_ivp call per trajectory."""
     from oracle import oracle as O
     name, rhs, t0, t1, y0, params, kw = case
@@ -241,7 +241,7 @@ def check_events_against_oracle(solve, case, exact=True):
     g = solve(rhs, y0a, par, t0, t1, **gkw)
     eq = np.array_equal if exact else (lambda a, b: np.allclose(a, b, rtol=1e-9, atol=1e-11))
     for b in range(3):
-        s = O.solve_ivp(rhs, t0, t1, y0a[:, b], params=params, detpow=True, **kw)
+        s = O.solve_ivp(rhs, t0, t1, y0a[:, b], params=params, detpow=True, fma=fma, **kw)
         for i in range(len(s.t_events)):
             m = int(g["n_ev"][i, b])
             assert m == len(s.t_events[i]), (name, b, i)

@@ -5,7 +5,8 @@
 // kernel logic (chunk boundaries, state save/restore, flag packing, DefaultSolOut on the device)
 // bit for bit against the CPU oracle before any GPU minute is spent.  It is NOT part of the
 // product: nothing in ivp_amd/ or libivp_hip.so links or loads it, and the product has no CPU path.
-// Compiled with g++ -ffp-contract=off (strict) or -ffp-contract=fast -DIVP_FAST=1 (fast).
+// Compiled with g++ -ffp-contract=off, once as is (strict) and once with -DIVP_FAST=1 (the FMA arithmetic mode:
+// explicit fma() at the IVP_MA sites).
 #include <cstdint>
 #include <cstring>
 #include <vector>
