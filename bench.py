@@ -92,6 +92,11 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary fast-FP-mode / pipelined measurements")
+    ap.add_argument("--output", choices=["end", "t_eval", "csr_log", "dense", "events", "all"], default="end",
+                    help="N = 1: measure the device DefaultSolOut output modes of the workload instead of the end-state "
+                         "headline (t_eval: 128 samples per trajectory; csr_log: every accepted step, count + fill passes; "
+                         "dense: step log + dense-output segments; events: a hiprtc CR3BP with the y = 0 crossing event); "
+                         "the default run carries t_eval and csr_log as the secondary object `outputs`")
     args = ap.parse_args()
 
     # RCCL prints a version banner on stdout while the process group comes up; keep stdout clean for the ONE JSON
@@ -320,6 +325,11 @@ def main():
             res["fma_fp_mode"] = fma_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, barrier_sync)
         if not args.no_fast and single and args.workload == "c2":
             res["pipelined"] = pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp, args)
+        if single and args.workload in ("c2", "c3") and (args.output != "end" or not args.no_fast):
+            modes = ["t_eval", "csr_log"] if args.output == "end" else (["t_eval", "csr_log", "dense", "events"] if args.output == "all" else [args.output])
+            if args.workload != "c2":
+                modes = [m for m in modes if m != "events"]
+            res["outputs"] = output_mode_numbers(ivp_amd, prob, wl, t0, t1, y0d, pd, fp, ctx, args, modes, ms_per_step)
         if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
             res["accuracy"] = accuracy_vs_truth(ivp_amd, prob, mk_opts(0), ctx, dev)
@@ -350,6 +360,109 @@ def fma_mode_numbers(ivp_amd, prob, t0, t1, y0d, pd, ctx, args, sync_all):
     acc = float(out.naccpt.sum().item())
     return {"value": acc * k / dt, "unit": "steps/s", "ms_per_step": dt / k * 1e3, "steps": k, "this_rank_only": True,
             "fp_mode": "fma", "oracle": "oracle/liboracle_fma.so (bit-exact, tests/test_fma_mode.py)"}
+
+
+CR3BP_EVENT_SRC = r"""
+__device__ void ode(double t, const double* s, double* d, const double* p)
+{
+    const double mu = p[0];
+    const double x = s[0], y = s[1], z = s[2], vx = s[3], vy = s[4], vz = s[5];
+    const double a = x + mu, b = x - 1.0 + mu;
+    const double r1 = sqrt(a * a + y * y + z * z), r2 = sqrt(b * b + y * y + z * z);
+    const double r13 = r1 * r1 * r1, r23 = r2 * r2 * r2;
+    d[0] = vx; d[1] = vy; d[2] = vz;
+    d[3] = x + 2.0 * vy - (1.0 - mu) * (x + mu) / r13 - mu * (x - 1.0 + mu) / r23;
+    d[4] = y - 2.0 * vx - (1.0 - mu) * y / r13 - mu * y / r23;
+    d[5] = -(1.0 - mu) * z / r13 - mu * z / r23;
+}
+__device__ void events(double t, const double* s, double* g, const double* p) { g[0] = s[1]; }   // crossings of the x axis
+"""
+
+
+def output_mode_numbers(ivp_amd, prob, wl, t0, t1, y0d, pd, fp, ctx, args, modes, end_state_ms):
+    """The device DefaultSolOut (src/solve/solout.rs:127-431) at the workload's full size: wall time per complete solve,
+    bytes the mode writes (records x record size: algorithmic, what the reference pushes into its Vecs) and the HBM rate
+    that corresponds to -- against 8 TB/s.  Buffers are allocated once and reused (`out=`); every solve is complete."""
+    import torch
+    from ivp_amd import workloads as W
+    n = prob.n
+    B = int(y0d.shape[1])
+    base = dict(method=wl["method"], rtol=wl["rtol"], atol=wl["atol"], fp_mode=fp, chunk_attempts=args.chunk)
+    k = max(3, min(10, args.steps // 2))
+    t_hi = float(t1.max()) if np.ndim(t1) else float(t1)
+    t1d = torch.as_tensor(t1, device=y0d.device) if np.ndim(t1) else t1
+
+    def timed(fn):
+        out = fn(None)
+        out = fn(out)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(k):
+            out = fn(out)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / k * 1e3, out
+
+    res = {"solves_timed": k, "end_state_ms_per_solve": end_state_ms, "hbm_peak_GBs": HBM_PEAK_GBS,
+           "note": "bytes = records x record size (algorithmic); GB/s = bytes / wall time of the whole solve, integration included"}
+    for mode in modes:
+        try:
+            if mode == "t_eval":
+                ne = 128
+                te = np.linspace(0.0, t_hi, ne)
+                o = ivp_amd.Options(t_eval=te, **base)
+                ms, out = timed(lambda prev: ivp_amd.solve_ivp_batch(prob, t0, t1d, y0d, pd, o, ctx, prev))
+                rec = int(out.n_filled.sum().item())
+                byts = rec * (n * 8 + 4)
+                res[mode] = {"samples_per_trajectory": ne, "records": rec}
+            elif mode == "csr_log":
+                o = ivp_amd.Options(**base)
+                torch.cuda.synchronize()
+                ivp_amd.solve_ivp_batch_logged(prob, t0, t1d, y0d, pd, o, ctx)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(k):
+                    out = ivp_amd.solve_ivp_batch_logged(prob, t0, t1d, y0d, pd, o, ctx)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t) / k * 1e3
+                rec = int(out.t_log.shape[0])
+                byts = rec * (n + 1) * 8
+                res[mode] = {"records": rec, "passes": "counting solve + exclusive scan + filling solve (allocation of the log included)"}
+            elif mode == "dense":
+                ml = int(out_max_log(ivp_amd, prob, t0, t1d, y0d, pd, base, ctx))
+                o = ivp_amd.Options(dense_output=True, max_log=ml, **base)
+                ms, out = timed(lambda prev: ivp_amd.solve_ivp_batch(prob, t0, t1d, y0d, pd, o, ctx, prev))
+                nseg, nlog = int(out.n_seg.sum().item()), int(out.n_log.sum().item())
+                nc = int(out.seg_cont.shape[1])
+                byts = nseg * (nc + 2) * 8 + nlog * (n + 1) * 8
+                res[mode] = {"max_log": ml, "segments": nseg, "log_records": nlog, "coefficients_per_segment": nc,
+                             "buffer_GB": (out.seg_cont.numel() + out.y_log.numel()) * 8 / 1e9}
+                del out
+                torch.cuda.empty_cache()
+            elif mode == "events":
+                f = ivp_amd.DeviceIVP(CR3BP_EVENT_SRC, n=6, params=(W.ARENSTORF_MU,), ctx=ctx, events=[ivp_amd.EventConfig()])
+                o = ivp_amd.Options(max_events=16, **base)
+                ms, out = timed(lambda prev: ivp_amd.solve_ivp_batch(f, t0, t1d, y0d, pd, o, ctx, prev))
+                o0 = ivp_amd.Options(**base)
+                f0 = ivp_amd.DeviceIVP(CR3BP_EVENT_SRC.split("__device__ void events")[0], n=6, params=(W.ARENSTORF_MU,), ctx=ctx)
+                ms0, _ = timed(lambda prev: ivp_amd.solve_ivp_batch(f0, t0, t1d, y0d, pd, o0, ctx, prev))
+                rec = int(out.n_event_hits.sum().item())
+                byts = rec * (n + 1) * 8
+                res[mode] = {"event": "g = y (x-axis crossings), direction All, not terminal; hiprtc right-hand side", "records": rec,
+                             "same_rhs_without_events_ms_per_solve": ms0, "max_events": 16}
+            else:
+                continue
+            res[mode].update({"ms_per_solve": ms, "bytes_written": byts, "achieved_GBs": byts / (ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "hbm_floor_ms": byts / (HBM_PEAK_GBS * 1e9) * 1e3})
+        except Exception as e:   # noqa: BLE001
+            res[mode] = {"error": repr(e)}
+    return res
+
+
+def out_max_log(ivp_amd, prob, t0, t1d, y0d, pd, base, ctx):
+    """Longest accepted-step log of the batch (+ the initial record): the dense [max_log, ..., B] buffers are sized for it."""
+    cnt = ivp_amd.solve_ivp_batch(prob, t0, t1d, y0d, pd, ivp_amd.Options(count_log=True, **base), ctx)
+    return int(cnt.n_log.max().item()) + 1
 
 
 def pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp_mode, args, streams=4):

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ivp_jit.h"
@@ -81,6 +82,10 @@ struct DevBuf {
 
 struct ivp_ctx {
     int device = 0;
+    // the part's geometry (hipDeviceProp_t): the launch policy sizes everything from it.  CDNA compute units have
+    // 4 SIMDs and wave64; multiProcessorCount is 256 on MI355X, 304 on MI300X, fewer on a partitioned device.
+    uint32_t cus = 256, simds = 1024;
+    uint32_t one_wave_per_simd() const { return simds * (uint32_t)IVP_WAVE; }   // lanes that fill every SIMD with one wave
     std::string err;
     // scratch (device)
     DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval, tolvec, zero_off;
@@ -195,13 +200,10 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     return IVP_OK;
 }
 
-// lanes (8 per trajectory) up to which the lane-cooperative kernels take over: two waves per SIMD
-constexpr size_t kCoopCapLanesDefault = 2u * 256u * 4u * 64u;
-
 // Launch-policy knobs.  The defaults are the measured optimum for the BASELINE configs on MI355X; the environment
 // overrides exist for tuning runs (tools/tune_policy.py) and are read once per process.
 struct Tune {
-    size_t coop_cap_lanes = kCoopCapLanesDefault;
+    size_t coop_cap_lanes = 0;       // lanes (8 per trajectory) up to which the lane-cooperative kernels take over; 0 = two waves per SIMD of the device
     uint32_t bulk_chunk = 64;        // attempts per bulk launch
     int launches_per_poll = 3;       // bulk launches between two host polls
     int bdf_lpw = 0;                 // trajectories per wave of the BDF chunk launches: 0 = auto (spread the active set over the SIMDs)
@@ -214,7 +216,14 @@ struct Tune {
     }
 };
 const Tune &tune() { static const Tune t; return t; }
-#define kCoopCapLanes (tune().coop_cap_lanes)
+// lanes (8 per trajectory) up to which the lane-cooperative kernels take over: two cooperative waves per SIMD
+size_t coop_cap_lanes(const ivp_ctx *ctx) { return tune().coop_cap_lanes ? tune().coop_cap_lanes : 2u * (size_t)ctx->one_wave_per_simd(); }
+// restores the caller's current HIP device when a multi-device entry point returns
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 
 hipEvent_t pend_event(ivp_ctx *ctx)
 {
@@ -263,7 +272,7 @@ int enqueue_round(ivp_ctx *ctx)
 {
     ivp_ctx::Pending &P = ctx->pend;
     hipStream_t s = P.stream;
-    const uint32_t kOneWavePerSimd = 256u * 4u * 64u;
+    const uint32_t kOneWavePerSimd = ctx->one_wave_per_simd();
     uint32_t *counts = (uint32_t *)ctx->counts.p;
     const uint32_t lanes = P.lanes;
     const bool profile = P.profile != 0;
@@ -279,7 +288,7 @@ int enqueue_round(ivp_ctx *ctx)
                            (P.variant == 2 || (P.variant == 0 && (size_t)lanes <= 2 * (size_t)kOneWavePerSimd));
     // eight lanes per trajectory pay off once the cooperative waves fit two per SIMD, and only for systems
     // with enough components to share out (measured: break-even at n = 3, a loss at n = 2)
-    const size_t coop_cap = kCoopCapLanes;
+    const size_t coop_cap = coop_cap_lanes(ctx);
     const bool use_coop = P.coop_ok && (P.variant == 3 ||
                                         (P.variant == 0 && P.adaptive && P.n >= 4 && (size_t)lanes * 8u <= coop_cap));
     // Long chunks (one launch per poll) once compaction cannot help any more: in the cooperative kernels, and for
@@ -300,7 +309,7 @@ int enqueue_round(ivp_ctx *ctx)
     // two, 9.6 with eight: the fewer lanes, the fewer phases a wave runs on behalf of some other lane).
     uint32_t lpw = 0;
     if (P.method == IVP_BDF && !P.group) {   // built-in and hiprtc right-hand sides alike
-        const uint32_t cus = 256u;
+        const uint32_t cus = ctx->cus;
         const uint32_t want = tune().bdf_lpw > 0 ? (uint32_t)tune().bdf_lpw : std::max(1u, (lanes + cus - 1u) / cus);
         lpw = std::min(64u, want);
     }
@@ -371,7 +380,7 @@ int finish_round(ivp_ctx *ctx, int *done)
     if (P.spec) {
         P.spec = false;
         const uint32_t left_by_bulk = ctx->pinned[2];
-        if ((size_t)left_by_bulk * 8u > kCoopCapLanes) {   // the speculative launch declined: nothing moved, its slot is reused
+        if ((size_t)left_by_bulk * 8u > coop_cap_lanes(ctx)) {   // the speculative launch declined: nothing moved, its slot is reused
             P.c -= 1;
             P.lanes = left_by_bulk;
             if (!P.step_is_coop.empty()) P.step_is_coop.back() = 0;   // its few microseconds count as plain stepping time
@@ -446,6 +455,11 @@ int ivp_ctx_create(ivp_ctx_t **out, int device)
     if (hipSetDevice(device) != hipSuccess) return IVP_ERR_HIP;
     ivp_ctx *c = new ivp_ctx();
     c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        c->cus = (uint32_t)prop.multiProcessorCount;
+        c->simds = c->cus * 4u;   // CDNA: four SIMDs per compute unit
+    }
     if (hipHostMalloc((void **)&c->pinned, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return IVP_ERR_HIP;
@@ -873,13 +887,17 @@ int drive_all(ivp_ctx_t *const *ctxs, const char *live, int n)
     int rc_first = IVP_OK, pending = 0;
     for (int i = 0; i < n; ++i) { done[i] = live[i] ? 0 : 1; pending += live[i] ? 1 : 0; }
     while (pending) {
+        bool progressed = false;
         for (int i = 0; i < n; ++i) {
             if (done[i]) continue;
             int d = 0;
+            const uint64_t before = ctxs[i]->pend.c;
             const int rc = ivp_batch_poll(ctxs[i], &d);
             if (rc != IVP_OK) { if (rc_first == IVP_OK) rc_first = rc; d = 1; }
             if (d) { done[i] = 1; --pending; }
+            progressed = progressed || d || ctxs[i]->pend.c != before;
         }
+        if (!progressed) std::this_thread::yield();   // every shard's round is still in flight: do not spin on the event queries
     }
     return rc_first;
 }
@@ -892,6 +910,7 @@ int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_probl
                           int32_t gather_device, ivp_batch_result_t *gathered)
 {
     if (!shards || n_shards <= 0 || n_shards > 64) return IVP_ERR_BAD_ARGUMENT;
+    DeviceGuard restore_device;   // hipSetDevice below must not leak into the caller (its allocations / launches follow the current device)
     ivp_ctx_t *c0 = nullptr;
     for (int i = 0; i < n_shards; ++i) {
         if (!shards[i].ctx) return IVP_ERR_BAD_ARGUMENT;
@@ -955,6 +974,7 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
                                const ivp_options_t *opt, ivp_batch_result_t *out)
 {
     if (!ctxs || n_ctx <= 0 || n_ctx > 64 || !ctxs[0]) return IVP_ERR_BAD_ARGUMENT;
+    DeviceGuard restore_device;
     ivp_ctx_t *c0 = ctxs[0];
     for (int i = 0; i < n_ctx; ++i) {
         if (!ctxs[i]) return IVP_ERR_BAD_ARGUMENT;

@@ -5,6 +5,9 @@
 #ifndef IVP_MIN_WAVES
 #define IVP_MIN_WAVES 2
 #endif
+#ifndef IVP_BDF_MIN_WAVES
+#define IVP_BDF_MIN_WAVES 1
+#endif
 
 namespace IVP_NS {
 
@@ -72,7 +75,7 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 // CTL = true: controller fields from IvpKArgs.ctl_* (a direct method call with non-default struct fields);
 // CTL = false keeps them compile-time constants, which is the path solve_ivp() takes.
 template <int M, class R, bool FULL, bool CTL = false>
-__global__ __launch_bounds__(IVP_WAVE, (M == M_BDF || (M == M_DOP853 && FULL && R::N >= 5)) ? 1 : IVP_MIN_WAVES) void chunk_kernel_t(const IvpKArgs a)
+__global__ __launch_bounds__(IVP_WAVE, (M == M_BDF) ? IVP_BDF_MIN_WAVES : ((M == M_DOP853 && FULL && R::N >= 5) ? 1 : IVP_MIN_WAVES)) void chunk_kernel_t(const IvpKArgs a)
 {
     chunk_kernel_body<M, R, FULL, CTL>(a);
 }

@@ -163,7 +163,7 @@ def test_fma_c2_hand_over_to_the_cooperative_tail_is_invisible():
     y0, p, t0, t1 = W.cr3bp_batch(100000)
     y0, p = np.ascontiguousarray(y0[:, 40000:60000]), np.ascontiguousarray(p[:, 40000:60000])
     o = dict(method="DOPRI5", rtol=1e-6, atol=1e-9)
-    auto = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, fast=True, **o)
+    auto = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, fast=True, profile=1, **o)
     lean = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, fast=True, variant=1, **o)
     coop = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, fast=True, variant=3, **o)
     assert auto["stats"]["coop_launches"] > 0      # the tail really ran in the cooperative kernel

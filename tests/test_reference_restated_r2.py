@@ -157,6 +157,76 @@ def test_detpow_substitution_statistics_on_the_full_c2_horizon():
     assert np.median(err_det) < 1.5 * np.median(err_libm) and err_det.max() < 10 * err_libm.max()   # BASELINE: within 10x of the CPU reference
 
 
+def test_detpow_substitution_statistics_on_c3_dop853():
+    """The same question for BASELINE C3 (Van der Pol, DOP853, rtol 1e-8; dop853.rs:432-434 calls powf once or twice
+    per attempt): libm-pow oracle vs portable-pow oracle (= the GPU's strict bits) on the first 200 000 trajectories of
+    the 1M batch, end-state difference against the integration error measured on the committed SciPy truth subset."""
+    import json
+    import os
+    from ivp_amd import workloads as W
+    y0, p, t0, t1 = W.vdp_batch(1_000_000)
+    B = 200_000
+    y0, p, t1 = np.ascontiguousarray(y0[:, :B]), np.ascontiguousarray(p[:, :B]), t1[:B]
+    kw = dict(method="DOP853", rtol=1e-8, atol=1e-10, threads=8)
+    a = O.solve_batch("vdp", y0, p, t0, t1, detpow=False, **kw)
+    b = O.solve_batch("vdp", y0, p, t0, t1, detpow=True, **kw)
+    same_steps = float(np.mean((a["naccpt"] == b["naccpt"]) & (a["nrejct"] == b["nrejct"])))
+    rel_steps = abs(float(a["naccpt"].sum()) - float(b["naccpt"].sum())) / float(a["naccpt"].sum())
+    delta = np.abs(a["y_end"] - b["y_end"]).max(axis=0)
+    truth = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scipy_truth.json")))["truth"]["vdp"]
+    n = int(truth["subset"])
+    ref = np.asarray(truth["y_end"]).T
+    ty0, tp, _, tt1 = W.vdp_batch(int(truth["B"]), seed=int(truth["seed"]))      # the batch the truth subset was drawn from
+    ta = O.solve_batch("vdp", ty0[:, :n], tp[:, :n], t0, tt1[:n], detpow=False, **kw)
+    tb = O.solve_batch("vdp", ty0[:, :n], tp[:, :n], t0, tt1[:n], detpow=True, **kw)
+    err_libm = np.abs(ta["y_end"] - ref).max(axis=0)
+    err_det = np.abs(tb["y_end"] - ref).max(axis=0)
+    print(f"C3: identical (naccpt, nrejct): {same_steps:.5f}; total accepted steps differ by {rel_steps:.2e}; "
+          f"median |dy| {np.median(delta):.2e}, max |dy| {delta.max():.2e}; "
+          f"truth error median libm {np.median(err_libm):.2e} detpow {np.median(err_det):.2e}, max libm {err_libm.max():.2e} detpow {err_det.max():.2e}")
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    assert same_steps > 0.99 and rel_steps < 1e-4
+    assert np.median(delta) < 1e-2 * np.median(err_libm)          # invisible next to the method's own error
+    assert np.median(err_det) < 1.5 * np.median(err_libm) and err_det.max() < 10 * err_libm.max()
+
+
+def test_detpow_substitution_statistics_on_c5_bdf():
+    """BASELINE C5 (10k stiff Van der Pol, BDF): here the portable power function sits inside the order selection and
+    the rejection factor (bdf.rs:482, 568-577: err^(-1/(order+k))) and the Newton contraction estimate uses products
+    instead of powf (bdf.rs:408, orc_pow_small_int).  Quantified on the whole batch: step / Jacobian / LU counts, the
+    ORDER HISTORIES of a sample (from the dense-output segments, whose 7th slot is the order), end-state difference
+    against the distance to the SciPy Radau @ 1e-10 truth."""
+    import json
+    import os
+    from ivp_amd import workloads as W
+    y0, p, t0, t1 = W.vdp_stiff_batch(10_000)
+    kw = dict(method="BDF", rtol=1e-4, atol=1e-6, threads=8)
+    a = O.solve_batch("vdp", y0, p, t0, t1, detpow=False, **kw)
+    b = O.solve_batch("vdp", y0, p, t0, t1, detpow=True, **kw)
+    assert np.array_equal(a["status"], b["status"]) or np.mean(a["status"] != b["status"]) < 2e-3
+    same = {k: float(np.mean(a[k] == b[k])) for k in ("naccpt", "nrejct", "njev", "nlu", "nfev")}
+    rel_steps = abs(float(a["naccpt"].sum()) - float(b["naccpt"].sum())) / float(a["naccpt"].sum())
+    delta = np.abs(a["y_end"] - b["y_end"]).max(axis=0)
+    truth = np.asarray(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scipy_stiff_truth.json")))["truth"]["vdp_mu1000_t3000"])
+    e_libm = float(np.abs(a["y_end"][:, 0] - truth).max())
+    e_det = float(np.abs(b["y_end"][:, 0] - truth).max())
+    # order histories of 40 trajectories
+    same_hist, n_hist = 0, 0
+    for j in range(0, 10_000, 250):
+        sa = O.solve_ivp("vdp", t0, t1, y0[:, j], params=p[:, j], detpow=False, dense_output=True, method="BDF", rtol=1e-4, atol=1e-6)
+        sb = O.solve_ivp("vdp", t0, t1, y0[:, j], params=p[:, j], detpow=True, dense_output=True, method="BDF", rtol=1e-4, atol=1e-6)
+        oa, ob = np.asarray(sa.seg_cont)[:, 6], np.asarray(sb.seg_cont)[:, 6]
+        n_hist += 1
+        same_hist += int(oa.shape == ob.shape and np.array_equal(oa, ob))
+    print(f"C5: identical counts {same}; total accepted steps differ by {rel_steps:.2e}; median |dy| {np.median(delta):.2e}, "
+          f"max |dy| {delta.max():.2e}; trajectory 0 vs Radau truth: libm {e_libm:.2e} detpow {e_det:.2e}; "
+          f"identical order histories {same_hist}/{n_hist}")
+    assert rel_steps < 2e-3 and same["naccpt"] > 0.5
+    assert np.median(delta) < 1e-4                                  # far below the rtol = 1e-4 the run asks for
+    assert e_det < 1e-2 and e_libm < 1e-2
+    assert same_hist >= n_hist // 2
+
+
 # ---- trait IVP::jac override (src/ivp.rs:67-107) ---------------------------------------------------------------------
 def _rob_jac(t, s, p):
     y, z = s[1], s[2]
