@@ -316,6 +316,16 @@ def main():
         if weak is not None:
             res["weak"] = weak
         if world > 1:
+            # the builder's own single-GPU prediction of this curve, on the record next to the measured number
+            # (every rank's shard timed alone on one MI355X; max over ranks = what the job takes, gather excluded)
+            try:
+                pred = json.load(open(os.path.join(ROOT, "profiles", "r02_strong_scaling_prediction.json")))
+                res["strong_scaling_prediction"] = {"source": "profiles/r02_strong_scaling_prediction.json (tools/strong_scaling_prediction.py, strict mode, "
+                                                              "one MI355X, gather excluded)", "prediction": pred,
+                                                    "baseline_target": ">= 6x at 8 GPUs (BASELINE.json); predicted ~1.8x for ONE 100k batch: the slowest "
+                                                                       "trajectory's 702 sequential attempts do not shrink with the shard"}
+            except Exception:   # noqa: BLE001
+                pass
             res["latency_floor_note"] = ("strong scaling of one C2 batch is bounded by its slowest trajectory: 702 sequential "
                                          "step attempts (192 in the bulk kernel + 510 in the lane-cooperative tail kernel) "
                                          "do not shrink with the shard -- see DESIGN.md section 7")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IVP_HIP_ABI_VERSION 3
+#define IVP_HIP_ABI_VERSION 4
 
 /* Method: same order as `enum Method`, src/solve/options.rs:14-27. The explicit RK methods (RK23, DOPRI5,
  * DOP853, the fixed-step RK4) and the variable-order implicit BDF are on the accelerated path; RADAU returns
@@ -65,7 +65,7 @@ typedef enum {
     IVP_ERR_INVALID_STEP_SIZE = -5,       /* ConfigError::InvalidStepSize (RK4: first_step zero / wrong sign, rk4.rs:81-87) */
     IVP_ERR_INVALID_SCALE_FACTORS = -6,   /* ConfigError::InvalidScaleFactors  */
     IVP_ERR_BAD_ARGUMENT = -100,          /* NULL pointer, unknown rhs id, n mismatch ...            */
-    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU (any problem), or BDF for a large-n problem        */
+    IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU: not on the accelerated path (every other method is, for every n) */
     IVP_ERR_NO_DEVICE = -102,             /* no HIP device: there is deliberately no CPU fallback    */
     IVP_ERR_HIP = -103,                   /* a HIP runtime call failed; see ivp_last_error_string()  */
     IVP_ERR_JIT = -104                    /* hiprtc compilation of a user RHS failed                 */
@@ -96,9 +96,11 @@ typedef enum {
     /* Large state dimensions (8 < n <= 512): one 64-lane wavefront integrates one trajectory, the state is
      * distributed over its lanes and the error norm is a wavefront reduction.  RK23 / DOPRI5 / DOP853 / RK4 with
      * every output mode (t_eval, step log, dense output), events (hiprtc problems) and scalar or vector tolerances;
-     * no BDF. */
+     * BDF with the n x n matrices J and LU = (I - cJ) per trajectory (in LDS for n <= 128, see ivp_options_t.variant). */
     IVP_RHS_LINEAR_DECAY_100 = 100, /* y' = -y                            n=100 benches/benchmark.py:40-42,139-148 */
     IVP_RHS_HEAT1D_256 = 101,       /* y_i' = k (y_{i-1} - 2 y_i + y_{i+1}), p={k}  n=256 (method of lines)  */
+    IVP_RHS_DENSE_64 = 102,         /* y' = A y, A dense 64 x 64: a_ii = -k (4 + i mod 5), a_ij = ((i j + i + 2 j) mod 17 - 8) / 256,
+                                       p={k}: a FULL Jacobian for the per-trajectory LU of BDF (n=64) */
     IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */
 } ivp_rhs_id_t;
 
@@ -137,7 +139,8 @@ typedef struct {
     int32_t rtol_vec_len;   /* must equal n when rtol_vec != NULL */
     int32_t atol_vec_len;
     uint64_t max_steps;     /* Options.max_steps; 0 = None = unlimited (src/solve/solve_ivp.rs:218) */
-    const double *t_eval;   /* Options.t_eval: shared output grid, host pointer, or NULL = None */
+    const double *t_eval;   /* Options.t_eval: output grid shared by the batch (or B concatenated grids, see
+                               t_eval_offsets below), host pointer, or NULL = None */
     int64_t n_eval;         /* number of t_eval points (ignored when t_eval == NULL) */
     int32_t has_first_step; /* Options.first_step is Some(..) */
     double first_step;
@@ -145,7 +148,7 @@ typedef struct {
     double max_step;
     int32_t dense_output;   /* Options.dense_output: record per-step interpolants (needs max_log > 0) */
     /* event_config(i) of the problem (src/solve/event.rs:5-77), for problems whose functor defines events */
-    int32_t ev_direction[4];  /* Direction: 0 All, > 0 Positive, < 0 Negative                     */
+    int32_t ev_direction[4];  /* Direction: 0 All, > 0 Positive, < 0 Negative  (up to 4 events; more: *_vec below) */
     uint32_t ev_terminal[4];  /* terminal_count: 0 = None, k = interrupt at the k-th occurrence   */
     uint32_t max_events;      /* capacity of t_events / y_events per event and trajectory          */
     int32_t has_min_step;   /* Options.min_step is Some(..) (read by BDF only, src/solve/solve_ivp.rs:271) */
@@ -158,7 +161,8 @@ typedef struct {
     int32_t variant;        /* stepping-kernel variant: 0 = auto, 1 = lean registers, 2 = coefficients resident,
                                3 = lane-cooperative (eight lanes per trajectory: DOPRI5 / DOP853, every output mode,
                                problems with events, built-in and hiprtc systems with n <= 8; otherwise as 0).
-                               Strict-mode results do not depend on the variant. */
+                               Large-n BDF (8 < n <= 128, built-in problems): 0 / 2 = factors of (I - cJ) resident in
+                               LDS, 1 = in global memory.  Results do not depend on the variant in either arithmetic mode. */
     int32_t profile;        /* 1: time every kernel launch with HIP events (see ivp_run_stats_t);
                                2: additionally sum naccpt / attempts over the batch on the host */
     /* ---- direct per-method call: `DOPRI5 {..}.solve()`, `DOP853 {..}.solve()`, `RK23 {..}.solve()` ----
@@ -177,6 +181,22 @@ typedef struct {
     uint64_t stiff_test;    /* default 1000                                      */
     int32_t count_log;      /* 1: run DefaultSolOut's accepted-step recording without storing anything: out->n_log
                                receives the number of records per trajectory (first pass of the CSR log) */
+    /* ---- ABI v4 ---- */
+    /* Per-trajectory output grids.  Every reference solve_ivp() call has its own Options.t_eval
+     * (src/solve/options.rs:75-123); t_eval_offsets != NULL (host pointer, [B + 1], offsets[0] = 0, non-decreasing,
+     * offsets[B] = n_eval) makes t_eval the concatenation of B grids: trajectory b samples
+     * t_eval[offsets[b] .. offsets[b+1]).  The outputs are then time-major CSR records like Solution.y
+     * (Vec<Vec<f64>>): with e = 1 for problems with event functions (a terminal event appends its own sample,
+     * src/solve/solout.rs:316-319) and 0 otherwise, the k-th sample of trajectory b is record
+     * q = offsets[b] + b * e + k:  y_eval[q * n + c], eval_idx[q] (index into b's OWN grid, -1 for the terminal sample);
+     * y_eval holds (n_eval + B * e) * n doubles, eval_idx n_eval + B * e entries, n_filled[b] counts b's samples.
+     * Single-context entry points only. */
+    const uint64_t *t_eval_offsets;
+    /* event_config(i) for problems with MORE than 4 event functions (trait IVP::n_events is unbounded,
+     * src/ivp.rs:31-52): host arrays of n_event_cfg entries that replace ev_direction / ev_terminal above */
+    const int32_t *ev_direction_vec;
+    const uint32_t *ev_terminal_vec;
+    int32_t n_event_cfg;
 } ivp_options_t;
 
 /* Per-trajectory results: `struct Solution` (src/solve/solution.rs:7-20) + IntegrationResult.h
@@ -316,6 +336,12 @@ int ivp_batch_wait(ivp_ctx_t *ctx);
  * stride B) at column offset `first` -- same-device copies for shards that live on gather_device,
  * hipMemcpyPeerAsync / peer-enabled 2-D copies (xGMI) otherwise -- and the call returns when everything has landed.
  * Two contexts on ONE device are legal (the degenerate case the single-GPU tests run).
+ * What travels is the reference's whole `Solution` (src/solve/solution.rs:7-20), not only the end states: the t_eval
+ * samples (y_eval / eval_idx / n_filled), event records and dense [max_log] logs are SoA members like y_end; a CSR
+ * step log (out.log_offsets / t_log / y_log per shard, offsets starting at 0 in the shard's own buffers: run the
+ * counting pass first, options.count_log = 1, with out.n_log gathered) is gathered into gathered->t_log /
+ * gathered->y_log in trajectory order, and gathered->log_offsets[B + 1] (device memory, written here) holds the shard
+ * offsets re-based by the records of the shards before them.
  *
  * ivp_batch_solve_multi_host: host-pointer convenience form (arguments as ivp_batch_solve): splits the batch into
  * n_ctx contiguous balanced shards (the first B % n_ctx shards get one more), stages each to its context's device,
@@ -356,8 +382,12 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
  * ivp_rhs_compile_events: the snippet additionally defines the trait's event functions
  *     __device__ void events(double x, const double* y, double* g, const double* p);   // g[0..n_events)
  * ivp_rhs_compile_ex: flags & IVP_RHS_HAS_JAC -- the snippet also overrides the trait's Jacobian (src/ivp.rs:67-107;
- * used by BDF instead of the default forward differences), row-major j[row*n + col], n <= 8:
+ * used by BDF instead of the default forward differences).  n <= 8: the whole matrix, row-major j[row*n + col],
  *     __device__ void jac(double x, const double* y, double* j, const double* p);
+ * 8 < n <= 512 (one wavefront per trajectory): column form -- write column `col` of dF/dy into column[0..n),
+ *     __device__ void jac_col(int col, double x, const double* y, double* column, const double* p);
+ * Either way the storage starts zeroed and persists between calls like the reference's Matrix (bdf.rs:152): entries an
+ * override never writes are 0.
  */
 #define IVP_RHS_HAS_JAC 1u
 int ivp_rhs_compile(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, void **handle);

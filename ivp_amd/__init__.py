@@ -6,14 +6,14 @@ package being the host-side mirror of the reference's ``solve_ivp`` / ``IVP`` / 
 """
 from .api import (  # noqa: F401
     BUILTIN, BouncingBall, Cannon, CR3BP, Direction, EventConfig, RationalEvents, SHOZeroEvent, BatchSolution, ConfigError, Context, ContinuousOutput, DeviceIVP, Exp2, ExponentialDecay,
-    FpMode, Heat1D256, LinearDecay100, InterpolationError, IVP, IvpError, LinearSystem, Lorenz, Method, Options, PendingBatch, Rational, Robertson, RobertsonJac, SHO, Solution, Status, StiffVanDerPol,
+    Dense64, FpMode, Heat1D256, LinearDecay100, InterpolationError, IVP, IvpError, LinearSystem, Lorenz, Method, Options, PendingBatch, Rational, Robertson, RobertsonJac, SHO, Solution, Status, StiffVanDerPol,
     VanDerPol, ZeroRhs, default_context, solve_ivp, solve_ivp_batch, solve_ivp_batch_logged,
 )
 from . import pyfront, workloads  # noqa: F401
 
 __all__ = [
     "BUILTIN", "BouncingBall", "Cannon", "CR3BP", "Direction", "EventConfig", "RationalEvents", "SHOZeroEvent", "BatchSolution", "ConfigError", "Context", "ContinuousOutput", "DeviceIVP", "Exp2",
-    "ExponentialDecay", "FpMode", "Heat1D256", "LinearDecay100", "InterpolationError", "IVP", "IvpError", "LinearSystem", "Lorenz", "Method", "Options", "PendingBatch",
+    "ExponentialDecay", "Dense64", "FpMode", "Heat1D256", "LinearDecay100", "InterpolationError", "IVP", "IvpError", "LinearSystem", "Lorenz", "Method", "Options", "PendingBatch",
     "Rational", "Robertson", "RobertsonJac", "SHO", "Solution", "Status", "StiffVanDerPol", "VanDerPol", "ZeroRhs", "default_context", "solve_ivp",
     "solve_ivp_batch", "solve_ivp_batch_logged", "pyfront", "workloads",
 ]

@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libivp_hip.so")
+# IVP_AMD_LIB: an alternative build of the SAME library for A/B measurements (tools/, exp_libs/); never a fallback
+LIB_PATH = os.environ.get("IVP_AMD_LIB") or os.path.join(_HERE, "libivp_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 c_double_p = C.POINTER(C.c_double)
@@ -38,6 +39,8 @@ class OptionsT(C.Structure):
         ("has_settings", C.c_int32), ("uround", C.c_double), ("safety_factor", C.c_double), ("scale_min", C.c_double),
         ("scale_max", C.c_double), ("beta", C.c_double), ("stiff_test", C.c_uint64),
         ("count_log", C.c_int32),
+        ("t_eval_offsets", C.POINTER(C.c_uint64)), ("ev_direction_vec", C.POINTER(C.c_int32)), ("ev_terminal_vec", C.POINTER(C.c_uint32)),
+        ("n_event_cfg", C.c_int32),
     ]
 
 

@@ -275,9 +275,18 @@ class Heat1D256(IVP):
     def params(self): return (self.kappa,)
 
 
+@dataclass
+class Dense64(IVP):
+    """y' = A y with a dense, diagonally dominant 64 x 64 matrix (a_ii = -k (4 + i mod 5), a_ij = ((i j + i + 2 j) mod 17 - 8) / 256):
+    a full Jacobian for the per-trajectory LU of BDF on the wave-per-trajectory path."""
+    k: float = 1.0
+    rhs_id = 102; n = 64; n_params = 1
+    def params(self): return (self.k,)
+
+
 MAX_LANE_N = 8   # largest n of the thread-per-trajectory kernels; above it one wavefront owns a trajectory
 
-BUILTIN = {"linear_decay100": LinearDecay100, "heat1d256": Heat1D256, "sho_ev": SHOZeroEvent, "ball": BouncingBall, "cannon": Cannon, "rational_ev": RationalEvents,
+BUILTIN = {"linear_decay100": LinearDecay100, "heat1d256": Heat1D256, "dense64": Dense64, "sho_ev": SHOZeroEvent, "ball": BouncingBall, "cannon": Cannon, "rational_ev": RationalEvents,
            "linear": LinearSystem, "robertson": Robertson, "robertson_jac": RobertsonJac, "vdp_eps": StiffVanDerPol, "decay": ExponentialDecay, "sho": SHO, "vdp": VanDerPol, "cr3bp": CR3BP, "lorenz": Lorenz,
            "zero": ZeroRhs, "rational": Rational, "exp2": Exp2}
 
@@ -300,7 +309,9 @@ class DeviceIVP(IVP):
         ``__device__ void events(double x, const double* y, double* g, const double* p)``.
         ``jac=True``: ``source`` also overrides the trait's Jacobian (src/ivp.rs:67-107), used by BDF in place of the
         default forward differences: ``__device__ void jac(double x, const double* y, double* j, const double* p)``
-        with ``j[row * n + col]`` (n <= 8)."""
+        with ``j[row * n + col]`` for n <= 8; for larger systems the column form
+        ``__device__ void jac_col(int col, double x, const double* y, double* column, const double* p)``.  Entries the
+        override never writes are zero (the reference's Matrix starts zeroed)."""
         self.source = source
         self.n = int(n)
         self._params = tuple(float(v) for v in params)
@@ -348,6 +359,10 @@ class Options:
     atol: Union[float, Sequence[float]] = 1e-6
     max_steps: Optional[int] = None
     t_eval: Optional[Sequence[float]] = None
+    # Batch calls only: one output grid PER TRAJECTORY -- every reference solve_ivp() call has its own Options.t_eval
+    # (options.rs:75-123).  A sequence of B sequences (ragged); mutually exclusive with t_eval.  The samples come back as
+    # time-major CSR records (BatchSolution.eval_offsets / eval_of(b)).
+    t_eval_per_trajectory: Optional[Sequence[Sequence[float]]] = None
     first_step: Optional[float] = None
     max_step: Optional[float] = None
     min_step: Optional[float] = None      # read by BDF only (src/solve/solve_ivp.rs:271)
@@ -394,6 +409,17 @@ class Options:
                 keep.append(te)
             o.t_eval = te.ctypes.data_as(_lib.c_double_p)
             o.n_eval = len(self.t_eval)
+        if self.t_eval_per_trajectory is not None:
+            if self.t_eval is not None:
+                raise ValueError("give t_eval (one shared grid) or t_eval_per_trajectory, not both")
+            grids = [np.ascontiguousarray(g, dtype=np.float64).reshape(-1) for g in self.t_eval_per_trajectory]
+            off = np.zeros(len(grids) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([g.size for g in grids])
+            te = np.concatenate(grids) if grids and off[-1] else np.zeros(1)
+            keep += [te, off]
+            o.t_eval = te.ctypes.data_as(_lib.c_double_p)
+            o.n_eval = int(off[-1])
+            o.t_eval_offsets = off.ctypes.data_as(C.POINTER(C.c_uint64))
         if self.first_step is not None:
             o.has_first_step, o.first_step = 1, float(self.first_step)
         if self.max_step is not None:
@@ -653,9 +679,17 @@ class BatchSolution:
     t_term: object = None
     njev: object = None
     nlu: object = None
+    eval_offsets: object = None  # per-trajectory t_eval grids: [B+1] record offsets into y_eval [total, n] / eval_idx [total]
     log_offsets: object = None   # CSR step log (solve_ivp_batch_logged): [B+1] record offsets; t_log [total], y_log [total, n]
     stats: dict = field(default_factory=dict)
     event_overflow: bool = False  # some trajectory detected more occurrences of an event than max_events could store
+
+    def eval_of(self, b: int):
+        """(index into trajectory b's own t_eval grid, y) of its emitted samples (per-trajectory grids); index -1 marks the
+        sample a terminal event appended."""
+        lo = int(self.eval_offsets[b])
+        m = int(self.n_filled[b])
+        return self.eval_idx[lo:lo + m], self.y_eval[lo:lo + m]
 
     def log_of(self, b: int):
         """(t, y) of trajectory b from a CSR step log: Solution.t / Solution.y of that solve_ivp() call."""
@@ -793,6 +827,12 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
     keep: list = []
     copt = options._c(n, keep)
     method = options.method_enum
+    per_traj = options.t_eval_per_trajectory is not None
+    if per_traj:
+        if len(options.t_eval_per_trajectory) != B:
+            raise ValueError(f"t_eval_per_trajectory needs one grid per trajectory ({B}), got {len(options.t_eval_per_trajectory)}")
+        if not on_device:
+            raise ValueError("t_eval_per_trajectory needs device arrays (y0 as a CUDA tensor): the CSR outputs exist on the device-pointer entry points")
     ne = 0 if options.t_eval is None else len(options.t_eval)
     ml = int(options.max_log)
     nc = method.coeffs_per_state() * n if method != Method.RADAU else 0
@@ -819,6 +859,8 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
             total = int(out.t_log.shape[0])
             want["t_log"], want["y_log"] = ((total,), f64), ((total, n), f64)
             want["log_offsets"] = ((B + 1,), u64)
+        if options.t_eval_per_trajectory is not None:   # CSR sample records: checked where they are bound below
+            want.pop("y_eval"); want.pop("eval_idx")
         for name, (shape, dt) in want.items():
             v = getattr(out, name)
             if v is None:
@@ -839,6 +881,20 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         res.y_eval = xp_zeros((rows, n, B), f64)
         res.eval_idx = xp_zeros((rows, B), i32)
         res.n_filled = xp_zeros((B,), i32)
+    if per_traj:
+        import torch
+        extra = 1 if f.n_events() else 0                    # a terminal event appends its own sample
+        sizes = np.array([len(g) for g in options.t_eval_per_trajectory], dtype=np.int64) + extra
+        offs = np.zeros(B + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(sizes)
+        total = int(offs[-1])
+        if res.y_eval is None:
+            res.y_eval = xp_zeros((max(total, 1), n), f64)
+            res.eval_idx = xp_zeros((max(total, 1),), i32)
+            res.n_filled = xp_zeros((B,), i32)
+        elif tuple(res.y_eval.shape) != (max(total, 1), n):
+            raise ValueError(f"out.y_eval: expected shape {(max(total, 1), n)} for these per-trajectory grids")
+        res.eval_offsets = torch.as_tensor(offs, device=y0.device)
     if options.count_log and res.n_log is None:
         res.n_log = xp_zeros((B,), u32)
     if options.t_eval is None and ml > 0 and res.t_log is None and res.log_offsets is None:
@@ -857,6 +913,13 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
             cfg = f.event_config(i)
             copt.ev_direction[i] = int(cfg.direction)
             copt.ev_terminal[i] = int(cfg.terminal_count or 0)
+        if ne_ev > 4:   # trait IVP::n_events is unbounded (src/ivp.rs:31-52): the configurations travel as arrays
+            dirs = np.array([int(f.event_config(i).direction) for i in range(ne_ev)], dtype=np.int32)
+            terms = np.array([int(f.event_config(i).terminal_count or 0) for i in range(ne_ev)], dtype=np.uint32)
+            keep += [dirs, terms]
+            copt.ev_direction_vec = dirs.ctypes.data_as(C.POINTER(C.c_int32))
+            copt.ev_terminal_vec = terms.ctypes.data_as(C.POINTER(C.c_uint32))
+            copt.n_event_cfg = ne_ev
         mev = max(int(options.max_events), 1)
         if res.t_events is None:
             res.t_events = xp_zeros((ne_ev, mev, B), f64)

@@ -420,8 +420,9 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
     if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
         if (FULL) {
             if (a.n_eval >= 0) {
-                for (int32_t i = 0; i < a.n_eval; ++i)
-                    if (fabs(a.t_eval[i] - L.x0) < 1e-12) so_emit_eval<M_BDF, N, P>(a, j, L, i, y);
+                const EvalGrid grid = so_grid(a, j);
+                for (int32_t i = 0; i < grid.n; ++i)
+                    if (fabs(grid.t[i] - L.x0) < 1e-12) so_emit_eval<M_BDF, N, P>(a, j, L, i, y);
             } else if (a.t_log != nullptr) {
                 so_push_log<M_BDF, N, P>(a, j, L, L.x0, y);
             }

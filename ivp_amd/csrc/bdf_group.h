@@ -17,7 +17,19 @@
 //     n + 1 evaluations of the component-form right-hand side through LDS.
 // The weighted RMS norms use NormOps<GroupRhs>::sum (strict build: index-order sum, the reference's bits).
 // All controller scalars are computed redundantly by every lane, so control flow is group-uniform.
-// Outputs: end state, t_eval sampling and the accepted-step log (dense_output segments are not collected here).
+// Outputs: end state, t_eval sampling, the accepted-step log and dense-output segments.
+//
+// LDS-resident factors (LDSLU kernels; BASELINE C5's "batched dense LU of per-trajectory Jacobians in LDS").  With one
+// wavefront per trajectory and n <= 128 the n x n matrix LU = (I - cJ) fits the CU's 160 KiB of LDS (80 KB at n = 100:
+// two trajectories per CU; 128 KB at n = 128: one), so the LDSLU instantiation keeps it THERE for the whole launch:
+// lu_decomp and lin_solve are the very same functions (every access below is `a[col * NT + row]` on a pointer whose
+// address space the compiler infers), but a pivot step now waits for LDS round trips (~64 cycles) instead of L2 / HBM
+// round trips (~1-2 us for a lone wavefront), and the trailing update no longer leaves the CU.  J stays in global memory
+// (it is read once per refactorisation, coalesced).  LDS does not survive a launch: factors that are current when a
+// launch ends are written back to the trajectory's global block and fetched again by the next launch, so the
+// refactorisation count (`nlu`) and every bit of the results equal the global-memory path's.
+// All barriers in this file are workgroup barriers of a ONE-WAVEFRONT workgroup (blockDim.x == IVP_WAVE, enforced by the
+// launch tables): groups of a wavefront may diverge around them (NGROUP > 1) without deadlock.
 #pragma once
 
 namespace IVP_NS {
@@ -66,6 +78,30 @@ struct BdfG {
 #pragma unroll
                 for (int c = 0; c < C; ++c) if (own(c)) jac[(size_t)col * NT + gi(c)] = (fp[c] - fo[c]) / pert;
             }
+        }
+    }
+
+    // f.jac(x, y, &mut j): the problem's own Jacobian when the functor has one -- the `impl IVP { fn jac }` override of
+    // src/ivp.rs:67-107 in COLUMN form, static void jac_col(int col, double x, const double* y, double* column /* [n] */,
+    // const double* p), which writes column `col` of dF/dy (entries it does not write keep their previous value: the
+    // reference's Matrix persists between calls and starts zeroed, bdf.rs:152) -- else the forward differences above.
+    // Lane l fills columns l, l + G, ...: every column of the column-major J is one contiguous run of memory.
+    template <class RR, class = void>
+    struct HasJacCol { enum { v = 0 }; };
+    template <class RR>
+    struct HasJacCol<RR, decltype((void)&RR::jac_col)> { enum { v = 1 }; };
+    static __device__ __forceinline__ void eval_jac(double x, const double (&y)[C], const double *p, double *jac)
+    {
+        if constexpr (HasJacCol<R>::v) {
+            double *st = GR::scratch();
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < C; ++c) if (own(c)) st[gi(c)] = y[c];
+            __syncthreads();
+            for (int col = gl(); col < NT; col += G) R::jac_col(col, x, st, jac + (size_t)col * NT, p);
+            __syncthreads();
+        } else {
+            fd_jac(x, y, p, jac);
         }
     }
 
@@ -240,8 +276,7 @@ struct BdfG {
     // lin_solve (src/matrix/linear.rs:55-96): b (this lane's components) <- A^-1 b
     static __device__ __forceinline__ void lin_solve(const double *a, const uint32_t *piv, double (&bl)[C])
     {
-        __shared__ double rhs_lds[NGROUP * NT];
-        double *b = rhs_lds + GR::gb();
+        double *b = GR::scratch();
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < C; ++c) if (own(c)) b[gi(c)] = bl[c];
@@ -357,8 +392,9 @@ __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32
     if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
         if (FULL) {
             if (a.n_eval >= 0) {
-                for (int32_t i = 0; i < a.n_eval; ++i)
-                    if (fabs(a.t_eval[i] - L.x0) < 1e-12) so_emit_eval<M_BDF, C, P, MAP>(a, j, L, i, y);
+                const EvalGrid grid = so_grid(a, j);
+                for (int32_t i = 0; i < grid.n; ++i)
+                    if (fabs(grid.t[i] - L.x0) < 1e-12) so_emit_eval<M_BDF, C, P, MAP>(a, j, L, i, y);
             } else if (a.t_log != nullptr) {
                 so_push_log<M_BDF, C, P, MAP>(a, j, L, L.x0, y);
             }
@@ -389,7 +425,10 @@ __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32
     const double hmax = fabs(a.has_max_step ? a.max_step : fabs(L.xend - L.x0));
     GR::ode(L.x0, y, f0, L.p);
     double *jac = a.bdf_jac + (size_t)j * NT * NT;
-    BG::fd_jac(L.x0, y, L.p, jac);
+    if constexpr (BG::template HasJacCol<R>::v) {   // the reference's jac storage starts zeroed (bdf.rs:152)
+        for (int e = BG::gl(); e < NT * NT; e += G) jac[e] = 0.0;
+    }
+    BG::eval_jac(L.x0, y, L.p, jac);
     double h_abs;
     if (a.has_first_step) {
         if (a.first_step == 0.0) {   // Err(InvalidStepSize), bdf.rs:192-197
@@ -593,7 +632,7 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
         iters += 1;
     }
     if (!converged) {   // bdf.rs:448-459: refresh the Jacobian at the predictor, halve the step
-        BG::fd_jac(x_new, y_predict, L.p, jac);
+        BG::eval_jac(x_new, y_predict, L.p, jac);
         S.d_njev += 1;
         lu_current = false;
         S.pending_factor = 0.5; S.flags |= IVP_BDF_PENDING;
@@ -704,19 +743,23 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
         order = new_order;
         n_equal = 0;
         lu_current = false;
-        if (new_order != old_order) { BG::fd_jac(S.x, S.y, L.p, jac); S.d_njev += 1; }
+        if (new_order != old_order) { BG::eval_jac(S.x, S.y, L.p, jac); S.d_njev += 1; }
     }
     pack();
     return true;
 }
 
-template <class R, bool FULL, int G>
+// largest n whose factors the LDSLU kernels keep in LDS (128 x 128 doubles = 128 KiB of the CU's 160)
+#define IVP_LDS_LU_MAX_N 128
+template <class R, bool FULL, int G, bool LDSLU>
 __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     using BG = BdfG<R, G>;
     using GR = GroupRhs<R, G>;
     using MAP = typename OutMap<GR>::type;
     constexpr int C = BG::C, NT = BG::NT, P = R::P;
+    constexpr bool kLds = LDSLU && BG::NGROUP == 1 && NT <= IVP_LDS_LU_MAX_N;
+    static_assert(!LDSLU || kLds, "LDS-resident factors: one wavefront per trajectory, n <= IVP_LDS_LU_MAX_N");
     const size_t B = a.B;
     BdfGLane<C> S;
     Lane<C, P> L;
@@ -728,13 +771,26 @@ __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint
         for (int c = 0; c < C; ++c) S.d[k][c] = MAP::own(c) ? a.bdf_d[((size_t)k * NT + MAP::gi(c)) * B + j] : 0.0;
 #pragma unroll
     for (int c = 0; c < P; ++c) L.p[c] = a.params[c * B + j];
-    double *jac = a.bdf_jac + (size_t)j * NT * NT, *lu = a.bdf_lu + (size_t)j * NT * NT;
-    uint32_t *piv = a.bdf_piv + (size_t)j * NT;
+    double *jac = a.bdf_jac + (size_t)j * NT * NT, *lu_mem = a.bdf_lu + (size_t)j * NT * NT;
+    uint32_t *piv_mem = a.bdf_piv + (size_t)j * NT;
+    double *lu = lu_mem;
+    uint32_t *piv = piv_mem;
     S.x = a.x[j];
     S.current_h = a.h[j];
     S.current_c = a.facold[j];
     S.pending_factor = a.hlamb[j];
     S.flags = a.flags[j];
+    if constexpr (kLds) {
+        __shared__ double ivp_lu_lds[NT * NT];
+        __shared__ uint32_t ivp_piv_lds[NT];
+        lu = ivp_lu_lds;
+        piv = ivp_piv_lds;
+        if (S.flags & IVP_BDF_LU_CURRENT) {   // factors computed by an earlier launch: fetch them (coalesced)
+            for (int e = (int)threadIdx.x; e < NT * NT; e += IVP_WAVE) ivp_lu_lds[e] = lu_mem[e];
+            for (int e = (int)threadIdx.x; e < NT; e += IVP_WAVE) ivp_piv_lds[e] = piv_mem[e];
+        }
+        __syncthreads();
+    }
     S.x0 = a.t0[(size_t)j * a.t0_stride];
     S.xend = a.t1[(size_t)j * a.t1_stride];
     S.direction = rs_signum(S.xend - S.x0);
@@ -763,6 +819,12 @@ __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint
         ++it;
     }
     __syncthreads();
+    if constexpr (kLds) {
+        if (S.flags & IVP_BDF_LU_CURRENT) {   // the next launch continues with these factors (same nlu as the global-memory path)
+            for (int e = (int)threadIdx.x; e < NT * NT; e += IVP_WAVE) lu_mem[e] = lu[e];
+            for (int e = (int)threadIdx.x; e < NT; e += IVP_WAVE) piv_mem[e] = piv[e];
+        }
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) map_st<MAP>(a.y, c, B, j, S.y[c]);
 #pragma unroll

@@ -36,6 +36,7 @@ bool group_builtin(int rhs_id, int *n, int *p)
     switch (rhs_id) {
     case IVP_RHS_LINEAR_DECAY_100: *n = 100; *p = 0; return true;
     case IVP_RHS_HEAT1D_256: *n = 256; *p = 1; return true;
+    case IVP_RHS_DENSE_64: *n = 64; *p = 1; return true;
     }
     return false;
 }
@@ -88,7 +89,7 @@ struct ivp_ctx {
     uint32_t one_wave_per_simd() const { return simds * (uint32_t)IVP_WAVE; }   // lanes that fill every SIMD with one wave
     std::string err;
     // scratch (device)
-    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval, tolvec, zero_off;
+    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval, teval_off, evcfg, tolvec, zero_off;
     DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
     DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
     DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu, prev_event, sc_n_ev;
@@ -104,7 +105,7 @@ struct ivp_ctx {
         IvpKArgs a;
         ivp_problem_t prob;
         int method = 0, fp_mode = 0, variant = 0, profile = 0, n = 0;
-        bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false;
+        bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false, lds_lu_ok = false;
         uint32_t chunk = 64, lanes = 0;
         size_t B = 0;
         uint64_t c = 0;             // chunk launches so far
@@ -206,11 +207,13 @@ struct Tune {
     size_t coop_cap_lanes = 0;       // lanes (8 per trajectory) up to which the lane-cooperative kernels take over; 0 = two waves per SIMD of the device
     uint32_t bulk_chunk = 64;        // attempts per bulk launch
     int launches_per_poll = 3;       // bulk launches between two host polls
+    int lds_lu = 1;                  // large-n BDF: 0 = never keep the factors in LDS
     int bdf_lpw = 0;                 // trajectories per wave of the BDF chunk launches: 0 = auto (spread the active set over the SIMDs)
     Tune()
     {
         if (const char *e = getenv("IVP_TUNE_COOP_CAP_LANES")) coop_cap_lanes = (size_t)strtoull(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BULK_CHUNK")) bulk_chunk = (uint32_t)std::max(1l, strtol(e, nullptr, 10));
+        if (const char *e = getenv("IVP_TUNE_LDS_LU")) lds_lu = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BDF_LPW")) bdf_lpw = (int)std::min(64l, std::max(0l, strtol(e, nullptr, 10)));
         if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10)));
     }
@@ -243,7 +246,12 @@ hipError_t pend_launch(ivp_ctx *ctx, int what, const IvpKArgs &ka, uint32_t lane
     const bool fast = P.fp_mode == IVP_FP_FAST;
     if (P.jit) return ivp_jit_launch(P.prob.jit, (use_coop && what == IVP_LAUNCH_CHUNK) ? IVP_LAUNCH_COOP : what, P.method, P.fp_mode, P.full, ka, lanes, s);
     if (P.group) return (fast ? ivp_launch_group_fast : ivp_launch_group_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
-    if (P.method == IVP_BDF) return (fast ? ivp_launch_bdf_fast : ivp_launch_bdf_strict)(what, P.prob.rhs_id, P.full, ka, lanes, s);
+    if (P.method == IVP_BDF) {
+        // more than one full wave per SIMD still running: the two-waves-per-SIMD build (rk_bdf.hip); same bits either way
+        const bool occ2 = what == IVP_LAUNCH_CHUNK && lanes > ctx->one_wave_per_simd();
+        if (occ2) return (fast ? ivp_launch_bdf_fast_occ2 : ivp_launch_bdf_strict_occ2)(what, P.prob.rhs_id, P.full, ka, lanes, s);
+        return (fast ? ivp_launch_bdf_fast : ivp_launch_bdf_strict)(what, P.prob.rhs_id, P.full, ka, lanes, s);
+    }
     if (use_coop && what == IVP_LAUNCH_CHUNK) return (fast ? ivp_launch_coop_fast : ivp_launch_coop_strict)(P.method, P.prob.rhs_id, P.full, ka, lanes, s);
     if (use_hoist) return (fast ? ivp_launch_fast_hoist : ivp_launch_strict_hoist)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
     return (fast ? ivp_launch_fast : ivp_launch_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
@@ -318,6 +326,13 @@ int enqueue_round(ivp_ctx *ctx)
         IvpKArgs ka = P.a;
         ka.chunk = this_chunk;
         ka.lpw = lpw;
+        // LDS-resident factors (bdf_group.h) cost occupancy: an 80 KB matrix leaves room for two wavefronts per CU instead of
+        // four.  Measured (MI355X, profiles/r03_large_n_bdf_lds_vs_global.jsonl): while the active set fits two wavefronts per
+        // CU the LDS form is 2-12 % faster (a pivot step waits for LDS, not for L2); beyond that a dense Jacobian still gains
+        // 1.2x but a sparse one (whose trailing updates are mostly skipped) loses 1.5x to the lost occupancy -- so the
+        // automatic choice follows the active count, launch by launch (current factors travel through global memory
+        // between launches either way); variant 2 forces the LDS form for every launch
+        ka.lds_lu = (P.lds_lu_ok && (P.variant == 2 || (size_t)lanes <= 2u * (size_t)ctx->cus)) ? 1u : 0u;
         if (c == 0) {
             ka.perm_in = nullptr;
             ka.count_in = nullptr;
@@ -472,7 +487,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval, &c->tolvec, &c->zero_off,
+    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval, &c->teval_off, &c->evcfg, &c->tolvec, &c->zero_off,
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
@@ -562,7 +577,17 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     const bool want_dense = opt->dense_output && opt->max_log > 0 && out->seg_cont && out->seg_xold && out->seg_h;
     const bool group = n > IVP_MAX_N;
     const int n_events = prob->rhs_id == IVP_RHS_JIT ? ivp_jit_n_events(prob->jit) : group ? 0 : kRhsEvents[prob->rhs_id];
-    if (n_events > 4) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "at most 4 event functions");
+    if (n_events > 4 && !(opt->ev_direction_vec && opt->ev_terminal_vec && opt->n_event_cfg == n_events))
+        return fail(ctx, IVP_ERR_BAD_ARGUMENT, "%d event functions need ev_direction_vec / ev_terminal_vec with n_event_cfg = %d entries", n_events, n_events);
+    if (opt->t_eval_offsets) {   // per-trajectory grids: B + 1 offsets into the concatenated t_eval
+        if (!opt->t_eval) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets without t_eval");
+        if (opt->t_eval_offsets[0] != 0 || opt->t_eval_offsets[B] != (uint64_t)opt->n_eval)
+            return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets must run from 0 to n_eval");
+        for (size_t b = 0; b < B; ++b) {
+            if (opt->t_eval_offsets[b + 1] < opt->t_eval_offsets[b]) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets must be non-decreasing");
+            if (opt->t_eval_offsets[b + 1] - opt->t_eval_offsets[b] > 0x7FFFFFFFull) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "a trajectory's t_eval grid is too long");
+        }
+    }
     const bool full = want_eval || want_log || want_dense || n_events > 0;
     if (want_eval && opt->n_eval > 0 && !out->y_eval) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t_eval given but out.y_eval is NULL");
     if (opt->dense_output && !want_dense) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "dense_output needs max_log > 0 and seg_cont/seg_xold/seg_h");
@@ -661,6 +686,14 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     a.n_eval = -1;
     if (n_events > 0) {   // event state: prev_event, hit counters; outputs where given
         for (int i = 0; i < 4; ++i) { a.ev_direction[i] = opt->ev_direction[i]; a.ev_terminal[i] = opt->ev_terminal[i]; }
+        if (opt->ev_direction_vec && opt->ev_terminal_vec && opt->n_event_cfg == n_events) {   // any number of event functions
+            HIP_TRY(ctx, ctx->evcfg.reserve(sizeof(int32_t) * 2 * (size_t)n_events));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->evcfg.p, opt->ev_direction_vec, sizeof(int32_t) * n_events, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync((int32_t *)ctx->evcfg.p + n_events, opt->ev_terminal_vec, sizeof(uint32_t) * n_events, hipMemcpyHostToDevice, s));
+            a.ev_direction_dev = (const int32_t *)ctx->evcfg.p;
+            a.ev_terminal_dev = (const uint32_t *)ctx->evcfg.p + n_events;
+            for (int i = 0; i < 4 && i < n_events; ++i) { a.ev_direction[i] = opt->ev_direction_vec[i]; a.ev_terminal[i] = opt->ev_terminal_vec[i]; }
+        }
         const bool store = out->t_events && out->y_events && opt->max_events > 0;
         a.max_events = store ? opt->max_events : 0;
         a.t_events = out->t_events;
@@ -681,6 +714,12 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
             a.t_eval = (const double *)ctx->teval.p;
             a.y_eval = out->y_eval;
             a.eval_idx = out->eval_idx;
+            if (opt->t_eval_offsets) {
+                HIP_TRY(ctx, ctx->teval_off.reserve(sizeof(unsigned long long) * (B + 1)));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->teval_off.p, opt->t_eval_offsets, sizeof(unsigned long long) * (B + 1), hipMemcpyHostToDevice, s));
+                a.teval_off = (const unsigned long long *)ctx->teval_off.p;
+                a.teval_extra = n_events > 0 ? 1u : 0u;
+            }
         }
         BIND(n_filled, out->n_filled, sc_n_filled, sizeof(int32_t) * B);
         BIND(n_log, out->n_log, sc_n_log, sizeof(uint32_t) * B);
@@ -719,6 +758,9 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 8, s));
     a.err_flag = (uint32_t *)ctx->counts.p + 4;
+    // large-n BDF: the factors of (I - cJ) can live in LDS where the matrix fits (n <= 128, built-in problems: one wavefront
+    // per trajectory); enqueue_round decides per launch (a.lds_lu), the results do not depend on it
+    const bool lds_lu_ok = group && opt->method == IVP_BDF && prob->rhs_id != IVP_RHS_JIT && n <= 128 && opt->variant != 1 && tune().lds_lu != 0;
 
     ivp_ctx::Pending &P = ctx->pend;
     P.a = a;
@@ -731,6 +773,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.group = group;
     P.jit = prob->rhs_id == IVP_RHS_JIT;
     P.has_settings = opt->has_settings != 0;
+    P.lds_lu_ok = lds_lu_ok;
     // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for problems with
     // n <= 8.  Results are bit-identical to the thread-per-trajectory kernels in both arithmetic modes, so the loop
     // switches to them for the latency-bound tail.
@@ -911,6 +954,7 @@ int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_probl
 {
     if (!shards || n_shards <= 0 || n_shards > 64) return IVP_ERR_BAD_ARGUMENT;
     DeviceGuard restore_device;   // hipSetDevice below must not leak into the caller (its allocations / launches follow the current device)
+    if (opt && opt->t_eval_offsets) return IVP_ERR_BAD_ARGUMENT;   // offsets index the whole batch, a shard sees a slice: shard the grids yourself
     ivp_ctx_t *c0 = nullptr;
     for (int i = 0; i < n_shards; ++i) {
         if (!shards[i].ctx) return IVP_ERR_BAD_ARGUMENT;
@@ -958,7 +1002,40 @@ int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_probl
             void *dst = member(gathered, md[k]);
             const void *src = member(&sh.out, md[k]);
             if (!dst || !src) continue;
+            // a CSR step log is not an SoA member: it is gathered below
+            if (sh.out.log_offsets && (md[k].off == offsetof(ivp_batch_result_t, t_log) || md[k].off == offsetof(ivp_batch_result_t, y_log))) continue;
             HIP_TRY(c0, copy_rows_peer((char *)dst + sh.first * md[k].elem, gather_device, B, src, sh.ctx->device, sh.count, md[k].elem, sh.count, md[k].rows, s));
+        }
+    }
+    // ---- CSR step logs (Solution.t / Solution.y of every trajectory): every shard's records are one contiguous run
+    // [total_k] / [total_k][n]; in trajectory order the shards' runs follow each other, and a shard's offsets (which
+    // start at 0 in its own buffers) are re-based by the number of records of the shards before it ----
+    if (gathered->log_offsets) {
+        if (!gathered->t_log || !gathered->y_log) return fail(c0, IVP_ERR_BAD_ARGUMENT, "gathered.log_offsets needs gathered.t_log and gathered.y_log");
+        std::vector<int> order;
+        for (int i = 0; i < n_shards; ++i) if (shards[i].count) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return shards[a].first < shards[b].first; });
+        unsigned long long base = 0;
+        std::vector<unsigned long long> off;
+        for (int i : order) {
+            ivp_shard_t &sh = shards[i];
+            if (!sh.out.log_offsets || !sh.out.t_log || !sh.out.y_log)
+                return fail(c0, IVP_ERR_BAD_ARGUMENT, "shard %d has no CSR step log (out.log_offsets / t_log / y_log) to gather", i);
+            HIP_TRY(c0, hipSetDevice(sh.ctx->device));
+            hipStream_t s = (hipStream_t)sh.hip_stream;
+            off.resize(sh.count + 1);
+            HIP_TRY(c0, hipMemcpyAsync(off.data(), sh.out.log_offsets, (sh.count + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c0, hipStreamSynchronize(s));
+            const unsigned long long total = off[sh.count];
+            HIP_TRY(c0, copy_rows_peer((char *)gathered->t_log + base * 8, gather_device, total, sh.out.t_log, sh.ctx->device, total, 8, total, 1, s));
+            HIP_TRY(c0, copy_rows_peer((char *)gathered->y_log + base * 8 * (size_t)n, gather_device, total * (size_t)n, sh.out.y_log, sh.ctx->device,
+                                       total * (size_t)n, 8, total * (size_t)n, 1, s));
+            for (size_t k = 0; k <= sh.count; ++k) off[k] += base;
+            const bool last = i == order.back();
+            HIP_TRY(c0, hipMemcpyAsync((unsigned long long *)gathered->log_offsets + sh.first, off.data(), (sh.count + (last ? 1 : 0)) * sizeof(unsigned long long),
+                                       hipMemcpyHostToDevice, s));
+            HIP_TRY(c0, hipStreamSynchronize(s));   // `off` is reused by the next shard
+            base += total;
         }
     }
     for (int i = 0; i < n_shards; ++i) {
@@ -988,6 +1065,7 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
     if (np > 0 && !params) return fail(c0, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
     if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
     if (out->log_offsets) return fail(c0, IVP_ERR_BAD_ARGUMENT, "the CSR step log (log_offsets) is available on the device-pointer entry points only");
+    if (opt->t_eval_offsets) return fail(c0, IVP_ERR_BAD_ARGUMENT, "per-trajectory t_eval grids (t_eval_offsets) are available on the single-context device-pointer entry points only");
     MemberDesc md[kMembers];
     member_table(result_shape(prob, opt, n), md);
 
@@ -1062,10 +1140,9 @@ int ivp_rhs_compile_events(ivp_ctx_t *ctx, const char *ode_source, int32_t n, in
 int ivp_rhs_compile_ex(ivp_ctx_t *ctx, const char *ode_source, int32_t n, int32_t n_params, int32_t n_events, uint32_t flags, void **handle)
 {
     if (!ctx || !ode_source || !handle) return IVP_ERR_BAD_ARGUMENT;
-    if (n < 1 || n > IVP_MAX_GROUP_N || n_params < 0 || n_params > IVP_MAX_P || n_events < 0 || n_events > 4)
+    if (n < 1 || n > IVP_MAX_GROUP_N || n_params < 0 || n_params > IVP_MAX_P || n_events < 0 || n_events > 64)
         return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unsupported dimensions");
     if (flags & ~IVP_RHS_HAS_JAC) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown flags 0x%x", flags);
-    if ((flags & IVP_RHS_HAS_JAC) && n > IVP_MAX_N) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "a jac() override needs n <= %d", IVP_MAX_N);
     std::string log;
     int rc = ivp_jit_compile(ctx->device, ode_source, n, n_params, n_events, flags, handle, &log);
     if (rc != IVP_OK) ctx->err = log;

@@ -77,6 +77,9 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl, bool 
                       "#if IVP_USER_NE > 0\n"
                       "  static __device__ __forceinline__ void events(double x, const double* y, double* g, const double* p) { ::events(x, y, g, p); }\n"
                       "#endif\n"
+                      "#if IVP_USER_JAC\n"
+                      "  static __device__ __forceinline__ void jac_col(int col, double x, const double* y, double* column, const double* p) { ::jac_col(col, x, y, column, p); }\n"
+                      "#endif\n"
                       "}; }\n"
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<%d, ivp_jit::RhsUser, %s, %d>(a); }\n"
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<%d, ivp_jit::RhsUser, %s, %d>(a); }\n",

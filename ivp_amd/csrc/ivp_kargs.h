@@ -73,6 +73,11 @@ struct IvpKArgs {
     int32_t *eval_idx;        // [n_eval][B]
     int32_t *n_filled;        // [B] emitted samples so far
     int32_t *next_idx;        // [B] DefaultSolOut.next_idx
+    const unsigned long long *teval_off;  // per-trajectory grids (every reference call has its own Options.t_eval): [B+1] offsets into
+                              // t_eval; trajectory j samples t_eval[teval_off[j] .. teval_off[j+1]) and its k-th emitted sample is
+                              // record q = teval_off[j] + j * teval_extra + k of y_eval [..][N] / eval_idx [..] (time-major CSR);
+                              // NULL = one grid of n_eval points shared by the batch, y_eval [n_eval][N][B]
+    uint32_t teval_extra;     // spare records per trajectory in the CSR outputs (1 for problems with events: the terminal sample)
     uint32_t max_log;
     double *t_log;            // [max_log][B]
     double *y_log;            // [max_log][N][B]
@@ -88,6 +93,8 @@ struct IvpKArgs {
     // ---- events (trait IVP::events / event_config; FULL kernels of problems with NE > 0) ----
     int32_t ev_direction[4];  // 0 All, > 0 Positive, < 0 Negative (event.rs:59-77)
     uint32_t ev_terminal[4];  // EventConfig.terminal_count, 0 = None
+    const int32_t *ev_direction_dev;   // [NE] in device memory for problems with more than 4 event functions, else NULL
+    const uint32_t *ev_terminal_dev;
     uint32_t max_events;      // capacity of t_events / y_events per event and trajectory
     double *t_events;         // [NE][max_events][B]
     double *y_events;         // [NE][max_events][N][B]
@@ -109,6 +116,7 @@ struct IvpKArgs {
     uint32_t spec_cap;        // != 0: do nothing unless *count_in <= spec_cap (the host enqueued this launch before
                               // it knew the active count; it reads count_in afterwards to see which way it went)
     // ---- thin waves ----
+    uint32_t lds_lu;          // large-n BDF (bdf_group.h): != 0 selects the kernels that keep the factors of (I - cJ) in LDS
     uint32_t lpw;             // trajectories per wavefront of a thread-per-trajectory chunk launch (0 = 64).  A wave executes the
                               // UNION of its lanes' control flow; when the active set leaves SIMDs idle anyway, fewer lanes per
                               // wave on more SIMDs cost nothing and shrink that union (BDF: Newton iteration counts, D-rescaling,

@@ -10,9 +10,22 @@
 
 #define IVP_HD __host__ __device__ __forceinline__
 #define IVP_HOIST 2
-#if IVP_FAST
+// Second build (-DIVP_BDF_MIN_WAVES=2 -> *_occ2): the same source under __launch_bounds__(64, 2).  It spills a few
+// registers to scratch (84 B per lane at n = 2) and is ~10 % slower per attempt for a lone wave, but two resident waves
+// per SIMD hide each other's latencies once a batch over-subscribes the chip (262 144 stiff Van der Pol trajectories:
+// 24.7 -> 21.2 ms); the launch loop picks it for batches of more than one full wave per SIMD.  Same arithmetic, same bits.
+#ifndef IVP_BDF_MIN_WAVES
+#define IVP_BDF_MIN_WAVES 1
+#endif
+#if IVP_FAST && IVP_BDF_MIN_WAVES > 1
+#define IVP_NS ivp_bdf_fast_occ2
+#define IVP_LAUNCH_NAME ivp_launch_bdf_fast_occ2
+#elif IVP_FAST
 #define IVP_NS ivp_bdf_fast
 #define IVP_LAUNCH_NAME ivp_launch_bdf_fast
+#elif IVP_BDF_MIN_WAVES > 1
+#define IVP_NS ivp_bdf_strict_occ2
+#define IVP_LAUNCH_NAME ivp_launch_bdf_strict_occ2
 #else
 #define IVP_NS ivp_bdf_strict
 #define IVP_LAUNCH_NAME ivp_launch_bdf_strict

@@ -739,14 +739,32 @@ IVP_HD void interpolate(double xi, double *yi, const CP &cont, double xold, doub
 // collection, t_eval sampling, accepted-step recording with first_step enforcement.
 // `cont == nullptr` is the initial callback (interpolant None).
 // ------------------------------------------------------------------------------------------------
+// The t_eval grid of trajectory j: the batch's shared grid, or -- every reference solve_ivp() call has its own
+// Options.t_eval (options.rs:75-123) -- its own slice of a CSR grid.
+struct EvalGrid { const double *t; int32_t n; };
+IVP_HD EvalGrid so_grid(const IvpKArgs &a, uint32_t j)
+{
+    if (a.teval_off != nullptr) {
+        const unsigned long long lo = a.teval_off[j];
+        return EvalGrid{a.t_eval + lo, (int32_t)(a.teval_off[j + 1] - lo)};
+    }
+    return EvalGrid{a.t_eval, a.n_eval};
+}
 template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t ti, const double *yv)
 {
     const size_t B = a.B;
     const size_t k = (size_t)L.n_filled;
+    if (a.teval_off != nullptr) {   // per-trajectory grids: time-major CSR records like Solution.y (Vec<Vec<f64>>)
+        const size_t q = (size_t)a.teval_off[j] + (size_t)j * a.teval_extra + k;
 #pragma unroll
-    for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_eval[(k * MAP::NT + MAP::gi(c)) * B + j] = yv[c];
-    if (a.eval_idx) a.eval_idx[k * B + j] = ti;
+        for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_eval[q * MAP::NT + MAP::gi(c)] = yv[c];
+        if (a.eval_idx) a.eval_idx[q] = ti;
+    } else {
+#pragma unroll
+        for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_eval[(k * MAP::NT + MAP::gi(c)) * B + j] = yv[c];
+        if (a.eval_idx) a.eval_idx[k * B + j] = ti;
+    }
     L.n_filled += 1;
 }
 template <int M, int N, int P, class MAP = IdMap<N>>
@@ -811,18 +829,19 @@ IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold,
     double yi[N];
     if (a.n_eval >= 0) {  // Mode 1, solout.rs:344-386
         int32_t i = L.next_idx;
-        const int32_t ne = a.n_eval;
+        const EvalGrid grid = so_grid(a, j);
+        const int32_t ne = grid.n;
         if (fabs(xold - x) <= tol) {
-            while (i < ne && fabs(a.t_eval[i] - x) <= tol) { so_emit_eval<M, N, P, MAP>(a, j, L, i, y); ++i; }
+            while (i < ne && fabs(grid.t[i] - x) <= tol) { so_emit_eval<M, N, P, MAP>(a, j, L, i, y); ++i; }
         } else if (x > xold) {
-            while (i < ne && a.t_eval[i] <= x + tol) {
-                const double te = a.t_eval[i];
+            while (i < ne && grid.t[i] <= x + tol) {
+                const double te = grid.t[i];
                 if (te >= xold - tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P, MAP>(a, j, L, i, yi); }
                 ++i;
             }
         } else {
-            while (i < ne && a.t_eval[i] >= x - tol) {
-                const double te = a.t_eval[i];
+            while (i < ne && grid.t[i] >= x - tol) {
+                const double te = grid.t[i];
                 if (te <= xold + tol) { interpolate<M, N>(te, yi, cont, ixold, h); so_emit_eval<M, N, P, MAP>(a, j, L, i, yi); }
                 ++i;
             }
@@ -872,7 +891,7 @@ IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const double g_prev = a.prev_event[(size_t)i * B + j], g_cur = g_curr[i];
-        const int dir = a.ev_direction[i];
+        const int dir = a.ev_direction_dev ? a.ev_direction_dev[i] : a.ev_direction[i < 4 ? i : 3];
         bool crossed;
         if (dir == 0) crossed = (g_prev <= 0.0 && g_cur >= 0.0) || (g_prev >= 0.0 && g_cur <= 0.0);
         else if (dir > 0) crossed = g_prev < 0.0 && g_cur >= 0.0;
@@ -968,7 +987,7 @@ IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double
                     if (MAP::own(c)) a.y_events[(((size_t)i * a.max_events + k) * MAP::NT + MAP::gi(c)) * B + j] = det_y[u][c];
             }
             a.n_ev[(size_t)i * B + j] = k + 1;   // event_hits
-            const uint32_t term = a.ev_terminal[i];
+            const uint32_t term = a.ev_terminal_dev ? a.ev_terminal_dev[i] : a.ev_terminal[i < 4 ? i : 3];
             if (term != 0 && k + 1 >= term) {
                 // the terminal event point is appended to Solution.t / Solution.y (solout.rs:316-319)
                 if (a.n_eval >= 0) { so_emit_eval<M, N, P, MAP>(a, j, L, -1, det_y[u]); if (a.t_term) a.t_term[j] = det_t[u]; }
@@ -998,13 +1017,14 @@ IVP_HD bool solout_full(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, doub
 
 // does the accepted step [xold, xph] need dense coefficients? (lazy DOP853 dense stages)
 template <int N, int P>
-IVP_HD bool so_needs_dense(const IvpKArgs &a, const Lane<N, P> &L, double xold, double xph)
+IVP_HD bool so_needs_dense(const IvpKArgs &a, uint32_t j, const Lane<N, P> &L, double xold, double xph)
 {
     const double tol = 1e-12;
     if (a.collect_dense) return true;
     if (a.n_eval >= 0) {
-        if (L.next_idx >= a.n_eval) return false;
-        const double te = a.t_eval[L.next_idx];
+        const EvalGrid grid = so_grid(a, j);
+        if (L.next_idx >= grid.n) return false;
+        const double te = grid.t[L.next_idx];
         return xph > xold ? (te <= xph + tol) : (te >= xph - tol);
     }
     return a.t_log != nullptr && a.has_first_step && !(L.flags & IVP_F_FIRSTOUT);
@@ -1082,8 +1102,9 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, 0.0); }
         if (FULL) {
             if (a.n_eval >= 0) {
-                for (int32_t i = 0; i < a.n_eval; ++i)
-                    if (fabs(a.t_eval[i] - L.x0) < 1e-12) so_emit_eval<M, N, P, MAP>(a, j, L, i, L.y);
+                const EvalGrid grid = so_grid(a, j);
+                for (int32_t i = 0; i < grid.n; ++i)
+                    if (fabs(grid.t[i] - L.x0) < 1e-12) so_emit_eval<M, N, P, MAP>(a, j, L, i, L.y);
             } else if (a.t_log != nullptr) {
                 so_push_log<M, N, P, MAP>(a, j, L, L.x0, L.y);
             }
@@ -1546,7 +1567,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         L.d_nfev += 3;
         // the 8 x N dense block: staged through LDS when a lane holds more than one component (see ContStage)
         typename ivp_cond<(FULL && N >= 2), ContStage<8 * N>, ContRegs<(FULL ? 8 * N : 1)>>::type cont;
-        const bool need_dense = FULL && (R::NE > 0 || so_needs_dense<N, P>(a, L, x, xph));
+        const bool need_dense = FULL && (R::NE > 0 || so_needs_dense<N, P>(a, j, L, x, xph));
         if (FULL && need_dense) {
 { const double cD41 = KC(D41), cD46 = KC(D46), cD47 = KC(D47), cD48 = KC(D48), cD49 = KC(D49), cD410 = KC(D410), cD411 = KC(D411), cD412 = KC(D412), cD51 = KC(D51), cD56 = KC(D56), cD57 = KC(D57), cD58 = KC(D58), cD59 = KC(D59), cD510 = KC(D510), cD511 = KC(D511), cD512 = KC(D512), cD61 = KC(D61), cD66 = KC(D66), cD67 = KC(D67), cD68 = KC(D68), cD69 = KC(D69), cD610 = KC(D610), cD611 = KC(D611), cD612 = KC(D612), cD71 = KC(D71), cD76 = KC(D76), cD77 = KC(D77), cD78 = KC(D78), cD79 = KC(D79), cD710 = KC(D710), cD711 = KC(D711), cD712 = KC(D712);
 #pragma unroll

@@ -44,6 +44,20 @@ struct RhsHeat1D256 {        // method-of-lines heat equation, Dirichlet ends: y
     }
 };
 
+struct RhsDense64 {          // y' = A y with a dense, diagonally dominant 64 x 64 matrix (a full Jacobian for BDF's LU)
+    enum { N = 64, P = 1 };
+    static __device__ __forceinline__ double ode_comp(int i, double, const double *y, const double *p)
+    {
+        double s = -p[0] * (4.0 + (double)(i % 5)) * y[i];
+#pragma unroll 8
+        for (int j = 0; j < N; ++j) {
+            const double aij = (double)((i * j + i + 2 * j) % 17 - 8) * 0.00390625;   // / 256, exact
+            if (j != i) s = IVP_MA(s, aij, y[j]);
+        }
+        return s;
+    }
+};
+
 // number of event functions of a component-form functor (hiprtc user code defines NE; the built-ins have none)
 template <class R, class = void>
 struct GroupNE { enum { v = 0 }; };
@@ -56,10 +70,18 @@ struct GroupRhs {
     static_assert(G == 16 || G == 32 || G == 64, "group width");
     static __device__ __forceinline__ int gl() { return (int)threadIdx.x & (G - 1); }   // lane within the group
     static __device__ __forceinline__ int gb() { return ((int)threadIdx.x / G) * NT; }   // this group's LDS region
+    // ONE n-vector of LDS per group, shared by the three places that publish a vector to the whole group -- the stage
+    // state in ode(), the norm terms in NormOps::sum() (strict build), the right-hand side in BdfG::lin_solve().  Each
+    // user starts with a barrier, writes, and has read everything back before it returns, so the uses never overlap;
+    // one buffer instead of three is what lets two workgroups with an LDS-resident 100 x 100 matrix share a CU.
+    static __device__ __forceinline__ double *scratch()
+    {
+        __shared__ double ivp_group_vec[NGROUP * NT];
+        return ivp_group_vec + gb();
+    }
     static __device__ __forceinline__ void ode(double t, const double *ys, double *k, const double *p)
     {
-        __shared__ double stage[NGROUP * NT];
-        double *st = stage + gb();
+        double *st = scratch();
         __syncthreads();   // earlier readers of `stage` are done
 #pragma unroll
         for (int c = 0; c < N; ++c) { const int i = gl() + G * c; if (i < NT) st[i] = ys[c]; }
@@ -123,8 +145,7 @@ struct NormOps<GroupRhs<R, G>, void> {
         for (int o = G / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);   // stays inside the group: o < G
         return part;
 #else
-        __shared__ double red[GroupRhs<R, G>::NGROUP * NT];
-        double *rd = red + GroupRhs<R, G>::gb();
+        double *rd = GroupRhs<R, G>::scratch();
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < C; ++c) { const int i = gl + G * c; if (i < NT) rd[i] = term[c]; }
@@ -140,7 +161,7 @@ struct NormOps<GroupRhs<R, G>, void> {
 // BDF for large n (bdf_group.h, included after this header)
 template <class R, bool FULL, int G>
 __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32_t j);
-template <class R, bool FULL, int G>
+template <class R, bool FULL, int G, bool LDSLU>
 __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out);
 
 // init: one group of G lanes per trajectory, 64 / G trajectories per wavefront
@@ -153,8 +174,9 @@ __device__ __forceinline__ void group_init_body(const IvpKArgs &a)
     else (void)init_body<M, GroupRhs<R, G>, FULL>(a, j);
 }
 
-// up to a.chunk step attempts for the trajectories of this wave; controller fields from IvpKArgs (CTL = true)
-template <int M, class R, bool FULL, int G = IVP_WAVE>
+// up to a.chunk step attempts for the trajectories of this wave; controller fields from IvpKArgs (CTL = true).
+// LDSLU (BDF only): the factors of (I - cJ) live in LDS for the whole launch (bdf_group.h).
+template <int M, class R, bool FULL, int G = IVP_WAVE, bool LDSLU = false>
 __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
 {
     constexpr uint32_t NG = IVP_WAVE / G;
@@ -171,7 +193,7 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
     uint32_t it = 0;
     constexpr bool kCtl = M == M_RK23 || M == M_DOPRI5 || M == M_DOP853;
     if (active) {
-        if constexpr (M == M_BDF) it = bdf_group_chunk_body<R, FULL, G>(a, j, st);
+        if constexpr (M == M_BDF) it = bdf_group_chunk_body<R, FULL, G, LDSLU>(a, j, st);
         else it = chunk_body<M, GroupRhs<R, G>, FULL, kCtl>(a, j, st);
     }
     const bool lead = (threadIdx.x & (G - 1)) == 0;
@@ -190,7 +212,7 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
 
 template <int M, class R, bool FULL>
 __global__ __launch_bounds__(IVP_WAVE) void group_init_kernel(const IvpKArgs a) { group_init_body<M, R, FULL>(a); }
-template <int M, class R, bool FULL>
-__global__ __launch_bounds__(IVP_WAVE) void group_chunk_kernel(const IvpKArgs a) { group_chunk_body<M, R, FULL>(a); }
+template <int M, class R, bool FULL, bool LDSLU = false>
+__global__ __launch_bounds__(IVP_WAVE) void group_chunk_kernel(const IvpKArgs a) { group_chunk_body<M, R, FULL, IVP_WAVE, LDSLU>(a); }
 
 }  // namespace IVP_NS

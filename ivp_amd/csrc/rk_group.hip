@@ -32,8 +32,17 @@ hipError_t launch_group_one(int what, const IvpKArgs &a, uint32_t trajectories, 
     const dim3 grid(trajectories), block(IVP_WAVE);   // one wavefront per trajectory
     if (grid.x == 0) return hipSuccess;
     (void)hipGetLastError();   // drop a stale error of some earlier runtime call: the value returned below is this launch's
-    if (what == IVP_LAUNCH_INIT) hipLaunchKernelGGL((IVP_NS::group_init_kernel<M, R, FULL>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((IVP_NS::group_chunk_kernel<M, R, FULL>), grid, block, 0, s, a);
+    if (what == IVP_LAUNCH_INIT) {
+        hipLaunchKernelGGL((IVP_NS::group_init_kernel<M, R, FULL>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    if constexpr (M == IVP_NS::M_BDF && R::N <= IVP_LDS_LU_MAX_N) {
+        if (a.lds_lu) {   // factors of (I - cJ) resident in LDS (bdf_group.h)
+            hipLaunchKernelGGL((IVP_NS::group_chunk_kernel<M, R, FULL, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((IVP_NS::group_chunk_kernel<M, R, FULL>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -106,6 +115,7 @@ hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const Iv
     switch (rhs_id) {
     case 100: return launch_group<IVP_NS::RhsLinearDecay100>(what, method, full, a, trajectories, s);
     case 101: return launch_group<IVP_NS::RhsHeat1D256>(what, method, full, a, trajectories, s);
+    case 102: return launch_group<IVP_NS::RhsDense64>(what, method, full, a, trajectories, s);
     }
     return hipErrorInvalidValue;
 }

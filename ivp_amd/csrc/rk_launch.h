@@ -27,3 +27,6 @@ hipError_t ivp_launch_coop_fast(int method, int rhs_id, bool full, const IvpKArg
 // thread-per-trajectory BDF kernels (rk_bdf.hip: pinned-coefficient build, n <= 8)
 hipError_t ivp_launch_bdf_strict(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 hipError_t ivp_launch_bdf_fast(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+// ... and the same source under __launch_bounds__(64, 2) for batches that over-subscribe the chip (see rk_bdf.hip)
+hipError_t ivp_launch_bdf_strict_occ2(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_bdf_fast_occ2(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);

@@ -8,6 +8,13 @@ gather of the end states / statistics.
 
 Two drivers, the same partitioning:
 
+What is gathered is the reference's ``Solution`` (src/solve/solution.rs:7-20), not only the end states: with
+``Options.t_eval`` the sampled trajectory (``y_eval`` / ``eval_idx`` / ``n_filled``) are members of the same arena (still
+ONE collective), and with ``log=True`` every accepted step of every trajectory (``Solution.t`` / ``Solution.y``, the
+"RCCL gather of sol.y" of BASELINE config C4) travels as a CSR log: the counts ride in the arena, the records in ONE
+second collective of the padded per-rank record buffers, and the offsets are re-based so that trajectory b's records are
+``t_log[log_offsets[b]:log_offsets[b+1]]`` in the ORIGINAL trajectory order on every rank.
+
 * ``solve_ivp_sharded``  one PROCESS per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI, "gloo" in the
   CPU tests).  Every rank's result arrays are views into ONE contiguous byte arena (``ResultArena``): the kernels write
   their results straight into it and the gather is a single ``all_gather_into_tensor`` of raw bytes -- no packing
@@ -45,17 +52,25 @@ def shard_bounds(B: int, world: int, rank: int):
 
 
 class ResultArena:
-    """End-state result arrays of ONE shard (capacity ``m`` trajectories, state dimension ``n``) as views into one
-    contiguous byte buffer.  ``solution()`` hands the views to ``solve_ivp_batch(out=...)`` so the kernels write into
-    the arena; ``split(gathered, counts)`` turns the gathered ``[world, nbytes]`` buffer back into arrays."""
+    """Result arrays of ONE shard (capacity ``m`` trajectories, state dimension ``n``) as views into one contiguous byte
+    buffer: the end-state members, with ``eval_rows`` > 0 also the t_eval samples (``y_eval [eval_rows, n, m]``,
+    ``eval_idx [eval_rows, m]``, ``n_filled [m]``) and with ``log_counts`` the accepted-step counts ``n_log [m]``.
+    ``solution()`` hands the views to ``solve_ivp_batch(out=...)`` so the kernels write into the arena;
+    ``split(gathered, counts)`` turns the gathered ``[world, nbytes]`` buffer back into arrays."""
 
-    def __init__(self, n: int, m: int, device):
+    def __init__(self, n: int, m: int, device, eval_rows: int = 0, log_counts: bool = False):
         import torch
-        self.n, self.m = int(n), int(m)
+        self.n, self.m, self.eval_rows = int(n), int(m), int(eval_rows)
         self.layout = []   # (name, torch dtype, rows, byte offset)
         off = 0
         tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}
-        for name, dt, rows in ARENA_FIELDS:
+        fields = list(ARENA_FIELDS)
+        if self.eval_rows > 0:
+            fields += [("y_eval", np.float64, self.eval_rows * self.n), ("eval_idx", np.int32, self.eval_rows), ("n_filled", np.int32, 1)]
+        if log_counts:
+            fields += [("n_log", np.int32, 1)]
+        self.fields = tuple(fields)
+        for name, dt, rows in self.fields:
             rows = self.n if rows is None else rows
             self.layout.append((name, tdt[dt], rows, off))
             off += np.dtype(dt).itemsize * rows * self.m
@@ -70,7 +85,10 @@ class ResultArena:
         for name, tdt, rows, off in self.layout:
             nb = tdt.itemsize * rows * self.m
             v = buf[off:off + nb].view(tdt)
-            out[name] = v.view(rows, self.m) if rows > 1 or name == "y_end" else v
+            if name == "y_eval":
+                out[name] = v.view(self.eval_rows, self.n, self.m)
+            else:
+                out[name] = v.view(rows, self.m) if rows > 1 or name in ("y_end", "eval_idx") else v
         return out
 
     def solution(self, count: Optional[int] = None) -> api.BatchSolution:
@@ -79,12 +97,16 @@ class ResultArena:
         assert count is None or count == self.m
         v = self.views
         return api.BatchSolution(y_end=v["y_end"], t_end=v["t_end"], status=v["status"], nfev=v["nfev"], nstep=v["nstep"],
-                                 naccpt=v["naccpt"], nrejct=v["nrejct"], h_next=v["h_next"])
+                                 naccpt=v["naccpt"], nrejct=v["nrejct"], h_next=v["h_next"], y_eval=v.get("y_eval"),
+                                 eval_idx=v.get("eval_idx"), n_filled=v.get("n_filled"), n_log=v.get("n_log"))
 
     def store(self, shard: dict, count: int) -> None:
-        """Copy a shard result (``count`` <= m trajectories; tensors or numpy arrays) into the arena's first columns."""
+        """Copy a shard result (``count`` <= m trajectories; tensors or numpy arrays) into the arena's first columns.
+        Members the shard result does not carry (an integrator without eval_idx, say) are left as they are."""
         import torch
         for name, tdt, rows, _ in self.layout:
+            if name not in shard or shard[name] is None:
+                continue
             src = shard[name]
             t = src if api._is_torch(src) else torch.as_tensor(np.ascontiguousarray(src))
             t = t.to(device=self.buf.device, dtype=tdt)
@@ -108,6 +130,8 @@ def _as_numpy(d: dict) -> dict:
         a = v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
         if k in ("nfev", "nstep", "naccpt", "nrejct"):
             a = a.astype(np.uint64)
+        if k == "n_log":
+            a = a.astype(np.uint32)
         out[k] = a
     return out
 
@@ -130,12 +154,19 @@ def _unpermute(out: dict, perm, B: int) -> dict:
 
 def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.ndarray], options: api.Options,
                       *, permutation: Optional[np.ndarray] = None, group=None, device=None,
-                      solve_fn: Optional[Callable] = None, gather: bool = True, as_numpy: bool = True) -> dict:
+                      solve_fn: Optional[Callable] = None, gather: bool = True, as_numpy: bool = True,
+                      log: bool = False) -> dict:
     """Integrate a batch held (replicated) as host arrays on every rank; returns the gathered result on every
     rank in the ORIGINAL trajectory order: y_end[n,B], t_end, h_next, status, nfev, nstep, naccpt, nrejct
-    (numpy arrays, or tensors on the gather device with ``as_numpy=False``).  With ``gather=False`` only this rank's
-    shard is returned (plus its index list).  A rank whose shard is empty (world > B) still takes part in the
-    collective."""
+    (numpy arrays, or tensors on the gather device with ``as_numpy=False``).  With ``options.t_eval`` also the sampled
+    trajectories ``y_eval [rows, n, B]``, ``eval_idx [rows, B]``, ``n_filled [B]`` (same collective); with ``log=True``
+    (t_eval must be None) also ``Solution.t`` / ``Solution.y`` of every trajectory as a CSR log -- ``n_log [B]``,
+    ``log_offsets [B + 1]``, ``t_log [total]``, ``y_log [total, n]`` -- moved by one more collective.
+    With ``gather=False`` only this rank's shard is returned (plus its index list).  A rank whose shard is empty
+    (world > B) still takes part in the collectives.
+    ``solve_fn(f, t0, t1, y0, params, options)`` (tests) returns a dict of the end-state members, plus ``y_eval`` /
+    ``n_filled`` (/ ``eval_idx``) when options.t_eval is set; it is called with ``log=True`` for the CSR log and then
+    also returns ``n_log``, ``t_log [total]``, ``y_log [total, n]`` of its shard."""
     import torch
     import torch.distributed as dist
 
@@ -162,50 +193,143 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
         dev = torch.device("cpu")
     tdev = dev if use_cuda else torch.device("cpu")
     m_max = shard_bounds(B, world, 0)[1] - shard_bounds(B, world, 0)[0]
-    arena = ResultArena(n, m_max, tdev)
+    if log and options.t_eval is not None:
+        raise ValueError("the accepted-step log is what solve_ivp records when t_eval is None")
+    eval_rows = 0 if options.t_eval is None else len(options.t_eval) + (1 if f.n_events() else 0)
+    arena = ResultArena(n, m_max, tdev, eval_rows=max(eval_rows, 1) if options.t_eval is not None else 0, log_counts=log)
+    if eval_rows:
+        arena.views["eval_idx"].fill_(-1)
 
+    dev_in = None
     if m > 0:
         if solve_fn is None:
             in_place = m == m_max and use_cuda and tdev == dev   # the kernels write straight into the arena
-            r = api.solve_ivp_batch(f, torch.as_tensor(sh_t0, device=dev) if sh_t0.size > 1 else float(sh_t0[0]),
-                                    torch.as_tensor(sh_t1, device=dev) if sh_t1.size > 1 else float(sh_t1[0]),
-                                    torch.as_tensor(sh_y0, device=dev),
-                                    None if sh_p is None else torch.as_tensor(sh_p, device=dev), options,
-                                    out=arena.solution() if in_place else None)
+            dev_in = (torch.as_tensor(sh_t0, device=dev) if sh_t0.size > 1 else float(sh_t0[0]),
+                      torch.as_tensor(sh_t1, device=dev) if sh_t1.size > 1 else float(sh_t1[0]),
+                      torch.as_tensor(sh_y0, device=dev), None if sh_p is None else torch.as_tensor(sh_p, device=dev))
+            # with log=True this is the COUNTING pass of the CSR log (n_log, end states and statistics are final after it)
+            opts1 = options if not log else api.Options(**{**{k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log")},
+                                                           "count_log": True})
+            r = api.solve_ivp_batch(f, *dev_in, opts1, out=arena.solution() if in_place else None)
             if not in_place:
-                arena.store({k: getattr(r, k) for k, *_ in ARENA_FIELDS}, m)
+                arena.store({k: getattr(r, k, None) for k, *_ in arena.fields}, m)
         else:
-            arena.store(solve_fn(f, sh_t0, sh_t1, sh_y0, sh_p, options), m)
+            shard_res = solve_fn(f, sh_t0, sh_t1, sh_y0, sh_p, options, log=True) if log else solve_fn(f, sh_t0, sh_t1, sh_y0, sh_p, options)
+            arena.store(shard_res, m)
     if not gather or world == 1:
         out = {k: v[..., :m] for k, v in arena.views.items()}
+        if log:
+            out.update(_local_csr_log(f, dev_in, options, solve_fn, locals().get("shard_res"), out["n_log"], n, tdev))
         if world == 1:
-            out = _unpermute(out, perm, B)
+            out = _unpermute_solution(out, perm, B)
             return _as_numpy(out) if as_numpy else out
         out = _as_numpy(out) if as_numpy else out
         out["index"] = idx
         return out
 
+    # ---- collective 1: the arena (end states, statistics, t_eval samples, step counts) ----
     gathered = torch.empty((world, arena.buf.numel()), dtype=torch.uint8, device=tdev)
     if backend == "gloo":   # gloo has no all_gather_into_tensor
         dist.all_gather(list(gathered.unbind(0)), arena.buf, group=group)
     else:
         dist.all_gather_into_tensor(gathered, arena.buf, group=group)
     counts = [shard_bounds(B, world, r_)[1] - shard_bounds(B, world, r_)[0] for r_ in range(world)]
-    out = _unpermute(arena.split(gathered, counts), perm, B)
+    out = arena.split(gathered, counts)
+    if log:
+        # ---- collective 2: the records.  Every rank knows every shard's counts now, hence the padded size ----
+        nl = out["n_log"].to(torch.int64)
+        bounds = np.cumsum([0] + counts)
+        totals = [int(nl[bounds[r_]:bounds[r_ + 1]].sum().item()) for r_ in range(world)]
+        cap = max(max(totals), 1)
+        mine = _local_csr_log(f, dev_in, options, solve_fn, locals().get("shard_res"), arena.views["n_log"][:m], n, tdev) if m > 0 else None
+        rec = torch.zeros(cap * (n + 1), dtype=torch.float64, device=tdev)     # [t_log | y_log], padded to the largest shard
+        if mine is not None:
+            tot = int(mine["t_log"].shape[0])
+            rec[:tot] = mine["t_log"]
+            rec[cap:cap + tot * n] = mine["y_log"].reshape(-1)
+        grec = torch.empty((world, rec.numel()), dtype=torch.float64, device=tdev)
+        if backend == "gloo":
+            dist.all_gather(list(grec.unbind(0)), rec, group=group)
+        else:
+            dist.all_gather_into_tensor(grec, rec, group=group)
+        out["t_log"] = torch.cat([grec[r_, :totals[r_]] for r_ in range(world)])
+        out["y_log"] = torch.cat([grec[r_, cap:cap + totals[r_] * n].view(totals[r_], n) for r_ in range(world)])
+        off = torch.zeros(B + 1, dtype=torch.int64, device=tdev)
+        torch.cumsum(nl, 0, out=off[1:])
+        out["log_offsets"] = off
+    out = _unpermute_solution(out, perm, B)
     return _as_numpy(out) if as_numpy else out
+
+
+def _local_csr_log(f, dev_in, options, solve_fn, shard_res, n_log, n, tdev) -> dict:
+    """This rank's records in its own (shard) order: the FILL pass of the CSR log on the HIP path (offsets from the
+    counting pass), or the arrays the injected integrator returned."""
+    import torch
+    if solve_fn is not None:
+        return {"t_log": torch.as_tensor(np.ascontiguousarray(shard_res["t_log"], dtype=np.float64)).to(tdev),
+                "y_log": torch.as_tensor(np.ascontiguousarray(shard_res["y_log"], dtype=np.float64)).reshape(-1, n).to(tdev)}
+    t0d, t1d, y0d, pd = dev_in
+    m = int(y0d.shape[1])
+    dev = y0d.device
+    offsets = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(n_log.to(device=dev, dtype=torch.int64), 0, out=offsets[1:])
+    total = int(offsets[-1].item())
+    base = {k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log", "profile")}
+    i64, i32 = torch.int64, torch.int32
+    out = api.BatchSolution(y_end=torch.zeros((n, m), dtype=torch.float64, device=dev), t_end=torch.zeros(m, dtype=torch.float64, device=dev),
+                            status=torch.zeros(m, dtype=i32, device=dev), nfev=torch.zeros(m, dtype=i64, device=dev),
+                            nstep=torch.zeros(m, dtype=i64, device=dev), naccpt=torch.zeros(m, dtype=i64, device=dev),
+                            nrejct=torch.zeros(m, dtype=i64, device=dev), h_next=torch.zeros(m, dtype=torch.float64, device=dev),
+                            n_log=torch.zeros(m, dtype=i32, device=dev),
+                            t_log=torch.empty(max(total, 1), dtype=torch.float64, device=dev),
+                            y_log=torch.empty((max(total, 1), n), dtype=torch.float64, device=dev), log_offsets=offsets)
+    api.solve_ivp_batch(f, t0d, t1d, y0d, pd, api.Options(**base), out=out)
+    return {"t_log": out.t_log[:total].to(tdev), "y_log": out.y_log[:total].to(tdev)}
+
+
+def _unpermute_solution(out: dict, perm, B: int) -> dict:
+    """Original trajectory order for every member: the SoA members by column, a CSR log record by record (shard
+    position q holds trajectory perm[q]; its records move to the slot its count earns in the original order)."""
+    csr = {k: out.pop(k) for k in ("t_log", "y_log", "log_offsets") if k in out}
+    res = _unpermute(out, perm, B)
+    if "t_log" in csr:
+        import torch
+        tl, yl = csr["t_log"], csr["y_log"]
+        dev = tl.device
+        permt = torch.as_tensor(np.asarray(perm), device=dev, dtype=torch.int64)
+        nl_orig = res["n_log"].to(torch.int64)                   # counts in original order
+        nl_shard = nl_orig[permt]                                # counts in shard order
+        off_shard = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nl_shard, 0, out=off_shard[1:])
+        off_orig = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nl_orig, 0, out=off_orig[1:])
+        total = int(off_shard[-1].item())
+        q = torch.repeat_interleave(torch.arange(B, device=dev), nl_shard)        # shard position of every record
+        k = torch.arange(total, device=dev) - off_shard[q]                       # its index within the trajectory
+        dest = off_orig[permt[q]] + k
+        t2, y2 = torch.empty_like(tl), torch.empty_like(yl)
+        t2[dest] = tl
+        y2[dest] = yl
+        res["t_log"], res["y_log"], res["log_offsets"] = t2, y2, off_orig
+    return res
 
 
 def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Options = None, *,
                           devices: Optional[Sequence[int]] = None, contexts: Optional[Sequence[api.Context]] = None,
-                          permutation: Optional[np.ndarray] = None, gather_device: Optional[int] = None) -> api.BatchSolution:
+                          permutation: Optional[np.ndarray] = None, gather_device: Optional[int] = None,
+                          log: bool = False) -> api.BatchSolution:
     """One process, one host thread, one context per entry of ``devices`` (``ivp_batch_solve_multi``): the batch is cut
     into ``len(devices)`` contiguous balanced shards (after ``permutation``), each integrated on its device, and the
-    end states are gathered with peer copies onto ``gather_device`` (default: the first device).  ``devices`` may name
-    the same GPU more than once (the degenerate single-GPU case).  End-state results only (no t_eval / logs)."""
+    results are gathered with peer copies onto ``gather_device`` (default: the first device).  ``devices`` may name
+    the same GPU more than once (the degenerate single-GPU case).  Gathered: the end states and statistics; with
+    ``options.t_eval`` the sampled trajectories (y_eval / eval_idx / n_filled); with ``log=True`` every accepted step
+    of every trajectory as a CSR log (n_log, log_offsets, t_log, y_log: two passes over the shards, count then fill)."""
     import torch
     options = options or api.Options()
-    if options.t_eval is not None or options.max_log or options.dense_output:
-        raise ValueError("solve_ivp_batch_multi gathers end states only")
+    if options.max_log or options.dense_output:
+        raise ValueError("solve_ivp_batch_multi gathers end states, t_eval samples and the CSR step log (log=True), not dense [max_log] buffers")
+    if log and options.t_eval is not None:
+        raise ValueError("the accepted-step log is what solve_ivp records when t_eval is None")
     devices = list(devices) if devices is not None else list(range(torch.cuda.device_count()))
     if not devices:
         raise RuntimeError("no HIP device")
@@ -233,10 +357,20 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
 
     world = len(devices)
     keep: list = []
-    copt = options._c(n, keep)
+    base_opts = {k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log")}
+    copt = (api.Options(**base_opts, count_log=True) if log else options)._c(n, keep)
     prob = api._problem_c(f)
     shards = (_lib.ShardT * world)()
     ptr = lambda a: None if a is None else C.c_void_p(a.data_ptr())
+    tdt = {np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}
+    eval_rows = 0 if options.t_eval is None else max(len(options.t_eval) + (1 if f.n_events() else 0), 1)
+    fields = list(ARENA_FIELDS)
+    if eval_rows:
+        fields += [("y_eval", np.float64, (eval_rows, n)), ("eval_idx", np.int32, (eval_rows,)), ("n_filled", np.int32, 1)]
+    if log:
+        fields += [("n_log", np.int32, 1)]
+    shape_of = lambda rows, cols: (n, cols) if rows is None else ((cols,) if rows == 1 else tuple(rows) + (cols,))
+    shard_res: list = [None] * world
     for k, d in enumerate(devices):
         lo, hi = shard_bounds(B, world, k)
         m = hi - lo
@@ -251,15 +385,14 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
         ys, ps = cut(y0), None if params is None else cut(params)
         a0 = cut(t0v) if api._is_torch(t0v) else torch.as_tensor([t0v], dtype=torch.float64, device=dev)
         a1 = cut(t1v) if api._is_torch(t1v) else torch.as_tensor([t1v], dtype=torch.float64, device=dev)
-        res = {name: torch.zeros((n, m) if rows is None else (m,), dtype={np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}[dt], device=dev)
-               for name, dt, rows in ARENA_FIELDS}
+        res = {name: torch.zeros(shape_of(rows, m), dtype=tdt[dt], device=dev) for name, dt, rows in fields}
+        shard_res[k] = res
         keep += [ys, ps, a0, a1, res]
         S.y0, S.params, S.t0, S.t0_len, S.t1, S.t1_len = ptr(ys), ptr(ps), ptr(a0), a0.numel(), ptr(a1), a1.numel()
         for name in res:
             setattr(S.out, name, ptr(res[name]))
         S.hip_stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    g = {name: torch.zeros((n, B) if rows is None else (B,), dtype={np.float64: torch.float64, np.int64: torch.int64, np.int32: torch.int32}[dt], device=home)
-         for name, dt, rows in ARENA_FIELDS}
+    g = {name: torch.zeros(shape_of(rows, B), dtype=tdt[dt], device=home) for name, dt, rows in fields}
     gathered = _lib.BatchResultT()
     for name in g:
         setattr(gathered, name, ptr(g[name]))
@@ -268,10 +401,42 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
     rc = contexts[0].lib.ivp_batch_solve_multi(shards, world, C.byref(prob), B, C.byref(copt), gdev, C.byref(gathered))
     if rc != 0:
         raise api.ConfigError(rc, contexts[0].last_error())
+    if log:
+        # the counting pass is done (end states, statistics and n_log are final and gathered); FILL pass: every shard gets
+        # CSR buffers of exactly its own record count, offsets starting at 0, and the library re-bases them in the gather
+        total_all = int(g["n_log"].to(torch.int64).sum().item())
+        for k, d in enumerate(devices):
+            res = shard_res[k]
+            if res is None:
+                continue
+            dev = torch.device("cuda", d)
+            m = int(res["n_log"].shape[0])
+            off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(res["n_log"].to(torch.int64), 0, out=off[1:])
+            tot = int(off[-1].item())
+            res["log_offsets"] = off
+            res["t_log"] = torch.empty(max(tot, 1), dtype=torch.float64, device=dev)
+            res["y_log"] = torch.empty((max(tot, 1), n), dtype=torch.float64, device=dev)
+            for name in ("log_offsets", "t_log", "y_log"):
+                setattr(shards[k].out, name, ptr(res[name]))
+        g["log_offsets"] = torch.zeros(B + 1, dtype=torch.int64, device=home)
+        g["t_log"] = torch.empty(max(total_all, 1), dtype=torch.float64, device=home)
+        g["y_log"] = torch.empty((max(total_all, 1), n), dtype=torch.float64, device=home)
+        for name in ("log_offsets", "t_log", "y_log"):
+            setattr(gathered, name, ptr(g[name]))
+        copt = api.Options(**base_opts)._c(n, keep)
+        for d in set(devices) | {gdev}:
+            torch.cuda.synchronize(d)
+        rc = contexts[0].lib.ivp_batch_solve_multi(shards, world, C.byref(prob), B, C.byref(copt), gdev, C.byref(gathered))
+        if rc != 0:
+            raise api.ConfigError(rc, contexts[0].last_error())
+        g["t_log"], g["y_log"] = g["t_log"][:total_all], g["y_log"][:total_all]
     if perm_t is not None:
-        g = _unpermute(g, permutation, B)
+        g = _unpermute_solution(g, permutation, B)
     return api.BatchSolution(y_end=g["y_end"], t_end=g["t_end"], status=g["status"], nfev=g["nfev"], nstep=g["nstep"],
-                             naccpt=g["naccpt"], nrejct=g["nrejct"], h_next=g["h_next"])
+                             naccpt=g["naccpt"], nrejct=g["nrejct"], h_next=g["h_next"], y_eval=g.get("y_eval"),
+                             eval_idx=g.get("eval_idx"), n_filled=g.get("n_filled"), n_log=g.get("n_log"),
+                             log_offsets=g.get("log_offsets"), t_log=g.get("t_log"), y_log=g.get("y_log"))
 
 
 class OverlappedGather:

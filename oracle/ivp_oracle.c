@@ -312,6 +312,18 @@ static void rhs_heat1d256(double t, const double *y, double *d, const double *p)
         d[i] = p[0] * (MS(left, 2.0, y[i]) + right);
     }
 }
+static void rhs_dense64(double t, const double *y, double *d, const double *p)
+{   /* y' = A y: a_ii = -k (4 + i mod 5), a_ij = ((i j + i + 2 j) mod 17 - 8) / 256 (kernel: RhsDense64 in rk_group.h) */
+    (void)t;
+    for (int i = 0; i < 64; i++) {
+        double s = -p[0] * (4.0 + (double)(i % 5)) * y[i];
+        for (int j = 0; j < 64; j++) {
+            double aij = (double)((i * j + i + 2 * j) % 17 - 8) * 0.00390625;
+            if (j != i) s = MA(s, aij, y[j]);
+        }
+        d[i] = s;
+    }
+}
 /* event functions: trait IVP::events (src/ivp.rs:31-40) */
 static void ev_y0(double x, const double *y, double *g, const double *p)
 {   /* tests/ivp.rs:157-159, examples/bouncing_ball.rs:17-19, tests/test_ivp.py:156-157 */
@@ -355,6 +367,7 @@ orc_ode_fn orc_builtin_rhs(int rhs_id, int *n_out, int *np_out)
     };
     if (rhs_id == ORC_RHS_LINEAR_DECAY_100) { if (n_out) *n_out = 100; if (np_out) *np_out = 0; return rhs_linear_decay100; }
     if (rhs_id == ORC_RHS_HEAT1D_256) { if (n_out) *n_out = 256; if (np_out) *np_out = 1; return rhs_heat1d256; }
+    if (rhs_id == ORC_RHS_DENSE_64) { if (n_out) *n_out = 64; if (np_out) *np_out = 1; return rhs_dense64; }
     if (rhs_id < 0 || rhs_id >= ORC_RHS_COUNT) return NULL;
     if (n_out) *n_out = tab[rhs_id].n;
     if (np_out) *np_out = tab[rhs_id].np;

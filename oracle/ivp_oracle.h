@@ -74,13 +74,14 @@ enum {
     ORC_RHS_COUNT = 16,
     /* large-n problems (wave-per-trajectory kernels on the GPU side) */
     ORC_RHS_LINEAR_DECAY_100 = 100, /* benches/benchmark.py:40-42,139-148             n=100 */
-    ORC_RHS_HEAT1D_256 = 101        /* y_i' = kappa (y_{i-1} - 2 y_i + y_{i+1}), p={kappa}  n=256 */
+    ORC_RHS_HEAT1D_256 = 101,       /* y_i' = kappa (y_{i-1} - 2 y_i + y_{i+1}), p={kappa}  n=256 */
+    ORC_RHS_DENSE_64 = 102          /* y' = A y, dense 64 x 64 (no reference counterpart: a full Jacobian for BDF's LU), p={k} */
 };
 
 typedef void (*orc_ode_fn)(double x, const double *y, double *dydx, const double *p);
 typedef void (*orc_event_fn)(double x, const double *y, double *g, const double *p);   /* IVP::events, src/ivp.rs:31-40 */
 typedef void (*orc_jac_fn)(double x, const double *y, double *jac, const double *p);   /* IVP::jac override, jac[row*n+col] */
-#define ORC_MAX_EVENTS 4
+#define ORC_MAX_EVENTS 16
 #define ORC_MAX_N 512   /* largest state dimension the fixed-size work arrays accept */
 
 typedef struct {

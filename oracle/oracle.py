@@ -18,9 +18,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 METHODS = {"RK23": 0, "DOPRI5": 1, "RK45": 1, "DOP853": 2, "RK4": 3, "BDF": 5}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
        "linear": 8, "robertson": 9, "vdp_eps": 10, "sho_ev": 11, "ball": 12, "cannon": 13, "rational_ev": 14,
-       "robertson_jac": 15, "linear_decay100": 100, "heat1d256": 101}
+       "robertson_jac": 15, "linear_decay100": 100, "heat1d256": 101, "dense64": 102}
 RHS_DIMS = {0: (1, 1), 1: (2, 0), 2: (2, 1), 3: (6, 1), 4: (3, 3), 5: (3, 0), 6: (2, 0), 7: (2, 0),
-            8: (2, 0), 9: (3, 0), 10: (2, 1), 11: (2, 0), 12: (2, 2), 13: (2, 0), 14: (2, 0), 15: (3, 0), 100: (100, 0), 101: (256, 1)}
+            8: (2, 0), 9: (3, 0), 10: (2, 1), 11: (2, 0), 12: (2, 2), 13: (2, 0), 14: (2, 0), 15: (3, 0), 100: (100, 0), 101: (256, 1), 102: (64, 1)}
 STATUS = ["Success", "UserInterrupt", "NeedLargerNMax", "StepSizeTooSmall", "ProbablyStiff",
           "SingularMatrix", "PoorConvergence"]
 
@@ -36,7 +36,7 @@ class _Options(C.Structure):
         ("has_max_step", C.c_int), ("max_step", C.c_double),
         ("dense_output", C.c_int),
         ("has_min_step", C.c_int), ("min_step", C.c_double),
-        ("events", C.c_void_p), ("n_events", C.c_int), ("ev_direction", C.c_int * 4), ("ev_terminal", C.c_uint64 * 4),
+        ("events", C.c_void_p), ("n_events", C.c_int), ("ev_direction", C.c_int * 16), ("ev_terminal", C.c_uint64 * 16),
         ("attempt_guard", C.c_uint64),
         ("has_settings", C.c_int), ("uround", C.c_double), ("safety_factor", C.c_double), ("scale_min", C.c_double),
         ("scale_max", C.c_double), ("beta", C.c_double), ("stiff_test", C.c_uint64),
@@ -61,8 +61,8 @@ class _Solution(C.Structure):
         ("has_dense", C.c_int), ("ncoef", C.c_int), ("n", C.c_int),
         ("nseg", C.c_size_t), ("seg_cont", C.POINTER(C.c_double)),
         ("seg_xold", C.POINTER(C.c_double)), ("seg_h", C.POINTER(C.c_double)),
-        ("n_events", C.c_int), ("ev_len", C.c_size_t * 4),
-        ("t_events", C.POINTER(C.c_double) * 4), ("y_events", C.POINTER(C.c_double) * 4),
+        ("n_events", C.c_int), ("ev_len", C.c_size_t * 16),
+        ("t_events", C.POINTER(C.c_double) * 16), ("y_events", C.POINTER(C.c_double) * 16),
     ]
 
 
@@ -170,9 +170,9 @@ class _OptHolder:
                 o.has_max_steps, o.max_steps = 1, (10_000 if m == 0 else 100_000)
         self.event_direction = list(event_direction or [])
         self.event_terminal = list(event_terminal or [])
-        for i, d in enumerate(self.event_direction[:4]):
+        for i, d in enumerate(self.event_direction[:16]):
             o.ev_direction[i] = int(d)
-        for i, t in enumerate(self.event_terminal[:4]):
+        for i, t in enumerate(self.event_terminal[:16]):
             o.ev_terminal[i] = int(t or 0)
         self.c = o
         self.method = m

@@ -27,18 +27,18 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("perm_in", VP), ("count_in", VP), ("perm_out", VP), ("count_out", VP),
         ("chunk", C.c_uint32),
         ("t_eval", VP), ("n_eval", C.c_int32),
-        ("y_eval", VP), ("eval_idx", VP), ("n_filled", VP), ("next_idx", VP),
+        ("y_eval", VP), ("eval_idx", VP), ("n_filled", VP), ("next_idx", VP), ("teval_off", VP), ("teval_extra", C.c_uint32),
         ("max_log", C.c_uint32),
         ("t_log", VP), ("y_log", VP), ("n_log", VP), ("t_last", VP), ("log_off", VP),
         ("collect_dense", C.c_int32),
         ("seg_cont", VP), ("seg_xold", VP), ("seg_h", VP), ("n_seg", VP),
-        ("ev_direction", C.c_int32 * 4), ("ev_terminal", C.c_uint32 * 4), ("max_events", C.c_uint32),
+        ("ev_direction", C.c_int32 * 4), ("ev_terminal", C.c_uint32 * 4), ("ev_direction_dev", VP), ("ev_terminal_dev", VP), ("max_events", C.c_uint32),
         ("t_events", VP), ("y_events", VP), ("n_ev", VP), ("prev_event", VP), ("t_term", VP),
         ("min_step", C.c_double), ("has_min_step", C.c_int32),
         ("bdf_d", VP), ("bdf_jac", VP), ("bdf_lu", VP), ("bdf_piv", VP), ("njev", VP), ("nlu", VP),
         ("err_flag", VP),
         ("slot_counter", VP),
-        ("spec_cap", C.c_uint32), ("lpw", C.c_uint32),
+        ("spec_cap", C.c_uint32), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
     ]
 
 

@@ -24,7 +24,7 @@ def test_c_client_compiles_links_and_runs_without_a_gpu(tmp_path):
     exe = _build(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
-    assert "abi v3 ok" in r.stdout or "device solve ok" in r.stdout
+    assert "abi v4 ok" in r.stdout or "device solve ok" in r.stdout
 
 
 @pytest.mark.gpu

@@ -386,3 +386,44 @@ __device__ double ode_comp(int i, double t, const double* y, const double* p)
         assert int(r.status[b]) == int(o.status)
         assert (int(r.nfev[b]), int(r.njev[b]), int(r.nlu[b]), int(r.naccpt[b]), int(r.nrejct[b])) == (o.nfev, o.njev, o.nlu, o.naccpt, o.nrejct), b
         assert np.array_equal(np.asarray(r.y_end)[:, b], o.y[-1]), b
+
+
+# ---- LDS-resident LU (BASELINE C5: "batched dense LU of per-trajectory Jacobians in LDS") ------------------------------
+
+def _dense64_batch(B, seed=12):
+    rng = np.random.default_rng(seed)
+    y0 = 1.0 + 0.5 * rng.standard_normal((64, B))
+    k = np.full((1, B), 3.0) * (1.0 + 0.2 * rng.uniform(-1, 1, (1, B)))
+    return y0, k
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_bdf_dense_64_state_system_lds_and_global_factors_bitexact_vs_oracle(fast):
+    """A FULL 64 x 64 Jacobian (every pivot step updates every trailing column) through BDF on the wave-per-trajectory
+    path: factors of (I - cJ) resident in LDS (variant 0 = default for n <= 128) and in global memory (variant 1) -- the
+    same lu_decomp / lin_solve code on two address spaces -- both bit-exact vs the oracle (src/matrix/lu.rs:37-125,
+    linear.rs:55-96), including njev / nlu, for chunk lengths that make the factors travel LDS -> memory -> LDS between
+    launches while they are still current."""
+    y0, k = _dense64_batch(7)
+    o = dict(method="BDF", rtol=1e-6, atol=1e-9)
+    ref = oracle_batch("dense64", y0, k, 0.0, 0.6, fma=fast, **o)
+    assert (ref["status"] == 0).all() and (ref["nlu"] > 3).all()
+    for variant in (0, 1):
+        for chunk in (0, 1, 5):
+            got = gpu_batch("dense64", y0, k, 0.0, 0.6, variant=variant, chunk=chunk, fast=fast, **o)
+            assert_bitexact(got, ref, f"dense64 BDF variant {variant} chunk {chunk}: ")
+    # and the explicit methods on the same system (wave-per-trajectory RK kernels)
+    for method in ("DOPRI5", "DOP853"):
+        ref = oracle_batch("dense64", y0, k, 0.0, 0.6, fma=fast, method=method, rtol=1e-7, atol=1e-10)
+        got = gpu_batch("dense64", y0, k, 0.0, 0.6, fast=fast, method=method, rtol=1e-7, atol=1e-10)
+        assert_bitexact(got, ref, f"dense64 {method}: ")
+
+
+def test_bdf_n100_lds_factors_equal_global_factors_and_the_oracle():
+    y0, p, t0, t1 = _decay_batch(9)
+    o = dict(method="BDF", rtol=1e-5, atol=1e-8)
+    ref = oracle_batch("linear_decay100", y0, p, t0, t1, **o)
+    for variant in (0, 1):
+        for chunk in (0, 7):
+            got = gpu_batch("linear_decay100", y0, p, t0, t1, variant=variant, chunk=chunk, **o)
+            assert_bitexact(got, ref, f"N=100 BDF variant {variant} chunk {chunk}: ")

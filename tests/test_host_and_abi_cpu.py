@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ivp_abi_version() == 3
+    assert lib.ivp_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header(lib):
@@ -144,6 +144,79 @@ def test_sharded_solve_and_gather_under_gloo_world_size_2(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+_WORKER_SOL = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from ivp_amd import workloads as W, distributed as D
+import ivp_amd
+from oracle import oracle as O
+
+KW = dict(method="DOPRI5", rtol=1e-6, atol=1e-9, detpow=True)
+
+def oracle_solve(f, t0, t1, y0, p, opt, log=False):      # the per-shard integrator of this CPU test
+    kw = dict(KW)
+    if opt.t_eval is not None:
+        kw["t_eval"] = np.asarray(opt.t_eval)
+    r = O.solve_batch("cr3bp", y0, p, t0, t1, **kw)
+    out = {{k: r[k] for k in ("y_end", "t_end", "h_next", "status", "nfev", "nstep", "naccpt", "nrejct")}}
+    if opt.t_eval is not None:
+        out["y_eval"], out["n_filled"] = r["y_eval"], r["n_filled"]
+    if log:
+        ts, ys = [], []
+        for b in range(y0.shape[1]):
+            s = O.solve_ivp("cr3bp", float(np.atleast_1d(t0)[0]), float(np.atleast_1d(t1)[0]), y0[:, b], params=p[:, b], **KW)
+            ts.append(s.t); ys.append(s.y)
+        out["n_log"] = np.array([len(t) for t in ts], dtype=np.int32)
+        out["t_log"] = np.concatenate(ts) if ts else np.zeros(0)
+        out["y_log"] = np.concatenate(ys) if ys else np.zeros((0, 6))
+    return out
+
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+B = 53                                         # odd: unequal shards
+y0, p, t0, _ = W.cr3bp_batch(B)
+perm = W.shard_permutation(B)
+te = np.linspace(0.0, 2.0, 6)
+# ---- t_eval samples ride in the same arena as the end states: ONE collective ----
+opt = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, t_eval=te)
+got = D.solve_ivp_sharded(ivp_amd.CR3BP(), t0, 2.0, y0, p, opt, permutation=perm, solve_fn=oracle_solve)
+ref = O.solve_batch("cr3bp", y0, p, t0, 2.0, t_eval=te, **KW)
+for k in ("y_end", "t_end", "status", "naccpt", "y_eval", "n_filled"):
+    assert np.array_equal(np.asarray(got[k]).astype(ref[k].dtype), ref[k]), k
+# ---- Solution.t / Solution.y of every trajectory: CSR log, counts in the arena + ONE collective of the records ----
+opt = ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9)
+got = D.solve_ivp_sharded(ivp_amd.CR3BP(), t0, 2.0, y0, p, opt, permutation=perm, solve_fn=oracle_solve, log=True)
+off = got["log_offsets"]
+assert off[0] == 0 and off[-1] == got["t_log"].shape[0] == int(got["n_log"].sum())
+for b in range(B):                             # ORIGINAL trajectory order, record for record
+    s = O.solve_ivp("cr3bp", t0, 2.0, y0[:, b], params=p[:, b], **KW)
+    assert np.array_equal(got["t_log"][off[b]:off[b + 1]], s.t) and np.array_equal(got["y_log"][off[b]:off[b + 1]], s.y), b
+# a batch smaller than the world: rank 1 has no records, still takes part in both collectives
+got1 = D.solve_ivp_sharded(ivp_amd.CR3BP(), t0, 2.0, y0[:, :1], p[:, :1], opt, solve_fn=oracle_solve, log=True)
+s = O.solve_ivp("cr3bp", t0, 2.0, y0[:, 0], params=p[:, 0], **KW)
+assert np.array_equal(got1["t_log"], s.t) and np.array_equal(got1["y_log"], s.y)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", sys.argv[1], "ok")
+"""
+
+
+def test_sharded_solution_gather_carries_t_eval_samples_and_the_csr_log_under_gloo(tmp_path):
+    """BASELINE C4 says "gather of sol.y": the reference's Solution.y is the whole sampled trajectory
+    (src/solve/solution.rs:7-20, src/solve/solout.rs:344-428).  World size 2 under gloo, unequal shards, fixed
+    permutation: t_eval samples and the accepted-step log of every trajectory arrive on every rank in the original
+    order and equal the oracle's records."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker_sol.py"
+    script.write_text(_WORKER_SOL.format(root=ROOT, port=port))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
