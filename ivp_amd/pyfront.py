@@ -13,6 +13,11 @@ The one thing that cannot carry over is a Python callable as right-hand side: th
   parameters ``p[k]`` (``args`` become ``p``), e.g. ``"dydx[0] = -p[0] * y[0];"``, or complete HIP definitions
   (anything containing ``__device__``) exactly as ``DeviceIVP`` takes them.
 
+The statement form works for any state dimension up to 512: above 8 states (one wavefront per trajectory, component
+form) it is wrapped so that the body is evaluated into a local vector and the requested component returned -- n times
+the arithmetic; for a large system whose components are cheap on their own define
+``__device__ double ode_comp(int i, double x, const double* y, const double* p)`` (and ``jac_col``) yourself.
+
 ``events`` (string form only; a built-in problem carries its own): one ``Event`` or a list of them, each a C
 expression of ``x``, ``y``, ``p`` whose sign changes are located, with the ``terminal`` / ``direction`` attributes the
 reference reads off the Python event functions (solve.rs:246-289).  ``jac``: a string with the statements filling
@@ -135,8 +140,17 @@ def _event_config(ev) -> api.EventConfig:
 
 
 def _device_problem(fun: str, n: int, args, events: list, jac, ctx) -> api.DeviceIVP:
-    src = fun if "__device__" in fun else (
-        "__device__ void ode(double x, const double* y, double* dydx, const double* p) {\n" + fun + "\n}\n")
+    if "__device__" in fun:
+        src = fun
+    elif n <= api.MAX_LANE_N:
+        src = "__device__ void ode(double x, const double* y, double* dydx, const double* p) {\n" + fun + "\n}\n"
+    else:
+        # more than 8 states: one wavefront per trajectory, the kernels ask for ONE component at a time.  The statement
+        # form still describes the whole right-hand side, so it is wrapped: evaluate the body into a local vector and
+        # return the requested entry (n times the arithmetic; write `__device__ double ode_comp(int i, ...)` yourself
+        # for a large system whose components are cheap to evaluate one by one)
+        src = ("__device__ double ode_comp(int ivp_i, double x, const double* y, const double* p) {\n"
+               f"  double dydx[{n}];\n" + fun + "\n  return dydx[ivp_i];\n}\n")
     if events:
         body = "\n".join(f"  g[{i}] = ({getattr(e, 'expr', e)});" for i, e in enumerate(events))
         src += "__device__ void events(double x, const double* y, double* g, const double* p) {\n" + body + "\n}\n"
@@ -151,8 +165,14 @@ def _device_problem(fun: str, n: int, args, events: list, jac, ctx) -> api.Devic
             jbody = "\n".join(f"  j[{r * n + c}] = {float(m[r, c])!r};" for r in range(n) for c in range(n))
         if "__device__" in jbody:
             src += jbody
-        else:
+        elif n <= api.MAX_LANE_N:
             src += "__device__ void jac(double x, const double* y, double* j, const double* p) {\n" + jbody + "\n}\n"
+        else:
+            # the wave-per-trajectory kernels take the Jacobian column by column: fill a local row-major matrix with the
+            # statement form and hand out the requested column
+            src += ("__device__ void jac_col(int ivp_c, double x, const double* y, double* column, const double* p) {\n"
+                    f"  double j[{n * n}];\n  for (int q = 0; q < {n * n}; ++q) j[q] = 0.0;\n" + jbody +
+                    f"\n  for (int r = 0; r < {n}; ++r) column[r] = j[r * {n} + ivp_c];\n}}\n")
     params = () if args is None else tuple(float(a) for a in (args if isinstance(args, (tuple, list)) else (args,)))
     return api.DeviceIVP(src, n, params, ctx=ctx, events=[_event_config(e) for e in events], jac=has_jac)
 
@@ -185,7 +205,10 @@ def solve_ivp(fun: Union[api.IVP, str], t_span, y0, method=None, t_eval=None, de
         else:
             # the explicit methods never call the Jacobian (the reference accepts and ignores it there)
             uses_jac = isinstance(method, str) and api.Method.from_str(method) == api.Method.BDF
-            problem = _device_problem(fun, y0v.size, args, ev, jac if uses_jac else None, ctx)
+            try:
+                problem = _device_problem(fun, y0v.size, args, ev, jac if uses_jac else None, ctx)
+            except api.IvpError as e:   # a snippet that does not compile surfaces like any other solver failure (solve.rs:216-221)
+                raise RuntimeError(f"Solver failed: {e}") from e
         has_events = events is not None
         constant_jac = jac is not None and not isinstance(jac, str)
     else:

@@ -351,3 +351,24 @@ def test_nine_args():
 
     ref = O.solve_ivp(fun, 0.0, 3.0, y0, params=list(A.ravel()), method="DOP853", rtol=1e-10, atol=1e-12, detpow=True)
     assert np.array_equal(res.t, ref.t) and np.array_equal(res.y.T, ref.y) and res.nfev == ref.nfev
+
+
+@pytest.mark.gpu
+def test_statement_form_with_more_than_eight_states_and_a_statement_jacobian():
+    """The statement form of `fun` (and of `jac`) for a 12-state system: wrapped into the component / column forms the
+    wave-per-trajectory kernels ask for.  RK45 and BDF agree with the closed form; a snippet that does not compile
+    surfaces as the reference's RuntimeError("Solver failed: ...") (src/python/solve.rs:216-221)."""
+    from ivp_amd.pyfront import solve_ivp
+    n = 12
+    body = "\n".join(f"dydx[{i}] = -p[0] * {i + 1}.0 * y[{i}];" for i in range(n))
+    jac = "\n".join(f"j[{i * n + i}] = -p[0] * {i + 1}.0;" for i in range(n))
+    y0 = np.linspace(1.0, 2.0, n)
+    exact = y0 * np.exp(-0.3 * np.arange(1, n + 1) * 2.0)
+    r = solve_ivp(body, (0.0, 2.0), y0, method="RK45", args=(0.3,), rtol=1e-8, atol=1e-10)
+    assert r.status == 0 and r.y.shape[0] == n
+    np.testing.assert_allclose(r.y[:, -1], exact, rtol=1e-6)
+    b = solve_ivp(body, (0.0, 2.0), y0, method="BDF", args=(0.3,), jac=jac, rtol=1e-7, atol=1e-10)
+    assert b.status == 0 and b.njev >= 1
+    np.testing.assert_allclose(b.y[:, -1], exact, rtol=1e-4)
+    with pytest.raises(RuntimeError, match="Solver failed"):
+        solve_ivp("dydx[0] = this does not compile;", (0.0, 1.0), np.ones(n), method="RK45")

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Launch-policy sweep: how far is the automatic policy from the best of the IVP_TUNE_* grid, problem by problem?
+
+  python tools/policy_sweep.py            driver: one child process per policy setting (the knobs are read once per
+                                          process), prints a table and writes profiles/r03_policy_sweep.json
+  python tools/policy_sweep.py --child    one setting (taken from the environment): JSON lines, one per case
+
+Cases: BASELINE C2 (100k CR3BP, DOPRI5) at rtol 1e-3 ... 1e-10, and the reference's own benchmark problems
+(/root/reference/benches/benchmark.py:100-148: Van der Pol mu = 1 on [0, 100], Lorenz on [0, 100], the N = 100 linear
+system) as batches.  Strict arithmetic; every number is the mean wall time of complete solves."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+
+GRID = [
+    ("auto", {}),
+    ("chunk32", {"IVP_TUNE_BULK_CHUNK": "32"}),
+    ("chunk128", {"IVP_TUNE_BULK_CHUNK": "128"}),
+    ("polls2", {"IVP_TUNE_LAUNCHES_PER_POLL": "2"}),
+    ("polls4", {"IVP_TUNE_LAUNCHES_PER_POLL": "4"}),
+    ("polls6", {"IVP_TUNE_LAUNCHES_PER_POLL": "6"}),
+    ("coopcap_half", {"IVP_TUNE_COOP_CAP_LANES": str(256 * 4 * 64)}),
+    ("coopcap_double", {"IVP_TUNE_COOP_CAP_LANES": str(4 * 256 * 4 * 64)}),
+    ("chunk32_polls6", {"IVP_TUNE_BULK_CHUNK": "32", "IVP_TUNE_LAUNCHES_PER_POLL": "6"}),
+]
+
+
+def cases():
+    import numpy as np
+    from ivp_amd import workloads as W
+    import ivp_amd
+    out = []
+    y0, p, t0, t1 = W.cr3bp_batch(100_000)
+    for rtol in (1e-3, 1e-4, 1e-6, 1e-8, 1e-10):
+        out.append((f"C2 CR3BP DOPRI5 rtol={rtol:g}", ivp_amd.CR3BP(), y0, p, t0, t1, dict(method="DOPRI5", rtol=rtol, atol=rtol * 1e-3)))
+    out.append(("C2 CR3BP DOP853 rtol=1e-10", ivp_amd.CR3BP(), y0, p, t0, t1, dict(method="DOP853", rtol=1e-10, atol=1e-13)))
+    rng = np.random.default_rng(1)
+    B = 100_000
+    yv = np.stack([2.0 * (1 + 0.05 * rng.standard_normal(B)), 0.05 * rng.standard_normal(B)])
+    mu = np.ones((1, B))
+    for m in ("RK45", "DOP853"):   # benchmark.py:106-115
+        out.append((f"VanDerPol mu=1 [0,100] {m} rtol=1e-6", ivp_amd.VanDerPol(), yv, mu, 0.0, 100.0, dict(method=m, rtol=1e-6, atol=1e-8)))
+    B = 20_000
+    yl = 1.0 + 0.01 * rng.standard_normal((3, B))
+    pl = np.repeat(np.array([[10.0], [28.0], [8.0 / 3.0]]), B, axis=1)
+    for m in ("RK45", "DOP853"):   # benchmark.py:128-137
+        out.append((f"Lorenz [0,100] {m} rtol=1e-8", ivp_amd.Lorenz(), yl, pl, 0.0, 100.0, dict(method=m, rtol=1e-8, atol=1e-10)))
+    yd = 1.0 + 0.3 * rng.standard_normal((100, 20_000))
+    out.append(("linear N=100 [0,10] RK45 rtol=1e-6", ivp_amd.LinearDecay100(), yd, None, 0.0, 10.0, dict(method="RK45", rtol=1e-6, atol=1e-8)))  # :139-148
+    return out
+
+
+def child():
+    import torch
+    import ivp_amd
+    dev = torch.device("cuda:0")
+    for name, prob, y0, p, t0, t1, o in cases():
+        y0d = torch.as_tensor(y0, device=dev)
+        pd = None if p is None else torch.as_tensor(p, device=dev)
+        opts = ivp_amd.Options(**o)
+        r = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts)
+        r = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, out=r)
+        torch.cuda.synchronize()
+        k = 4
+        t = time.perf_counter()
+        for _ in range(k):
+            r = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, out=r)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / k * 1e3
+        print(json.dumps({"case": name, "ms": ms, "accepted": int(r.naccpt.sum().item()), "ok": bool((r.status == 0).all().item())}), flush=True)
+
+
+def main():
+    if "--child" in sys.argv:
+        return child()
+    table = {}
+    for label, env in GRID:
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=e, capture_output=True, text=True, timeout=900)
+        if out.returncode != 0:
+            print(label, "FAILED", out.stderr[-500:], file=sys.stderr)
+            continue
+        for line in out.stdout.splitlines():
+            if line.startswith("{"):
+                j = json.loads(line)
+                table.setdefault(j["case"], {})[label] = j["ms"]
+        print("done", label, flush=True)
+    rows = []
+    for case, v in table.items():
+        best = min(v, key=v.get)
+        rows.append({"case": case, "auto_ms": v.get("auto"), "best": best, "best_ms": v[best], "auto_over_best": v.get("auto", float("nan")) / v[best], "all": v})
+        print(f"{case:45s} auto {v.get('auto', float('nan')):8.3f} ms   best {best:16s} {v[best]:8.3f} ms   auto/best {rows[-1]['auto_over_best']:.3f}")
+    path = os.path.join(ROOT, "gpurun_out", "policy_sweep.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump({"grid": [g[0] for g in GRID], "rows": rows}, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
