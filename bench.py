@@ -227,22 +227,28 @@ def main():
         gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         tflops = (attempts_per_launch * flop_per_attempt / (avg_launch_ms * 1e-3) / 1e12) if (avg_launch_ms > 0 and flop_per_attempt) else None
         traffic = traffic_src = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes_per_launch.json")
+        pmc_name = f"r03_pmc_hbm_bytes_per_launch_{args.fp}.json"
+        if not os.path.exists(os.path.join(ROOT, "profiles", pmc_name)) and args.fp == "strict":
+            pmc_name = "pmc_hbm_bytes_per_launch.json"          # round 2's pass (the strict kernels' traffic has not changed)
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc) and args.workload == "c2" and world == 1 and B == 100_000:
             try:
                 j = json.load(open(pmc))
                 traffic = j.get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_hbm_bytes_per_launch.json (" + str(j.get("run", "rocprofv3 --pmc passes of tools/profile_c2.sh")) + \
+                traffic_src = f"profiles/{pmc_name} (" + str(j.get("run", "rocprofv3 --pmc passes of tools/profile_c2.sh")) + \
                               "): PMC counters of a separate profiled run of this command, not of this process"
             except Exception:
                 traffic = None
         # VALU issue view of the dominant kernel: the thread-per-trajectory stepping kernel is bound by vector-instruction
         # issue (one wave64 FP64 instruction per 4 cycles per SIMD at best), not by bytes or by counted flops (strict mode
         # spends separate multiply and add instructions, 11 on a division, 18 on a square root).  Instructions per launch
-        # come from the committed SQ-counter profile of this command (profiles/r02_sq_counters_<workload>.json,
+        # come from the committed SQ-counter profile of this command (profiles/r03_sq_counters_<workload>_<fp>.json,
         # SQ_INSTS_VALU, tools/profile_sq.sh), the launch duration is this run's.
         issue = None
-        sqf = os.path.join(ROOT, "profiles", f"r02_sq_counters_{args.workload}.json")
+        sq_name = f"r03_sq_counters_{args.workload}_{args.fp}.json"
+        if not os.path.exists(os.path.join(ROOT, "profiles", sq_name)) and args.fp == "strict":
+            sq_name = f"r02_sq_counters_{args.workload}.json"
+        sqf = os.path.join(ROOT, "profiles", sq_name)
         chunk_launches = launches - coop_launches
         chunk_ms = (kern_ms - coop_ms) / max(chunk_launches, 1)
         if os.path.exists(sqf) and world == 1 and B == wl["B"] and chunk_ms > 0:
@@ -254,7 +260,7 @@ def main():
                 issue = {"bound": "valu_issue", "kernel": "chunk_kernel_t", "achieved": valu / (chunk_ms * 1e-3), "peak": peak,
                          "unit": "wave-instructions/s", "frac": valu / (chunk_ms * 1e-3) / peak, "valu_instructions_per_launch": valu,
                          "avg_launch_ms": chunk_ms,
-                         "source": f"profiles/r02_sq_counters_{args.workload}.json (SQ_INSTS_VALU per launch, separate rocprofv3 --pmc "
+                         "source": f"profiles/{sq_name} (SQ_INSTS_VALU per launch, separate rocprofv3 --pmc "
                                    "run of this command) / this run's launch duration"}
             except Exception:
                 issue = None

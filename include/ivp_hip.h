@@ -99,7 +99,7 @@ typedef enum {
      * BDF with the n x n matrices J and LU = (I - cJ) per trajectory (in LDS for n <= 128, see ivp_options_t.variant). */
     IVP_RHS_LINEAR_DECAY_100 = 100, /* y' = -y                            n=100 benches/benchmark.py:40-42,139-148 */
     IVP_RHS_HEAT1D_256 = 101,       /* y_i' = k (y_{i-1} - 2 y_i + y_{i+1}), p={k}  n=256 (method of lines)  */
-    IVP_RHS_DENSE_64 = 102,         /* y' = A y, A dense 64 x 64: a_ii = -k (4 + i mod 5), a_ij = ((i j + i + 2 j) mod 17 - 8) / 256,
+    IVP_RHS_DENSE_64 = 102,         /* y' = A y, A dense 64 x 64: a_ii = -k (4 + i mod 5), a_ij = (((5 i + 3 j) & 15) - 8) / 256,
                                        p={k}: a FULL Jacobian for the per-trajectory LU of BDF (n=64) */
     IVP_RHS_JIT = 1000    /* problem.jit holds a handle from ivp_rhs_compile() */
 } ivp_rhs_id_t;

@@ -277,7 +277,7 @@ class Heat1D256(IVP):
 
 @dataclass
 class Dense64(IVP):
-    """y' = A y with a dense, diagonally dominant 64 x 64 matrix (a_ii = -k (4 + i mod 5), a_ij = ((i j + i + 2 j) mod 17 - 8) / 256):
+    """y' = A y with a dense, diagonally dominant 64 x 64 matrix (a_ii = -k (4 + i mod 5), a_ij = (((5 i + 3 j) & 15) - 8) / 256):
     a full Jacobian for the per-trajectory LU of BDF on the wave-per-trajectory path."""
     k: float = 1.0
     rhs_id = 102; n = 64; n_params = 1

@@ -89,7 +89,7 @@ struct ivp_ctx {
     uint32_t one_wave_per_simd() const { return simds * (uint32_t)IVP_WAVE; }   // lanes that fill every SIMD with one wave
     std::string err;
     // scratch (device)
-    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, teval, teval_off, evcfg, tolvec, zero_off;
+    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, ran, teval, teval_off, evcfg, tolvec, zero_off;
     DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
     DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
     DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu, prev_event, sc_n_ev;
@@ -107,6 +107,7 @@ struct ivp_ctx {
         int method = 0, fp_mode = 0, variant = 0, profile = 0, n = 0;
         bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false, lds_lu_ok = false;
         uint32_t chunk = 64, lanes = 0;
+        uint32_t chunk_now = 64;    // attempts per bulk launch of the next round (adaptive: follows the decay of the active set)
         size_t B = 0;
         uint64_t c = 0;             // chunk launches so far
         bool spec = false;          // the last launch of the round in flight was a speculative cooperative one
@@ -228,6 +229,8 @@ struct DeviceGuard {
     ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
 
+constexpr uint32_t kMaxRanSlots = 1u << 16;   // profiled launches whose "did work" flag is recorded
+
 hipEvent_t pend_event(ivp_ctx *ctx)
 {
     ivp_ctx::Pending &P = ctx->pend;
@@ -308,7 +311,7 @@ int enqueue_round(ivp_ctx *ctx)
     // cooperative kernel then happens after 192 instead of 256 attempts (3.33 -> 3.25 ms); more polls cost ~40 us each
     const bool tail = P.adaptive && (use_coop || (fits_one_wave && !spec_ok));
     const int launches_per_sync = tail ? 1 : tune().launches_per_poll;
-    const uint32_t this_chunk = tail ? 1024u : P.chunk;
+    const uint32_t this_chunk = tail ? 1024u : P.chunk_now;
     // BDF (thread per trajectory): thin waves.  BASELINE C5's 10 000 trajectories are 157 full waves on a chip with 256 CUs.
     // A wave pays for the union of its lanes' control flow on every attempt, and (measured, MI355X) a wave that has its
     // CU to itself runs this branch-heavy kernel fastest: 10.95 ms with 64 lanes per wave (157 waves), 10.5 ms with 40
@@ -321,11 +324,25 @@ int enqueue_round(ivp_ctx *ctx)
         const uint32_t want = tune().bdf_lpw > 0 ? (uint32_t)tune().bdf_lpw : std::max(1u, (lanes + cus - 1u) / cus);
         lpw = std::min(64u, want);
     }
+    // Paired launches.  For a problem whose stragglers go to the lane-cooperative kernels, every bulk launch of a round
+    // is followed by a cooperative launch on the SAME input / output lists: the bulk one works while more than T
+    // trajectories are still running, the cooperative one once at most T are (T = two cooperative waves per SIMD); the
+    // decision is taken on the device from the active count, so the hand-over happens at the first LAUNCH boundary at
+    // which it pays (every `chunk` attempts), not at the next host poll (every 3 x chunk), and costs no poll at all.  A
+    // launch that declines returns at once (~3 us).  Results never depend on where the hand-over falls.
+    const bool paired = !tail && !use_coop && spec_ok;
+    const uint32_t pair_threshold = (uint32_t)(coop_cap / 8u);
+    auto ran_slot = [&]() -> uint32_t * {   // profiling: which launch of a pair did the work
+        if (!profile || !paired || P.step_ev.size() >= kMaxRanSlots) return nullptr;
+        return (uint32_t *)ctx->ran.p + P.step_ev.size();
+    };
     for (int r = 0; r < launches_per_sync; ++r, ++P.c) {
         const uint64_t c = P.c;
         IvpKArgs ka = P.a;
         ka.chunk = this_chunk;
         ka.lpw = lpw;
+        ka.spec_min = (paired && c > 0) ? pair_threshold : 0u;
+        ka.ran_out = ran_slot();
         // LDS-resident factors (bdf_group.h) cost occupancy: an 80 KB matrix leaves room for two wavefronts per CU instead of
         // four.  Measured (MI355X, profiles/r03_large_n_bdf_lds_vs_global.jsonl): while the active set fits two wavefronts per
         // CU the LDS form is 2-12 % faster (a pivot step waits for LDS, not for L2); beyond that a dense Jacobian still gains
@@ -348,31 +365,19 @@ int enqueue_round(ivp_ctx *ctx)
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
         LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, lanes, use_hoist, use_coop));
-        if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(use_coop ? 1 : 0); }
-        ctx->stats.launches += 1;
-        if (use_coop) ctx->stats.coop_launches += 1;
-    }
-    // Speculative hand-over: after a round of bulk launches the cooperative kernel is enqueued right away, sized for
-    // the largest set it may take; it does nothing unless the active count turned out small enough.  When it runs, the
-    // poll between the bulk and the tail of a batch (~40 us of host round trip) disappears.
-    P.spec = false;
-    if (!tail && !use_coop && spec_ok) {
-        const uint64_t c = P.c;
-        IvpKArgs ka = P.a;
-        ka.chunk = 1024u;
-        ka.spec_cap = (uint32_t)(coop_cap / 8u);
-        ka.perm_in = (const uint32_t *)ctx->perm[(c - 1) & 1].p;
-        ka.count_in = counts + ((c - 1) & 3);
-        ka.perm_out = (uint32_t *)ctx->perm[c & 1].p;
-        ka.count_out = counts + (c & 3);
-        if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
-        LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, std::min<uint32_t>(lanes, ka.spec_cap), false, true));
-        if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(1); }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 2, counts + ((c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // what the bulk left
-        P.c += 1;
-        P.spec = true;
+        if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back((use_coop ? 1 : 0) | (ka.ran_out ? 2 : 0)); }
+        if (!profile) { ctx->stats.launches += 1; if (use_coop) ctx->stats.coop_launches += 1; }   // with profile: counted from the ran flags
+        if (paired && c > 0) {   // the cooperative partner of this launch: same lists, the complementary condition
+            IvpKArgs kc = ka;
+            kc.chunk = 1024u;
+            kc.spec_min = 0u;
+            kc.spec_cap = pair_threshold;
+            kc.lpw = 0u;
+            kc.ran_out = ran_slot();
+            if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
+            LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, kc, std::min<uint32_t>(lanes, pair_threshold), false, true));
+            if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(1 | (kc.ran_out ? 2 : 0)); }
+        }
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((P.c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (!P.err_checked) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -391,19 +396,21 @@ int finish_round(ivp_ctx *ctx, int *done)
             return fail(ctx, IVP_ERR_INVALID_STEP_SIZE, "RK4: step size is zero or its sign does not match xend - x0 for at least one trajectory");
         }
     }
-    P.lanes = ctx->pinned[0];
-    if (P.spec) {
-        P.spec = false;
-        const uint32_t left_by_bulk = ctx->pinned[2];
-        if ((size_t)left_by_bulk * 8u > coop_cap_lanes(ctx)) {   // the speculative launch declined: nothing moved, its slot is reused
-            P.c -= 1;
-            P.lanes = left_by_bulk;
-            if (!P.step_is_coop.empty()) P.step_is_coop.back() = 0;   // its few microseconds count as plain stepping time
-        } else {
-            ctx->stats.launches += 1;
-            ctx->stats.coop_launches += 1;
+    // Chunk length from the observed decay of the active set: a round that retired (almost) nobody says that the
+    // trajectories are long compared with the chunk -- launch boundaries only cost (state round trip, launch gap, the
+    // wait for each launch's slowest wave), so the next round's launches run twice as many attempts (up to 256); as
+    // soon as a round retires a sizeable part of the set, compaction matters again and the chunk returns to its base.
+    {
+        const uint32_t before = P.lanes, after = ctx->pinned[0];
+        // (problems with a cooperative tail keep the base chunk: their hand-over happens at launch boundaries, and measured
+        // on C2 at rtol 1e-10 coarser boundaries cost 8 % where problems without one gain 3-5 %)
+        const bool has_coop_tail = P.coop_ok && P.variant == 0 && P.n >= 4 && !P.jit;
+        if (P.adaptive && !has_coop_tail) {
+            if ((uint64_t)after * 100u >= (uint64_t)before * 97u) P.chunk_now = std::min(P.chunk_now * 2u, std::max(P.chunk, 256u));
+            else if ((uint64_t)after * 2u < (uint64_t)before) P.chunk_now = P.chunk;
         }
     }
+    P.lanes = ctx->pinned[0];
     if (P.lanes != 0) return enqueue_round(ctx);
     P.active = false;
     *done = 1;
@@ -415,10 +422,20 @@ int finish_round(ivp_ctx *ctx, int *done)
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, P.ev_t0, P.ev_init1));
         ctx->stats.init_kernel_ms = ms;
-        for (size_t q = 0; q < P.step_ev.size(); ++q) {
+        // which launches did work (a launch of a (bulk, cooperative) pair that declined set no flag: its few microseconds
+        // count as stepping time of the kernel kind that ran, and it is not counted as a launch)
+        std::vector<uint32_t> ran(std::min(P.step_ev.size(), (size_t)kMaxRanSlots), 1u);
+        if (!ran.empty()) HIP_TRY(ctx, hipMemcpy(ran.data(), ctx->ran.p, ran.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < P.step_ev.size(); ++q) {   // step_is_coop: bit 0 = cooperative kernel, bit 1 = half of a pair (has a ran flag)
             HIP_TRY(ctx, hipEventElapsedTime(&ms, P.step_ev[q].first, P.step_ev[q].second));
+            const bool coop = (P.step_is_coop[q] & 1) != 0, flagged = (P.step_is_coop[q] & 2) != 0;
+            const bool did = !flagged || q >= ran.size() || ran[q] != 0;
             ctx->stats.step_kernel_ms += ms;
-            if (P.step_is_coop[q]) ctx->stats.coop_kernel_ms += ms;
+            if (coop) ctx->stats.coop_kernel_ms += ms;
+            if (did) {
+                ctx->stats.launches += 1;
+                if (coop) ctx->stats.coop_launches += 1;
+            }
         }
         HIP_TRY(ctx, hipEventElapsedTime(&ms, P.ev_t0, ev_end));
         ctx->stats.total_ms = ms;
@@ -487,7 +504,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->teval, &c->teval_off, &c->evcfg, &c->tolvec, &c->zero_off,
+    DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->ran, &c->teval, &c->teval_off, &c->evcfg, &c->tolvec, &c->zero_off,
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
@@ -755,6 +772,8 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         HIP_TRY(ctx, ctx->slot.reserve(2 * sizeof(unsigned long long)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->slot.p, 0, 2 * sizeof(unsigned long long), s));
         a.slot_counter = (unsigned long long *)ctx->slot.p;
+        HIP_TRY(ctx, ctx->ran.reserve(kMaxRanSlots * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ran.p, 0, kMaxRanSlots * sizeof(uint32_t), s));
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts.p, 0, sizeof(uint32_t) * 8, s));
     a.err_flag = (uint32_t *)ctx->counts.p + 4;
@@ -780,6 +799,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.coop_ok = !group && (opt->method == IVP_DOPRI5 || opt->method == IVP_DOP853);
     P.variant = (opt->variant == 3 && !P.coop_ok) ? 0 : opt->variant;
     P.chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : tune().bulk_chunk;
+    P.chunk_now = P.chunk;
     P.adaptive = opt->chunk_attempts == 0;
     P.B = B;
     P.lanes = (uint32_t)B;

@@ -115,6 +115,10 @@ struct IvpKArgs {
     // ---- speculative launch of the lane-cooperative kernel (rk_coop.h) ----
     uint32_t spec_cap;        // != 0: do nothing unless *count_in <= spec_cap (the host enqueued this launch before
                               // it knew the active count; it reads count_in afterwards to see which way it went)
+    uint32_t spec_min;        // thread-per-trajectory chunk kernels: != 0: do nothing unless the active count is > spec_min.
+                              // The launch loop enqueues (bulk launch with spec_min = T, cooperative launch with spec_cap = T)
+                              // PAIRS on the same input / output lists: exactly one of the two works, decided on the device
+    uint32_t *ran_out;        // profiling: a launch that did work sets *ran_out = 1 (which kernel of a pair ran)
     // ---- thin waves ----
     uint32_t lds_lu;          // large-n BDF (bdf_group.h): != 0 selects the kernels that keep the factors of (I - cJ) in LDS
     uint32_t lpw;             // trajectories per wavefront of a thread-per-trajectory chunk launch (0 = 64).  A wave executes the

@@ -238,6 +238,7 @@ __device__ __forceinline__ void coop_chunk_body(const IvpKArgs &a)
     const uint32_t count = a.perm_in ? *a.count_in : a.B;
     if (a.spec_cap && count > a.spec_cap) return;   // speculative launch declined: the set is still too large (uniform)
     if (blockIdx.x * 8u >= count) return;   // whole wave beyond the active set (stale grid bound)
+    if (a.ran_out && blockIdx.x == 0 && threadIdx.x == 0) *a.ran_out = 1u;
     const uint32_t i = blockIdx.x * 8u + (lane >> 3);
     const bool valid = i < count;
     uint32_t j = 0;

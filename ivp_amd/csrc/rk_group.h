@@ -51,7 +51,7 @@ struct RhsDense64 {          // y' = A y with a dense, diagonally dominant 64 x 
         double s = -p[0] * (4.0 + (double)(i % 5)) * y[i];
 #pragma unroll 8
         for (int j = 0; j < N; ++j) {
-            const double aij = (double)((i * j + i + 2 * j) % 17 - 8) * 0.00390625;   // / 256, exact
+            const double aij = (double)(((i * 5 + j * 3) & 15) - 8) * 0.00390625;   // in [-8, 7] / 256, exact
             if (j != i) s = IVP_MA(s, aij, y[j]);
         }
         return s;

@@ -313,12 +313,12 @@ static void rhs_heat1d256(double t, const double *y, double *d, const double *p)
     }
 }
 static void rhs_dense64(double t, const double *y, double *d, const double *p)
-{   /* y' = A y: a_ii = -k (4 + i mod 5), a_ij = ((i j + i + 2 j) mod 17 - 8) / 256 (kernel: RhsDense64 in rk_group.h) */
+{   /* y' = A y: a_ii = -k (4 + i mod 5), a_ij = (((5 i + 3 j) & 15) - 8) / 256 (kernel: RhsDense64 in rk_group.h) */
     (void)t;
     for (int i = 0; i < 64; i++) {
         double s = -p[0] * (4.0 + (double)(i % 5)) * y[i];
         for (int j = 0; j < 64; j++) {
-            double aij = (double)((i * j + i + 2 * j) % 17 - 8) * 0.00390625;
+            double aij = (double)(((i * 5 + j * 3) & 15) - 8) * 0.00390625;
             if (j != i) s = MA(s, aij, y[j]);
         }
         d[i] = s;

@@ -38,7 +38,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("bdf_d", VP), ("bdf_jac", VP), ("bdf_lu", VP), ("bdf_piv", VP), ("njev", VP), ("nlu", VP),
         ("err_flag", VP),
         ("slot_counter", VP),
-        ("spec_cap", C.c_uint32), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
+        ("spec_cap", C.c_uint32), ("spec_min", C.c_uint32), ("ran_out", VP), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
     ]
 
 

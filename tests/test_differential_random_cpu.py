@@ -93,15 +93,16 @@ def _same(a, b):
     return a.shape == b.shape and bool(((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))).all())
 
 
-def compare(solve, seed):
+def compare(solve, seed, fma=False):
+    """`fma`: the kernels' FMA arithmetic mode (solve must then run it: fast=True) against liboracle_fma.so."""
     rhs, y0, p, t0, t1, o, extra, chunk = random_case(seed)
-    tag = f"seed {seed}: {rhs} {o} chunk {chunk}: "
+    tag = f"seed {seed}{' [fma]' if fma else ''}: {rhs} {o} chunk {chunk}: "
     g = solve(rhs, y0, p, t0, t1, chunk=chunk, **o, **extra)
-    ref = oracle_batch(rhs, y0, p, t0, t1, **o)       # end states and counters of the whole batch
+    ref = oracle_batch(rhs, y0, p, t0, t1, fma=fma, **o)       # end states and counters of the whole batch
     assert_bitexact(g, ref, tag)
     B = y0.shape[1]
     for b in range(B):
-        s = O.solve_ivp(rhs, t0, t1, y0[:, b], params=() if p is None else tuple(p[:, b]), detpow=True, **o)
+        s = O.solve_ivp(rhs, t0, t1, y0[:, b], params=() if p is None else tuple(p[:, b]), detpow=True, fma=fma, **o)
         if "t_eval" in o:
             m = int(g["n_filled"][b])
             assert m == len(s.t), tag
@@ -128,3 +129,11 @@ def compare(solve, seed):
 def test_random_configurations_bitexact(block):
     for seed in range(1000 + 25 * block, 1000 + 25 * (block + 1)):
         compare(emul_batch, seed)
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_configurations_bitexact_in_fma_mode(block):
+    """The same random option combinations in the FMA arithmetic mode: host-compiled kernel bodies (-DIVP_FAST=1) vs
+    liboracle_fma.so, bit for bit."""
+    for seed in range(5000 + 25 * block, 5000 + 25 * (block + 1)):
+        compare(lambda *a, **kw: emul_batch(*a, fast=True, **kw), seed, fma=True)
