@@ -149,13 +149,16 @@ def main():
         y0d, pd = torch.as_tensor(y0, device=dev), torch.as_tensor(p, device=dev)
         t1d = torch.as_tensor(t1, device=dev) if np.ndim(t1) else t1
         opts = mk_opts(profile)
-        acc = dict(kern_ms=0.0, launches=0.0, slots=0.0, lane_launches=0.0, coop_ms=0.0, coop_launches=0.0)
+        acc = dict(kern_ms=0.0, launches=0.0, slots=0.0, lane_launches=0.0, coop_ms=0.0, coop_launches=0.0,
+                   decl=0.0, decl_coop=0.0, decl_ms=0.0, decl_coop_ms=0.0)
 
         def on_step(out):
             if profile:
                 st = out.stats
                 acc["kern_ms"] += st["step_kernel_ms"]; acc["launches"] += st["launches"]; acc["slots"] += st["lane_attempt_slots"]
                 acc["lane_launches"] += st["lane_launches"]; acc["coop_ms"] += st["coop_kernel_ms"]; acc["coop_launches"] += st["coop_launches"]
+                acc["decl"] += st["declined_launches"]; acc["decl_coop"] += st["declined_coop_launches"]
+                acc["decl_ms"] += st["declined_ms"]; acc["decl_coop_ms"] += st["declined_coop_ms"]
 
         el, out, og, _ = run_steps(lambda sol: ivp_amd.solve_ivp_batch(prob, 0.0, t1d, y0d, pd, opts, ctx, sol), n_state, m, dev,
                                    args.steps, args.warmup, gather=with_gather, d2h=with_d2h, on_step=on_step)
@@ -303,11 +306,18 @@ def main():
                 "kernel": wl["kernel"], "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": launches / args.steps,
                 # per kernel name, for a one-to-one check against the rocprofv3 --kernel-trace --stats rows
+                # (bulk, cooperative) launch PAIRS: exactly one launch of a pair works, its partner returns at once (~3 us).
+                # launches_per_step / avg_launch_ms are the working launches; *_incl_declined is what a kernel trace averages
+                # (rocprofv3 --stats counts the declined partner launches as calls of the same kernel)
                 "per_kernel": {
                     "chunk_kernel_t": {"launches_per_step": (launches - coop_launches) / args.steps,
-                                       "avg_launch_ms": (kern_ms - coop_ms) / max(launches - coop_launches, 1)},
+                                       "avg_launch_ms": (kern_ms - coop_ms - (acc["decl_ms"] - acc["decl_coop_ms"])) / max(launches - coop_launches, 1),
+                                       "calls_per_step_incl_declined": (launches - coop_launches + acc["decl"] - acc["decl_coop"]) / args.steps,
+                                       "avg_call_ms_incl_declined": (kern_ms - coop_ms) / max(launches - coop_launches + acc["decl"] - acc["decl_coop"], 1)},
                     "coop_chunk_kernel": {"launches_per_step": coop_launches / args.steps,
-                                          "avg_launch_ms": (coop_ms / coop_launches) if coop_launches else None},
+                                          "avg_launch_ms": ((coop_ms - acc["decl_coop_ms"]) / coop_launches) if coop_launches else None,
+                                          "calls_per_step_incl_declined": (coop_launches + acc["decl_coop"]) / args.steps,
+                                          "avg_call_ms_incl_declined": (coop_ms / (coop_launches + acc["decl_coop"])) if (coop_launches + acc["decl_coop"]) else None},
                 },
                 "note": "state is device-resident: HBM traffic is per trajectory per launch, not per step; "
                         "this fraction is informational, the binding resource is FP64 VALU issue (roofline_fp64)",

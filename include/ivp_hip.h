@@ -254,6 +254,11 @@ typedef struct {
     uint64_t lane_launches;     /* sum over launches of trajectories that loaded + stored their state */
     uint32_t coop_launches;     /* of `launches`: lane-cooperative tail launches (variant 3 / auto policy) */
     double coop_kernel_ms;      /* of `step_kernel_ms`: time in those launches                            */
+    /* ABI v4: (bulk, cooperative) launch pairs -- exactly one launch of a pair works, the other returns at once */
+    uint32_t declined_launches;      /* pair halves that declined (not counted in `launches`)            */
+    uint32_t declined_coop_launches; /* of those: cooperative-kernel halves                              */
+    double declined_ms;              /* their HIP-event durations (included in step_kernel_ms)           */
+    double declined_coop_ms;         /* of that: cooperative-kernel halves (included in coop_kernel_ms)  */
 } ivp_run_stats_t;
 
 typedef struct ivp_ctx ivp_ctx_t;

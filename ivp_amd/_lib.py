@@ -64,6 +64,7 @@ class RunStatsT(C.Structure):
         ("step_kernel_ms", C.c_double), ("init_kernel_ms", C.c_double), ("total_ms", C.c_double),
         ("total_accepted", C.c_uint64), ("total_attempts", C.c_uint64), ("lane_attempt_slots", C.c_uint64),
         ("lane_launches", C.c_uint64), ("coop_launches", C.c_uint32), ("coop_kernel_ms", C.c_double),
+        ("declined_launches", C.c_uint32), ("declined_coop_launches", C.c_uint32), ("declined_ms", C.c_double), ("declined_coop_ms", C.c_double),
     ]
 
 

@@ -144,10 +144,10 @@ IVP_HD void bdf_change_d_generic(double (&d)[8][N], int order, double factor)
                     double ru = 0.0;
 #pragma unroll
                     for (int m = 0; m < 6; ++m)
-                        if (m < size && r[k][m] != 0.0) ru += r[k][m] * u[m];
+                        if (m < size && r[k][m] != 0.0) ru = IVP_MA(ru, r[k][m], u[m]);
                     if (ru != 0.0) {
 #pragma unroll
-                        for (int c = 0; c < N; ++c) scratch[row][c] += ru * d[k][c];
+                        for (int c = 0; c < N; ++c) scratch[row][c] = IVP_MA(scratch[row][c], ru, d[k][c]);
                     }
                 }
             }
@@ -246,7 +246,7 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
         for (int k = 1; k < 6; ++k)
 #pragma unroll
             for (int row = 1; row < 6; ++row)
-                if (m <= row) ru[k][row] = ru[k][row] + r[k][m] * U.v[m][row];
+                if (m <= row) ru[k][row] = IVP_MA(ru[k][row], r[k][m], U.v[m][row]);
 #pragma unroll
     for (int k = 1; k < 6; ++k)
 #pragma unroll
@@ -263,7 +263,7 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
 #pragma unroll
         for (int row = 1; row < 6; ++row)
 #pragma unroll
-            for (int c = 0; c < N; ++c) scratch[row][c] = scratch[row][c] + ru[k][row] * d[k][c];
+            for (int c = 0; c < N; ++c) scratch[row][c] = IVP_MA(scratch[row][c], ru[k][row], d[k][c]);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
         if (i <= order) {
@@ -311,7 +311,7 @@ IVP_HD bool bdf_lu_decomp(double (&a)[N][N], uint32_t &piv)
                     if (m == i) { const double tmp = a[i][j]; a[i][j] = a[k][j]; a[k][j] = tmp; }
                 if (tj != 0.0) {
 #pragma unroll
-                    for (int i = k + 1; i < N; ++i) a[i][j] += a[i][k] * tj;
+                    for (int i = k + 1; i < N; ++i) a[i][j] = IVP_MA(a[i][j], a[i][k], tj);
                 }
             }
         }
@@ -332,14 +332,14 @@ IVP_HD void bdf_lin_solve(const double (&a)[N][N], double (&b)[N], uint32_t piv)
         for (int i = k + 1; i < N; ++i)
             if (m == i) { const double t = b[i]; b[i] = b[k]; b[k] = t; }
 #pragma unroll
-        for (int i = k + 1; i < N; ++i) b[i] += a[i][k] * b[k];
+        for (int i = k + 1; i < N; ++i) b[i] = IVP_MA(b[i], a[i][k], b[k]);
     }
 #pragma unroll
     for (int kb = 1; kb < N; ++kb) {
         const int k = N - kb;
         b[k] /= a[k][k];
 #pragma unroll
-        for (int i = 0; i < k; ++i) b[i] += a[i][k] * -b[k];
+        for (int i = 0; i < k; ++i) b[i] = IVP_MA(b[i], a[i][k], -b[k]);
     }
     b[0] /= a[0][0];
 }
@@ -568,7 +568,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        scale[i] = a.atol[i] + a.rtol[i] * fabs(y_predict[i]);
+        scale[i] = IVP_MA(a.atol[i], a.rtol[i], fabs(y_predict[i]));
         if (scale[i] == 0.0) scale[i] = EPS;
     }
     const double alpha_o = bdf_sel6(T.alpha, order);
@@ -576,7 +576,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     for (int i = 0; i < N; ++i) {
         double sacc = 0.0;
 #pragma unroll
-        for (int jj = 1; jj < 6; ++jj) if (jj <= order) sacc += T.gamma[jj] * S.d[jj][i];
+        for (int jj = 1; jj < 6; ++jj) if (jj <= order) sacc = IVP_MA(sacc, T.gamma[jj], S.d[jj][i]);
         psi[i] = sacc / alpha_o;
     }
     const double c = h_signed / alpha_o;
@@ -587,7 +587,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         for (int r = 0; r < N; ++r) {
 #pragma unroll
             for (int ci = 0; ci < N; ++ci) S.lu[r][ci] = -c * S.jac[r][ci];
-            S.lu[r][r] += 1.0;
+            S.lu[r][r] = IVP_MA(1.0, -c, S.jac[r][r]);   // (I - cJ)'s diagonal: -c j + 1
         }
         S.d_nlu += 1;
         if (bdf_lu_decomp<N>(S.lu, S.piv)) { lu_current = true; S.current_c = c; }
@@ -624,7 +624,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         R::ode(x_new, y_new, rhs, L.p);
         S.d_nfev += 1;
 #pragma unroll
-        for (int i = 0; i < N; ++i) rhs[i] = c * rhs[i] - psi[i] - delta[i];
+        for (int i = 0; i < N; ++i) rhs[i] = IVP_MB(c, rhs[i], psi[i]) - delta[i];
         bdf_lin_solve<N>(S.lu, rhs, S.piv);
         const double dy_norm = bdf_wrms<N>(rhs, scale);
         const bool have = has_prev && dy_norm_prev > 0.0;
@@ -660,7 +660,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     const double safety = 0.9 * (2.0 * (double)newton_maxiter + 1.0) / (2.0 * (double)newton_maxiter + (double)(iters + 1));
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        scale[i] = a.atol[i] + a.rtol[i] * fabs(y_new[i]);
+        scale[i] = IVP_MA(a.atol[i], a.rtol[i], fabs(y_new[i]));
         if (scale[i] == 0.0) scale[i] = EPS;
     }
     const double ec_o = bdf_sel6(T.error_const, order);

@@ -225,7 +225,7 @@ struct BdfG {
 #pragma unroll
                     for (int b = 0; b < JB; ++b) {
                         const double v = is_m[c] ? q.akj[b] : q.cur[b][c];   // row m receives row k's entry (the swap)
-                        const double w = v + mult[c] * q.tj[b];
+                        const double w = IVP_MA(v, mult[c], q.tj[b]);
                         const double v2 = (upd[b] && below[c]) ? w : v;
                         const double out = is_k[c] ? q.tj[b] : v2;
                         if (act[b] && ((c + 1) * G <= NT || in_range[c])) a[(size_t)jc[b] * NT + gi(c)] = out;
@@ -308,7 +308,7 @@ struct BdfG {
                 const int i = gi(c);
                 if (i > k && i < NT) {
                     const double bi = (i == m) ? bk_old : b[i];
-                    b[i] = bi + ccur[c] * t;
+                    b[i] = IVP_MA(bi, ccur[c], t);
                 }
             }
             __syncthreads();
@@ -335,7 +335,7 @@ struct BdfG {
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = gi(c);
-                if (i < k) b[i] += ccur[c] * -bk;
+                if (i < k) b[i] = IVP_MA(b[i], ccur[c], -bk);
             }
             __syncthreads();
         }
@@ -547,7 +547,7 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
     }
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        scale[i] = NormOps<GR>::atol(a, i) + NormOps<GR>::rtol(a, i) * fabs(y_predict[i]);
+        scale[i] = IVP_MA(NormOps<GR>::atol(a, i), NormOps<GR>::rtol(a, i), fabs(y_predict[i]));
         if (scale[i] == 0.0) scale[i] = EPS;
     }
     const double alpha_o = bdf_sel6(T.alpha, order);
@@ -555,7 +555,7 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
     for (int i = 0; i < C; ++i) {
         double sacc = 0.0;
 #pragma unroll
-        for (int jj = 1; jj < 6; ++jj) if (jj <= order) sacc += T.gamma[jj] * S.d[jj][i];
+        for (int jj = 1; jj < 6; ++jj) if (jj <= order) sacc = IVP_MA(sacc, T.gamma[jj], S.d[jj][i]);
         psi[i] = sacc / alpha_o;
     }
     const double c = h_signed / alpha_o;
@@ -568,8 +568,8 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
             for (int cc = 0; cc < C; ++cc) {
                 const int r = BG::gi(cc);
                 if (r < BG::NT) {
-                    double v = -c * jac[(size_t)col * BG::NT + r];
-                    if (r == col) v += 1.0;
+                    const double jv = jac[(size_t)col * BG::NT + r];
+                    const double v = r == col ? IVP_MA(1.0, -c, jv) : -c * jv;   // (I - cJ): the diagonal is -c j + 1
                     lu[(size_t)col * BG::NT + r] = v;
                 }
             }
@@ -599,7 +599,7 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
         GR::ode(x_new, y_new, rhs, L.p);
         S.d_nfev += 1;
 #pragma unroll
-        for (int i = 0; i < C; ++i) rhs[i] = c * rhs[i] - psi[i] - delta[i];
+        for (int i = 0; i < C; ++i) rhs[i] = IVP_MB(c, rhs[i], psi[i]) - delta[i];
         BG::lin_solve(lu, piv, rhs);
         const double dy_norm = BG::wrms(rhs, scale);
         bool rate_condition = false;
@@ -643,7 +643,7 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
     const double safety = 0.9 * (2.0 * (double)newton_maxiter + 1.0) / (2.0 * (double)newton_maxiter + (double)(iters + 1));
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        scale[i] = NormOps<GR>::atol(a, i) + NormOps<GR>::rtol(a, i) * fabs(y_new[i]);
+        scale[i] = IVP_MA(NormOps<GR>::atol(a, i), NormOps<GR>::rtol(a, i), fabs(y_new[i]));
         if (scale[i] == 0.0) scale[i] = EPS;
     }
     const double ec_o = bdf_sel6(T.error_const, order);

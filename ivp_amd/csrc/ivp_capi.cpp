@@ -108,6 +108,7 @@ struct ivp_ctx {
         bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false, lds_lu_ok = false;
         uint32_t chunk = 64, lanes = 0;
         uint32_t chunk_now = 64;    // attempts per bulk launch of the next round (adaptive: follows the decay of the active set)
+        uint32_t quiet_rounds = 0;  // consecutive rounds that retired (almost) nobody
         size_t B = 0;
         uint64_t c = 0;             // chunk launches so far
         bool spec = false;          // the last launch of the round in flight was a speculative cooperative one
@@ -396,18 +397,23 @@ int finish_round(ivp_ctx *ctx, int *done)
             return fail(ctx, IVP_ERR_INVALID_STEP_SIZE, "RK4: step size is zero or its sign does not match xend - x0 for at least one trajectory");
         }
     }
-    // Chunk length from the observed decay of the active set: a round that retired (almost) nobody says that the
+    // Chunk length from the observed decay of the active set: two rounds in a row that retired nobody (< 1 %) say that the
     // trajectories are long compared with the chunk -- launch boundaries only cost (state round trip, launch gap, the
     // wait for each launch's slowest wave), so the next round's launches run twice as many attempts (up to 256); as
-    // soon as a round retires a sizeable part of the set, compaction matters again and the chunk returns to its base.
+    // soon as trajectories start to retire (> 3 % in a round), compaction matters again and the chunk returns to its base.
     {
         const uint32_t before = P.lanes, after = ctx->pinned[0];
         // (problems with a cooperative tail keep the base chunk: their hand-over happens at launch boundaries, and measured
         // on C2 at rtol 1e-10 coarser boundaries cost 8 % where problems without one gain 3-5 %)
         const bool has_coop_tail = P.coop_ok && P.variant == 0 && P.n >= 4 && !P.jit;
         if (P.adaptive && !has_coop_tail) {
-            if ((uint64_t)after * 100u >= (uint64_t)before * 97u) P.chunk_now = std::min(P.chunk_now * 2u, std::max(P.chunk, 256u));
-            else if ((uint64_t)after * 2u < (uint64_t)before) P.chunk_now = P.chunk;
+            if ((uint64_t)after * 100u >= (uint64_t)before * 99u) {
+                P.quiet_rounds += 1;
+                if (P.quiet_rounds >= 2) P.chunk_now = std::min(P.chunk_now * 2u, std::max(P.chunk, 256u));   // two quiet rounds in a row
+            } else {
+                P.quiet_rounds = 0;
+                if ((uint64_t)after * 100u < (uint64_t)before * 97u) P.chunk_now = P.chunk;
+            }
         }
     }
     P.lanes = ctx->pinned[0];
@@ -435,6 +441,10 @@ int finish_round(ivp_ctx *ctx, int *done)
             if (did) {
                 ctx->stats.launches += 1;
                 if (coop) ctx->stats.coop_launches += 1;
+            } else {
+                ctx->stats.declined_launches += 1;
+                ctx->stats.declined_ms += ms;
+                if (coop) { ctx->stats.declined_coop_launches += 1; ctx->stats.declined_coop_ms += ms; }
             }
         }
         HIP_TRY(ctx, hipEventElapsedTime(&ms, P.ev_t0, ev_end));
@@ -800,6 +810,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.variant = (opt->variant == 3 && !P.coop_ok) ? 0 : opt->variant;
     P.chunk = opt->chunk_attempts > 0 ? (uint32_t)opt->chunk_attempts : tune().bulk_chunk;
     P.chunk_now = P.chunk;
+    P.quiet_rounds = 0;
     P.adaptive = opt->chunk_attempts == 0;
     P.B = B;
     P.lanes = (uint32_t)B;

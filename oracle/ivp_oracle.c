@@ -1362,7 +1362,7 @@ static int lu_decomp(double *a, int *ip, int n)
             double tj = a[m * n + j];
             if (m != k) { double tmp = a[m * n + j]; a[m * n + j] = a[k * n + j]; a[k * n + j] = tmp; }
             if (tj != 0.0)
-                for (int i = k + 1; i < n; i++) a[i * n + j] += a[i * n + k] * tj;
+                for (int i = k + 1; i < n; i++) a[i * n + j] = MA(a[i * n + j], a[i * n + k], tj);
         }
     }
     if (a[(n - 1) * n + (n - 1)] == 0.0) return -1;
@@ -1374,12 +1374,12 @@ static void lin_solve(const double *a, double *b, const int *ip, int n)
     for (int k = 0; k < n - 1; k++) {
         int m = ip[k];
         double t = b[m]; b[m] = b[k]; b[k] = t;
-        for (int i = k + 1; i < n; i++) b[i] += a[i * n + k] * b[k];
+        for (int i = k + 1; i < n; i++) b[i] = MA(b[i], a[i * n + k], b[k]);
     }
     for (int kb = 1; kb < n; kb++) {
         int k = n - kb;
         b[k] /= a[k * n + k];
-        for (int i = 0; i < k; i++) b[i] += a[i * n + k] * -b[k];
+        for (int i = 0; i < k; i++) b[i] = MA(b[i], a[i * n + k], -b[k]);
     }
     b[0] /= a[0];
 }
@@ -1448,7 +1448,7 @@ static void change_d(double *d /* [8][n] */, int n, int order, double factor)
         for (int k = 0; k < size; k++) {
             double coeff = r[i][k];
             if (coeff == 0.0) continue;
-            for (int j = 0; j < size; j++) ru[i][j] += coeff * u[k][j];
+            for (int j = 0; j < size; j++) ru[i][j] = MA(ru[i][j], coeff, u[k][j]);
         }
     double scratch[6][ORC_MAX_N];
     for (int row = 0; row <= order; row++) {
@@ -1456,7 +1456,7 @@ static void change_d(double *d /* [8][n] */, int n, int order, double factor)
         for (int k = 0; k <= order; k++) {
             double coeff = ru[k][row];
             if (coeff == 0.0) continue;
-            for (int i = 0; i < n; i++) scratch[row][i] += coeff * d[k * n + i];
+            for (int i = 0; i < n; i++) scratch[row][i] = MA(scratch[row][i], coeff, d[k * n + i]);
         }
     }
     for (int i = 0; i <= order; i++) memcpy(d + (size_t)i * n, scratch[i], (size_t)n * sizeof(double));
@@ -1561,19 +1561,19 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
             y_predict[i] = sum;
         }
         for (int i = 0; i < n; i++) {
-            scale[i] = tol_at(atol, i) + tol_at(rtol, i) * fabs(y_predict[i]);
+            scale[i] = MA(tol_at(atol, i), tol_at(rtol, i), fabs(y_predict[i]));
             if (scale[i] == 0.0) scale[i] = EPS;
         }
         for (int i = 0; i < n; i++) {
             double sacc = 0.0;
-            for (int j = 1; j <= order; j++) sacc += gamma[j] * d[j * n + i];
+            for (int j = 1; j <= order; j++) sacc = MA(sacc, gamma[j], d[j * n + i]);
             psi[i] = sacc / alpha[order];
         }
         const double c = h_signed / alpha[order];
         if (!lu_is_current || fabs(c - current_c) / fmax(fabs(c), 1.0) > 0.1) {
             for (int r = 0; r < n; r++) {
                 for (int ci = 0; ci < n; ci++) lu[r * n + ci] = -c * jac[r * n + ci];
-                lu[r * n + r] += 1.0;
+                lu[r * n + r] = MA(1.0, -c, jac[r * n + r]);   /* -c j + 1 */
             }
             nlu += 1;
             if (lu_decomp(lu, pivot, n) == 0) { lu_is_current = 1; current_c = c; }
@@ -1591,7 +1591,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
         while (iters < newton_maxiter) {
             f(x_new, y_new, rhs, p);
             nfev += 1;
-            for (int i = 0; i < n; i++) rhs[i] = c * rhs[i] - psi[i] - delta[i];
+            for (int i = 0; i < n; i++) rhs[i] = MB(c, rhs[i], psi[i]) - delta[i];
             lin_solve(lu, rhs, pivot, n);
             double dy_norm = wrms_scaled(rhs, scale, n);
             int rate_condition = 0;
@@ -1627,7 +1627,7 @@ static int bdf_solve(orc_ode_fn f, const double *p, int n, double x0, const doub
         const double safety = SAFETY_DEFAULT * (2.0 * (double)newton_maxiter + 1.0)
                             / (2.0 * (double)newton_maxiter + (double)(iters + 1));
         for (int i = 0; i < n; i++) {
-            scale[i] = tol_at(atol, i) + tol_at(rtol, i) * fabs(y_new[i]);
+            scale[i] = MA(tol_at(atol, i), tol_at(rtol, i), fabs(y_new[i]));
             if (scale[i] == 0.0) scale[i] = EPS;
         }
         for (int i = 0; i < n; i++) rhs[i] = error_const[order] * delta[i];

@@ -158,13 +158,14 @@ def test_nan_interval_retires_the_lane(method):
     assert np.array_equal(g["y_end"][:, :2], r["y_end"])
 
 
-def test_bdf_change_d_structured_equals_the_literal_form():
+@pytest.mark.parametrize("fast", [False, True])
+def test_bdf_change_d_structured_equals_the_literal_form(fast):
     """bdf_change_d exploits the structure of U = compute_r(order, 1) and of R's first row / column (bdf_core.h); the
     literal restatement of bdf.rs:669-732 stays in the header as bdf_change_d_generic.  Same bits on random and on
     adversarial inputs: factors that zero an R entry, signed zeros / infinities / NaNs in D, non-finite factors."""
     import ctypes as C
     from tests.host_emul import emul
-    lib = emul.lib()
+    lib = emul.lib(fast)      # fast: the FMA arithmetic mode (the multiply-add sites of both forms are fused)
     lib.emul_change_d.argtypes = [C.c_int, C.c_int, C.c_double] + [np.ctypeslib.ndpointer(np.float64, flags="C")] * 3
     lib.emul_change_d.restype = C.c_int
     rng = np.random.default_rng(20260207)

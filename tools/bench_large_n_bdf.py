@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Batched large-n BDF: factors of (I - cJ) resident in LDS (variant 0, default for n <= 128) vs in global memory
-(variant 1), 1 ... 20k systems per batch.  Prints one JSON line per (problem, batch size).
+"""Batched large-n BDF: factors of (I - cJ) resident in LDS (variant 2) vs in global memory (variant 1) vs the automatic
+per-launch choice (variant 0: LDS while the active set fits two wavefronts per CU), 1 ... 20k systems per batch.
+Prints one JSON line per (problem, batch size).
   python tools/bench_large_n_bdf.py > gpurun_out/large_n_bdf.jsonl"""
 import json
 import os
@@ -20,7 +21,7 @@ def run(prob, name, y0, p, t1, opts, reps):
     pd = None if p is None else torch.as_tensor(p, device=dev)
     out = {}
     ref = None
-    for label, variant in (("lds", 0), ("global", 1)):
+    for label, variant in (("lds", 2), ("global", 1), ("auto", 0)):
         o = ivp_amd.Options(variant=variant, **opts)
         r = ivp_amd.solve_ivp_batch(prob, 0.0, t1, y0d, pd, o)
         torch.cuda.synchronize()

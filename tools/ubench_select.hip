@@ -66,6 +66,12 @@ __global__ __launch_bounds__(64) void k_bench(double *out, double seed)
             REP8(asm volatile("v_lshl_add_u64 %0, %0, 0, %2\n v_mov_b64 %1, %2\n v_lshl_add_u64 %0, %0, 0, %2\n v_mov_b64 %1, %2" : "+v"(a), "+v"(d) : "v"(b));)
         } else if constexpr (K == 22) {  // divergent region: saveexec, cbranch_execz (not taken), body, restore
             REP8(asm volatile("v_cmp_neq_f64 vcc, 0, %1\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 1\n v_and_b32 %0, %0, %0\n s_or_b64 exec, exec, s[20:21]" : "+v"(u) : "v"(a) : "vcc", "s20", "s21", "scc");)
+        } else if constexpr (K == 23) {  // one compare -> vcc, six v_cndmask in VOP3 ENCODING that read vcc, one filler
+            REP8(asm volatile("v_cmp_neq_f64 vcc, 0, %3\n v_cndmask_b32_e64 %0, %0, %2, vcc\n v_cndmask_b32_e64 %1, %1, %2, vcc\n v_cndmask_b32_e64 %0, %0, %2, vcc\n v_cndmask_b32_e64 %1, %1, %2, vcc\n v_cndmask_b32_e64 %0, %0, %2, vcc\n v_cndmask_b32_e64 %1, %1, %2, vcc\n v_and_b32 %2, %2, %2" : "+v"(u), "+v"(v), "+v"(w) : "v"(a) : "vcc");)
+        } else if constexpr (K == 24) {  // one compare -> SGPR pair, six v_cndmask_e64 on that pair, one filler
+            REP8(asm volatile("v_cmp_neq_f64_e64 s[20:21], 0, %3\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_and_b32 %2, %2, %2" : "+v"(u), "+v"(v), "+v"(w) : "v"(a) : "s20", "s21");)
+        } else if constexpr (K == 25) {  // one compare -> vcc, copy to an SGPR pair (s_mov_b64), six v_cndmask_e64 on the copy
+            REP8(asm volatile("v_cmp_neq_f64 vcc, 0, %3\n s_mov_b64 s[20:21], vcc\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_and_b32 %2, %2, %2" : "+v"(u), "+v"(v), "+v"(w) : "v"(a) : "vcc", "s20", "s21");)
         }
     }
     if (a + d + u + v == 12345.678) out[threadIdx.x] = a + d + u + v;
@@ -85,6 +91,8 @@ int main()
         {"v_fma_f64 inline constant", k_bench<14>}, {"s_mov_b32 literal", k_bench<15>}, {"taken s_branch + skipped nop", k_bench<16>},
         {"cmp + 2 cndmask + and (x4 per 32)", k_bench<17>}, {"cmp + 6 cndmask + and (x8 per 32)", k_bench<18>}, {"writelane/readlane", k_bench<19>},
         {"div_scale/rcp/div_fmas/div_fixup", k_bench<20>}, {"v_lshl_add_u64 / v_mov_b64", k_bench<21>}, {"divergent region (5 instr per 32/8)", k_bench<22>},
+        {"cmp->vcc + 6 cndmask_e64 vcc + and", k_bench<23>}, {"cmp->sgpr + 6 cndmask_e64 sgpr + and", k_bench<24>},
+        {"cmp->vcc, s_mov, 6 cndmask_e64 sgpr", k_bench<25>},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
