@@ -259,6 +259,8 @@ def main():
                 sq = json.load(open(sqf))
                 ent = next(v for k, v in sq.items() if "chunk_kernel_t" in k and "coop" not in k)
                 valu = float(ent["mean_per_dispatch"]["SQ_INSTS_VALU"])
+                if "per_solve" in ent:   # instructions of a whole solve / this run's launches per solve: robust against a
+                    valu = float(ent["per_solve"]["SQ_INSTS_VALU"]) / max(chunk_launches / args.steps, 1e-9)   # different cut into launches
                 peak = 256 * 4 * 2.4e9 / 4.0   # SIMDs x (clock / 4 cycles per wave64 instruction), at the 2.4 GHz peak clock
                 issue = {"bound": "valu_issue", "kernel": "chunk_kernel_t", "achieved": valu / (chunk_ms * 1e-3), "peak": peak,
                          "unit": "wave-instructions/s", "frac": valu / (chunk_ms * 1e-3) / peak, "valu_instructions_per_launch": valu,

@@ -397,8 +397,9 @@ int finish_round(ivp_ctx *ctx, int *done)
             return fail(ctx, IVP_ERR_INVALID_STEP_SIZE, "RK4: step size is zero or its sign does not match xend - x0 for at least one trajectory");
         }
     }
-    // Chunk length from the observed decay of the active set: two rounds in a row that retired nobody (< 1 %) say that the
-    // trajectories are long compared with the chunk -- launch boundaries only cost (state round trip, launch gap, the
+    // Chunk length from the observed decay of the active set: three rounds in a row that retired nobody (< 1 %) say that the
+    // trajectories are long compared with the chunk (two were not enough for BASELINE C3, whose retirements start right
+    // after 384 attempts: the doubled round then cost 3 %) -- launch boundaries only cost (state round trip, launch gap, the
     // wait for each launch's slowest wave), so the next round's launches run twice as many attempts (up to 256); as
     // soon as trajectories start to retire (> 3 % in a round), compaction matters again and the chunk returns to its base.
     {
@@ -409,7 +410,7 @@ int finish_round(ivp_ctx *ctx, int *done)
         if (P.adaptive && !has_coop_tail) {
             if ((uint64_t)after * 100u >= (uint64_t)before * 99u) {
                 P.quiet_rounds += 1;
-                if (P.quiet_rounds >= 2) P.chunk_now = std::min(P.chunk_now * 2u, std::max(P.chunk, 256u));   // two quiet rounds in a row
+                if (P.quiet_rounds >= 3) P.chunk_now = std::min(P.chunk_now * 2u, std::max(P.chunk, 256u));   // three quiet rounds in a row
             } else {
                 P.quiet_rounds = 0;
                 if ((uint64_t)after * 100u < (uint64_t)before * 97u) P.chunk_now = P.chunk;

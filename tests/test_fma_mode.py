@@ -237,3 +237,35 @@ def test_fma_c2_full_size_all_100k_trajectories_bitexact():
     eg = np.abs(g["y_end"][:, :n].T - truth).max(axis=1)
     er = np.abs(ref["y_end"].T - truth).max(axis=1)
     assert np.median(eg) <= 10.0 * np.median(er) and eg.max() <= 10.0 * er.max()     # BASELINE's accuracy bar
+
+
+VDP_SRC = r"""
+__device__ void ode(double t, const double* y, double* d, const double* p)
+{
+    d[0] = y[1];
+    d[1] = p[0] * (1.0 - y[0] * y[0]) * y[1] - y[0];
+}
+"""
+
+
+@gpu
+@pytest.mark.parametrize("method", ["DOPRI5", "DOP853", "RK23", "BDF"])
+def test_fma_mode_with_a_user_right_hand_side_is_the_integrator_fused_and_the_snippet_as_written(method):
+    """hiprtc problems in FMA mode: the integrator's multiply-add sites are fused, the user's code is compiled without
+    contraction and evaluated as written.  The oracle's FMA build driven with the same right-hand side as a Python
+    callable (plain IEEE double arithmetic = the snippet as written) reproduces it bit for bit."""
+    import ivp_amd
+    f = ivp_amd.DeviceIVP(VDP_SRC, n=2, params=(1.5,))
+    rng = np.random.default_rng(9)
+    y0 = np.stack([2.0 + 0.1 * rng.standard_normal(4), 0.1 * rng.standard_normal(4)])
+    mu = np.full((1, 4), 1.5)
+    o = dict(method=method, rtol=1e-6, atol=1e-9)
+    r = ivp_amd.solve_ivp_batch(f, 0.0, 6.0, y0, mu, ivp_amd.Options(fp_mode=ivp_amd.FpMode.FMA, **o))
+    fun = lambda t, y, p: [y[1], p[0] * (1.0 - y[0] * y[0]) * y[1] - y[0]]
+    for b in range(4):
+        s = O.solve_ivp(fun, 0.0, 6.0, list(y0[:, b]), params=[1.5], fma=True, **o)
+        assert int(r.status[b]) == s.status == 0
+        assert np.array_equal(r.y_end[:, b], s.y[-1]) and int(r.naccpt[b]) == s.naccpt and int(r.nfev[b]) == s.nfev, (method, b)
+    # ... and it differs from the built-in problem's FMA form (whose right-hand side is fused as well) only at rounding level
+    rb = ivp_amd.solve_ivp_batch(ivp_amd.VanDerPol(), 0.0, 6.0, y0, mu, ivp_amd.Options(fp_mode=ivp_amd.FpMode.FMA, **o))
+    assert np.abs(np.asarray(rb.y_end) - np.asarray(r.y_end)).max() < 1e-6

@@ -8,6 +8,7 @@ import csv, json, sys
 from collections import defaultdict
 
 src, out = sys.argv[1:3]
+solves = int(sys.argv[3]) if len(sys.argv) > 3 else None   # complete solves the profiled command ran (bench.py: 3 passes x (steps + warmup))
 acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(src)):
     acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -17,6 +18,9 @@ for k, cs in acc.items():
         continue
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     e = {"dispatches": len(next(iter(cs.values()))), "mean_per_dispatch": m}
+    if solves:
+        e["profiled_solves"] = solves
+        e["per_solve"] = {c: sum(v) / solves for c, v in cs.items()}
     if m.get("SQ_WAVES"):
         e["valu_insts_per_wave"] = m.get("SQ_INSTS_VALU", 0.0) / m["SQ_WAVES"]
         e["salu_insts_per_wave"] = m.get("SQ_INSTS_SALU", 0.0) / m["SQ_WAVES"]

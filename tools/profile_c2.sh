@@ -19,4 +19,4 @@ python3 $R/tools/pmc_hbm.py $O/calib_fetch_counter_collection.csv $O/calib_write
 ls $O | head -40
 # SQ counters (their own pass): instructions per wave and where the wave cycles go
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o bench_sq -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fast --fp $FP > $O/b3.log 2>&1; echo b3 rc=$?
-python3 $R/tools/pmc_sq.py $O/bench_sq_counter_collection.csv $O/sq_counters_c2.json > $O/sq.log 2>&1; echo sq rc=$?
+python3 $R/tools/pmc_sq.py $O/bench_sq_counter_collection.csv $O/sq_counters_c2.json 21 > $O/sq.log 2>&1; echo sq rc=$?   # 3 passes x (5 + 2) solves
