@@ -119,6 +119,7 @@ struct ivp_ctx {
         hipEvent_t ev_t0 = nullptr, ev_init1 = nullptr;
         std::vector<std::pair<hipEvent_t, hipEvent_t>> step_ev;
         std::vector<char> step_is_coop;
+        std::vector<uint32_t> step_lanes;   // active count the host knew when it enqueued the launch (profiling trace)
     } pend;
 };
 
@@ -222,6 +223,8 @@ struct Tune {
 };
 const Tune &tune() { static const Tune t; return t; }
 // lanes (8 per trajectory) up to which the lane-cooperative kernels take over: two cooperative waves per SIMD
+// IVP_TRACE_LAUNCHES=1 with Options.profile: one stderr line per stepping-kernel launch (kind, ran / declined, duration)
+bool trace_launches() { static const bool on = getenv("IVP_TRACE_LAUNCHES") != nullptr; return on; }
 size_t coop_cap_lanes(const ivp_ctx *ctx) { return tune().coop_cap_lanes ? tune().coop_cap_lanes : 2u * (size_t)ctx->one_wave_per_simd(); }
 // restores the caller's current HIP device when a multi-device entry point returns
 struct DeviceGuard {
@@ -366,7 +369,7 @@ int enqueue_round(ivp_ctx *ctx)
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
         LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, lanes, use_hoist, use_coop));
-        if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back((use_coop ? 1 : 0) | (ka.ran_out ? 2 : 0)); }
+        if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back((use_coop ? 1 : 0) | (ka.ran_out ? 2 : 0)); P.step_lanes.push_back(lanes); }
         if (!profile) { ctx->stats.launches += 1; if (use_coop) ctx->stats.coop_launches += 1; }   // with profile: counted from the ran flags
         if (paired && c > 0) {   // the cooperative partner of this launch: same lists, the complementary condition
             IvpKArgs kc = ka;
@@ -377,7 +380,7 @@ int enqueue_round(ivp_ctx *ctx)
             kc.ran_out = ran_slot();
             if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
             LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, kc, std::min<uint32_t>(lanes, pair_threshold), false, true));
-            if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(1 | (kc.ran_out ? 2 : 0)); }
+            if (profile) { e1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e1, s)); P.step_ev.emplace_back(e0, e1); P.step_is_coop.push_back(1 | (kc.ran_out ? 2 : 0)); P.step_lanes.push_back(lanes); }
         }
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((P.c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -437,6 +440,7 @@ int finish_round(ivp_ctx *ctx, int *done)
             HIP_TRY(ctx, hipEventElapsedTime(&ms, P.step_ev[q].first, P.step_ev[q].second));
             const bool coop = (P.step_is_coop[q] & 1) != 0, flagged = (P.step_is_coop[q] & 2) != 0;
             const bool did = !flagged || q >= ran.size() || ran[q] != 0;
+            if (trace_launches()) fprintf(stderr, "ivp launch %3zu  %-4s %-8s lanes<=%-8u %8.4f ms\n", q, coop ? "coop" : "bulk", did ? "ran" : "declined", P.step_lanes[q], ms);
             ctx->stats.step_kernel_ms += ms;
             if (coop) ctx->stats.coop_kernel_ms += ms;
             if (did) {
@@ -821,6 +825,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.ev_used = 0;
     P.step_ev.clear();
     P.step_is_coop.clear();
+    P.step_lanes.clear();
     if (!P.round_done) HIP_TRY(ctx, hipEventCreateWithFlags(&P.round_done, hipEventDisableTiming));
 
     // ---- init: f0, hinit / first_step, initial SolOut call ----
