@@ -209,6 +209,7 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
 struct Tune {
     size_t coop_cap_lanes = 0;       // lanes (8 per trajectory) up to which the lane-cooperative kernels take over; 0 = two waves per SIMD of the device
     uint32_t bulk_chunk = 64;        // attempts per bulk launch
+    int window = 1;                  // windowed bulk launches (IvpKArgs.window): 1 = automatic, 0 = never, 2 = also for systems with fewer than four components
     int launches_per_poll = 3;       // bulk launches between two host polls
     int lds_lu = 1;                  // large-n BDF: 0 = never keep the factors in LDS
     int bdf_lpw = 0;                 // trajectories per wave of the BDF chunk launches: 0 = auto (spread the active set over the SIMDs)
@@ -216,6 +217,7 @@ struct Tune {
     {
         if (const char *e = getenv("IVP_TUNE_COOP_CAP_LANES")) coop_cap_lanes = (size_t)strtoull(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BULK_CHUNK")) bulk_chunk = (uint32_t)std::max(1l, strtol(e, nullptr, 10));
+        if (const char *e = getenv("IVP_TUNE_WINDOW")) window = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_LDS_LU")) lds_lu = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BDF_LPW")) bdf_lpw = (int)std::min(64l, std::max(0l, strtol(e, nullptr, 10)));
         if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10)));
@@ -314,7 +316,7 @@ int enqueue_round(ivp_ctx *ctx)
     // three short launches per poll: measured on C2 (attempts per trajectory peak at 160-200) the hand-over to the
     // cooperative kernel then happens after 192 instead of 256 attempts (3.33 -> 3.25 ms); more polls cost ~40 us each
     const bool tail = P.adaptive && (use_coop || (fits_one_wave && !spec_ok));
-    const int launches_per_sync = tail ? 1 : tune().launches_per_poll;
+    int launches_per_sync = tail ? 1 : tune().launches_per_poll;
     const uint32_t this_chunk = tail ? 1024u : P.chunk_now;
     // BDF (thread per trajectory): thin waves.  BASELINE C5's 10 000 trajectories are 157 full waves on a chip with 256 CUs.
     // A wave pays for the union of its lanes' control flow on every attempt, and (measured, MI355X) a wave that has its
@@ -327,6 +329,20 @@ int enqueue_round(ivp_ctx *ctx)
         const uint32_t cus = ctx->cus;
         const uint32_t want = tune().bdf_lpw > 0 ? (uint32_t)tune().bdf_lpw : std::max(1u, (lanes + cus - 1u) / cus);
         lpw = std::min(64u, want);
+    }
+    // Windowed bulk launches (IvpKArgs.window).  A thread-per-trajectory wave of a system with four or more components keeps
+    // the f64 pipe of its SIMD busy on its own (measured, BASELINE C2: 3.75-4.1 us per attempt alone, 7.5 us for each of two
+    // waves that share a SIMD), so a launch lasts ceil(waves / SIMDs) wave-rounds whether its last round is full or not:
+    // C2's 1563 waves on 1024 SIMDs take as long as 2048 would.  When the last round would be less than ~80 % full the
+    // launch therefore works on whole rounds only -- the first `window` entries of the list -- and the waves behind them
+    // pass their entries on; those land first in the output list, so every trajectory is at most one launch behind.
+    // Results never depend on how attempts are cut into launches.
+    uint32_t window = 0;
+    if (tune().window && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && (P.n >= 4 || tune().window == 2)) {
+        const uint32_t full = lanes / kOneWavePerSimd;
+        if (full >= 1 && full < 4 && (uint64_t)lanes * 5u < (uint64_t)(full + 1u) * kOneWavePerSimd * 4u) window = full * kOneWavePerSimd;
+        // a round still covers `launches_per_poll` chunks of the WHOLE list (a host poll idles the GPU for ~50 us)
+        if (window) launches_per_sync = (int)(((uint64_t)launches_per_sync * lanes + window - 1u) / window);
     }
     // Paired launches.  For a problem whose stragglers go to the lane-cooperative kernels, every bulk launch of a round
     // is followed by a cooperative launch on the SAME input / output lists: the bulk one works while more than T
@@ -345,6 +361,7 @@ int enqueue_round(ivp_ctx *ctx)
         IvpKArgs ka = P.a;
         ka.chunk = this_chunk;
         ka.lpw = lpw;
+        ka.window = window;
         ka.spec_min = (paired && c > 0) ? pair_threshold : 0u;
         ka.ran_out = ran_slot();
         // LDS-resident factors (bdf_group.h) cost occupancy: an 80 KB matrix leaves room for two wavefronts per CU instead of
@@ -377,6 +394,7 @@ int enqueue_round(ivp_ctx *ctx)
             kc.spec_min = 0u;
             kc.spec_cap = pair_threshold;
             kc.lpw = 0u;
+            kc.window = 0u;
             kc.ran_out = ran_slot();
             if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
             LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, kc, std::min<uint32_t>(lanes, pair_threshold), false, true));

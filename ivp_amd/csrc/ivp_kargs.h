@@ -125,4 +125,10 @@ struct IvpKArgs {
                               // UNION of its lanes' control flow; when the active set leaves SIMDs idle anyway, fewer lanes per
                               // wave on more SIMDs cost nothing and shrink that union (BDF: Newton iteration counts, D-rescaling,
                               // order adaptation, refactorisation and rejection differ from lane to lane on every attempt)
+    // ---- windowed bulk launches ----
+    uint32_t window;          // != 0: only the first `window` entries of the input list take steps in this launch; the waves behind
+                              // them pass their entries straight to the output list (where, having nothing else to do, they land
+                              // FIRST, so the next launch's window starts with them).  A thread-per-trajectory wave saturates the
+                              // f64 pipe of its SIMD on its own, so a launch of 1563 waves on 1024 SIMDs lasts as long as one of
+                              // 2048: the launch loop cuts such a launch down to whole multiples of one wave per SIMD.
 };

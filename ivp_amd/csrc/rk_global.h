@@ -54,6 +54,10 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
         j = a.perm_in ? a.perm_in[i] : i;
         active = a.status[j] == IVP_RUNNING;
     }
+    if (a.window && blockIdx.x * lpw >= a.window) {   // behind the window (wave-uniform): wait for a later launch
+        compact_append(a, j, active);
+        return;
+    }
     uint32_t it = 0;
     int32_t st = 0;
     if (active) it = any_chunk_body<M, R, FULL, CTL>(a, j, st);

@@ -496,3 +496,25 @@ def test_fast_mode_results_do_not_depend_on_the_batch():
     s2 = ivp_amd.solve_ivp_batch(ivp_amd.VanDerPol(), 0.0, 5.0, torch.as_tensor(np.ascontiguousarray(y2[:, :100]), device=dev),
                                  torch.as_tensor(np.ascontiguousarray(p2[:, :100]), device=dev), o2)
     assert torch.equal(s2.y_end, b2.y_end[:, :100])
+
+
+@pytest.mark.parametrize("fma", [False, True], ids=["strict", "fma"])
+@pytest.mark.parametrize("method", ["DOPRI5", "DOP853"])
+def test_windowed_bulk_launches_change_nothing(method, fma):
+    """70 000 CR3BP trajectories are 1094 waves on 1024 SIMDs: the automatic launch loop then steps only the first 65 536
+    entries of the active list per launch and passes the rest on (IvpKArgs.window).  With an explicit chunk length the loop
+    is the plain one (no window, no launch pairs): both must give the same bits, t_eval samples included, and the oracle's."""
+    B = 70_000
+    y0, p, t0, t1 = W.cr3bp_batch(B)
+    t1 = 6.0
+    o = dict(method=method, rtol=1e-6, atol=1e-9, t_eval=np.linspace(0.0, t1, 9))
+    a = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, fast=fma, **o)
+    b = gpu_batch("cr3bp", y0, p, t0, t1, device_arrays=True, fast=fma, chunk=64, **o)
+    assert_bitexact(a, b, "window vs plain: ")
+    assert np.array_equal(a["n_filled"], b["n_filled"]) and (a["n_filled"] == 9).all()
+    assert np.array_equal(a["y_eval"].view(np.uint64), b["y_eval"].view(np.uint64))
+    idx = np.random.default_rng(5).choice(B, 2000, replace=False)
+    r = oracle_batch("cr3bp", y0[:, idx], p[:, idx], t0, t1, threads=16, fma=fma, **o)
+    for k in ("y_end", "t_end", "h_next", "nfev", "nstep", "naccpt", "nrejct"):
+        assert np.array_equal(np.asarray(a[k])[..., idx], r[k]), k
+    assert np.array_equal(a["y_eval"][:, :, idx].view(np.uint64), r["y_eval"].view(np.uint64))

@@ -27,6 +27,8 @@ GRID = [
     ("coopcap_half", {"IVP_TUNE_COOP_CAP_LANES": str(256 * 4 * 64)}),
     ("coopcap_double", {"IVP_TUNE_COOP_CAP_LANES": str(4 * 256 * 4 * 64)}),
     ("chunk32_polls6", {"IVP_TUNE_BULK_CHUNK": "32", "IVP_TUNE_LAUNCHES_PER_POLL": "6"}),
+    ("window_off", {"IVP_TUNE_WINDOW": "0"}),
+    ("window_all_n", {"IVP_TUNE_WINDOW": "2"}),
 ]
 
 
