@@ -209,6 +209,7 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
 struct Tune {
     size_t coop_cap_lanes = 0;       // lanes (8 per trajectory) up to which the lane-cooperative kernels take over; 0 = two waves per SIMD of the device
     uint32_t bulk_chunk = 64;        // attempts per bulk launch
+    int bdf_occ2 = -1;               // BDF occupancy-2 build: -1 = automatic (batches wider than one wave per SIMD), 0 = never, 1 = always
     int window = 1;                  // windowed bulk launches (IvpKArgs.window): 1 = automatic, 0 = never, 2 = also for systems with fewer than four components
     int launches_per_poll = 3;       // bulk launches between two host polls
     int lds_lu = 1;                  // large-n BDF: 0 = never keep the factors in LDS
@@ -217,6 +218,7 @@ struct Tune {
     {
         if (const char *e = getenv("IVP_TUNE_COOP_CAP_LANES")) coop_cap_lanes = (size_t)strtoull(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BULK_CHUNK")) bulk_chunk = (uint32_t)std::max(1l, strtol(e, nullptr, 10));
+        if (const char *e = getenv("IVP_TUNE_BDF_OCC2")) bdf_occ2 = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_WINDOW")) window = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_LDS_LU")) lds_lu = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BDF_LPW")) bdf_lpw = (int)std::min(64l, std::max(0l, strtol(e, nullptr, 10)));
@@ -257,7 +259,7 @@ hipError_t pend_launch(ivp_ctx *ctx, int what, const IvpKArgs &ka, uint32_t lane
     if (P.group) return (fast ? ivp_launch_group_fast : ivp_launch_group_strict)(what, P.method, P.prob.rhs_id, P.full, ka, lanes, s);
     if (P.method == IVP_BDF) {
         // more than one full wave per SIMD still running: the two-waves-per-SIMD build (rk_bdf.hip); same bits either way
-        const bool occ2 = what == IVP_LAUNCH_CHUNK && lanes > ctx->one_wave_per_simd();
+        const bool occ2 = what == IVP_LAUNCH_CHUNK && (lanes > ctx->one_wave_per_simd() || tune().bdf_occ2 == 1) && tune().bdf_occ2 != 0;
         if (occ2) return (fast ? ivp_launch_bdf_fast_occ2 : ivp_launch_bdf_strict_occ2)(what, P.prob.rhs_id, P.full, ka, lanes, s);
         return (fast ? ivp_launch_bdf_fast : ivp_launch_bdf_strict)(what, P.prob.rhs_id, P.full, ka, lanes, s);
     }
