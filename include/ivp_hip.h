@@ -190,7 +190,9 @@ typedef struct {
      * src/solve/solout.rs:316-319) and 0 otherwise, the k-th sample of trajectory b is record
      * q = offsets[b] + b * e + k:  y_eval[q * n + c], eval_idx[q] (index into b's OWN grid, -1 for the terminal sample);
      * y_eval holds (n_eval + B * e) * n doubles, eval_idx n_eval + B * e entries, n_filled[b] counts b's samples.
-     * Single-context entry points only. */
+     * Every entry point takes them: ivp_batch_solve / ivp_batch_solve_multi_host copy the records back to the host arrays,
+     * ivp_batch_solve_multi hands each shard its slice of the grids (offsets re-based to 0: a shard's y_eval / eval_idx
+     * hold its own records) and places the shards' runs in the gathered arrays at the batch-wide offsets. */
     const uint64_t *t_eval_offsets;
     /* event_config(i) for problems with MORE than 4 event functions (trait IVP::n_events is unbounded,
      * src/ivp.rs:31-52): host arrays of n_event_cfg entries that replace ev_direction / ev_terminal above */

@@ -831,8 +831,6 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
     if per_traj:
         if len(options.t_eval_per_trajectory) != B:
             raise ValueError(f"t_eval_per_trajectory needs one grid per trajectory ({B}), got {len(options.t_eval_per_trajectory)}")
-        if not on_device:
-            raise ValueError("t_eval_per_trajectory needs device arrays (y0 as a CUDA tensor): the CSR outputs exist on the device-pointer entry points")
     ne = 0 if options.t_eval is None else len(options.t_eval)
     ml = int(options.max_log)
     nc = method.coeffs_per_state() * n if method != Method.RADAU else 0
@@ -882,7 +880,6 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         res.eval_idx = xp_zeros((rows, B), i32)
         res.n_filled = xp_zeros((B,), i32)
     if per_traj:
-        import torch
         extra = 1 if f.n_events() else 0                    # a terminal event appends its own sample
         sizes = np.array([len(g) for g in options.t_eval_per_trajectory], dtype=np.int64) + extra
         offs = np.zeros(B + 1, dtype=np.int64)
@@ -894,7 +891,7 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
             res.n_filled = xp_zeros((B,), i32)
         elif tuple(res.y_eval.shape) != (max(total, 1), n):
             raise ValueError(f"out.y_eval: expected shape {(max(total, 1), n)} for these per-trajectory grids")
-        res.eval_offsets = torch.as_tensor(offs, device=y0.device)
+        res.eval_offsets = __import__("torch").as_tensor(offs, device=y0.device) if on_device else offs
     if options.count_log and res.n_log is None:
         res.n_log = xp_zeros((B,), u32)
     if options.t_eval is None and ml > 0 and res.t_log is None and res.log_offsets is None:

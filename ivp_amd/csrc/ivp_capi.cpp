@@ -980,6 +980,14 @@ hipError_t copy_rows_peer(void *dst, int dst_dev, size_t dst_stride, const void 
     return hipSuccess;
 }
 
+// per-trajectory t_eval grids: the sample records of trajectories [first, first + count) in the batch-wide CSR arrays
+struct EvalRun { size_t first, count; };
+inline EvalRun eval_run(const ivp_options_t *opt, size_t first, size_t count, bool has_events)
+{
+    const size_t e = has_events ? 1 : 0;   // a terminal event appends its own sample
+    return EvalRun{(size_t)opt->t_eval_offsets[first] + first * e, (size_t)(opt->t_eval_offsets[first + count] - opt->t_eval_offsets[first]) + count * e};
+}
+
 // drive every submitted shard to completion from this thread; on an error the other solves are still drained
 int drive_all(ivp_ctx_t *const *ctxs, const char *live, int n)
 {
@@ -1011,7 +1019,6 @@ int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_probl
 {
     if (!shards || n_shards <= 0 || n_shards > 64) return IVP_ERR_BAD_ARGUMENT;
     DeviceGuard restore_device;   // hipSetDevice below must not leak into the caller (its allocations / launches follow the current device)
-    if (opt && opt->t_eval_offsets) return IVP_ERR_BAD_ARGUMENT;   // offsets index the whole batch, a shard sees a slice: shard the grids yourself
     ivp_ctx_t *c0 = nullptr;
     for (int i = 0; i < n_shards; ++i) {
         if (!shards[i].ctx) return IVP_ERR_BAD_ARGUMENT;
@@ -1028,12 +1035,34 @@ int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_probl
     }
     std::vector<ivp_ctx_t *> ctxs(n_shards);
     std::vector<char> live(n_shards, 0);
+    // Per-trajectory t_eval grids (ivp_options_t.t_eval_offsets): the offsets index the whole batch, a shard integrates a
+    // slice -- every shard gets its own view of the options: its part of the concatenated grid, offsets re-based to 0.
+    const bool grids = opt && opt->t_eval_offsets && opt->t_eval;
+    std::vector<ivp_options_t> shard_opt(grids ? n_shards : 0);
+    std::vector<std::vector<uint64_t>> shard_off(grids ? n_shards : 0);
+    if (grids) {
+        for (size_t b = 0; b < B; ++b)
+            if (opt->t_eval_offsets[b + 1] < opt->t_eval_offsets[b]) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets must be non-decreasing");
+        if (opt->t_eval_offsets[0] != 0 || opt->t_eval_offsets[B] != (uint64_t)opt->n_eval)
+            return fail(c0, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets must run from 0 to n_eval");
+        for (int i = 0; i < n_shards; ++i) {
+            const ivp_shard_t &sh = shards[i];
+            const uint64_t lo = opt->t_eval_offsets[sh.first];
+            shard_off[i].resize(sh.count + 1);
+            for (size_t k = 0; k <= sh.count; ++k) shard_off[i][k] = opt->t_eval_offsets[sh.first + k] - lo;
+            shard_opt[i] = *opt;
+            shard_opt[i].t_eval = opt->t_eval + lo;
+            shard_opt[i].n_eval = (int64_t)shard_off[i][sh.count];
+            shard_opt[i].t_eval_offsets = shard_off[i].data();
+        }
+    }
     int rc = IVP_OK;
     for (int i = 0; i < n_shards && rc == IVP_OK; ++i) {
         ivp_shard_t &sh = shards[i];
         ctxs[i] = sh.ctx;
         if (sh.count == 0) continue;
-        rc = ivp_batch_submit_device(sh.ctx, prob, sh.count, sh.y0, sh.params, sh.t0, sh.t0_len, sh.t1, sh.t1_len, opt, &sh.out, sh.hip_stream);
+        rc = ivp_batch_submit_device(sh.ctx, prob, sh.count, sh.y0, sh.params, sh.t0, sh.t0_len, sh.t1, sh.t1_len, grids ? &shard_opt[i] : opt, &sh.out,
+                                     sh.hip_stream);
         if (rc == IVP_OK) live[i] = 1;
         else if (sh.ctx != c0) c0->err = sh.ctx->err;   // the caller reads the first context's message
     }
@@ -1061,6 +1090,15 @@ int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_probl
             if (!dst || !src) continue;
             // a CSR step log is not an SoA member: it is gathered below
             if (sh.out.log_offsets && (md[k].off == offsetof(ivp_batch_result_t, t_log) || md[k].off == offsetof(ivp_batch_result_t, y_log))) continue;
+            if (grids && (md[k].off == offsetof(ivp_batch_result_t, y_eval) || md[k].off == offsetof(ivp_batch_result_t, eval_idx))) {
+                // samples on per-trajectory grids are time-major CSR records (include/ivp_hip.h): a shard's records are one
+                // contiguous run that starts at record offsets[first] + first * e of the batch-wide arrays
+                const EvalRun run = eval_run(opt, sh.first, sh.count, result_shape(prob, opt, n).nev > 0);
+                const size_t rec = md[k].off == offsetof(ivp_batch_result_t, y_eval) ? 8u * (size_t)n : 4u;
+                HIP_TRY(c0, copy_rows_peer((char *)dst + run.first * rec, gather_device, run.count * rec, src, sh.ctx->device, run.count * rec, 1,
+                                           run.count * rec, 1, s));
+                continue;
+            }
             HIP_TRY(c0, copy_rows_peer((char *)dst + sh.first * md[k].elem, gather_device, B, src, sh.ctx->device, sh.count, md[k].elem, sh.count, md[k].rows, s));
         }
     }
@@ -1122,7 +1160,10 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
     if (np > 0 && !params) return fail(c0, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
     if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
     if (out->log_offsets) return fail(c0, IVP_ERR_BAD_ARGUMENT, "the CSR step log (log_offsets) is available on the device-pointer entry points only");
-    if (opt->t_eval_offsets) return fail(c0, IVP_ERR_BAD_ARGUMENT, "per-trajectory t_eval grids (t_eval_offsets) are available on the single-context device-pointer entry points only");
+    const bool grids = opt->t_eval_offsets && opt->t_eval;
+    const bool grid_events = grids && result_shape(prob, opt, n).nev > 0;
+    auto is_eval_member = [&](const MemberDesc &d) { return grids && (d.off == offsetof(ivp_batch_result_t, y_eval) || d.off == offsetof(ivp_batch_result_t, eval_idx)); };
+    auto eval_rec_bytes = [&](const MemberDesc &d) -> size_t { return d.off == offsetof(ivp_batch_result_t, y_eval) ? 8u * (size_t)n : 4u; };
     MemberDesc md[kMembers];
     member_table(result_shape(prob, opt, n), md);
 
@@ -1156,7 +1197,8 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
         S.t0 = (const double *)ctx->st_t0.p; S.t0_len = l0;
         S.t1 = (const double *)ctx->st_t1.p; S.t1_len = l1;
         for (int k = 0; k < kMembers; ++k) {   // device mirrors of every requested output
-            const size_t bytes = md[k].elem * md[k].rows * m;
+            const size_t bytes = is_eval_member(md[k]) ? std::max<size_t>(eval_run(opt, S.first, m, grid_events).count, 1) * eval_rec_bytes(md[k])
+                                                       : md[k].elem * md[k].rows * m;
             if (member(out, md[k]) && bytes) {
                 HIP_TRY(c0, ctx->st_out[k].reserve(bytes));
                 member(&S.out, md[k]) = ctx->st_out[k].p;
@@ -1172,7 +1214,11 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
         for (int k = 0; k < kMembers; ++k) {
             void *host = member(out, md[k]);
             const void *dev = member(&S.out, md[k]);
-            if (host && dev)
+            if (host && dev && is_eval_member(md[k])) {   // CSR sample records: one contiguous run per shard
+                const EvalRun run = eval_run(opt, S.first, S.count, grid_events);
+                const size_t rec = eval_rec_bytes(md[k]);
+                if (run.count) HIP_TRY(c0, hipMemcpyAsync((char *)host + run.first * rec, dev, run.count * rec, hipMemcpyDeviceToHost, nullptr));
+            } else if (host && dev)
                 HIP_TRY(c0, copy_rows((char *)host + S.first * md[k].elem, B, dev, S.count, md[k].elem, S.count, md[k].rows, hipMemcpyDeviceToHost, nullptr));
         }
     }

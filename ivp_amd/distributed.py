@@ -193,7 +193,7 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
         dev = torch.device("cpu")
     tdev = dev if use_cuda else torch.device("cpu")
     m_max = shard_bounds(B, world, 0)[1] - shard_bounds(B, world, 0)[0]
-    if log and options.t_eval is not None:
+    if log and (options.t_eval is not None or options.t_eval_per_trajectory is not None):
         raise ValueError("the accepted-step log is what solve_ivp records when t_eval is None")
     eval_rows = 0 if options.t_eval is None else len(options.t_eval) + (1 if f.n_events() else 0)
     arena = ResultArena(n, m_max, tdev, eval_rows=max(eval_rows, 1) if options.t_eval is not None else 0, log_counts=log)
@@ -367,6 +367,18 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
     fields = list(ARENA_FIELDS)
     if eval_rows:
         fields += [("y_eval", np.float64, (eval_rows, n)), ("eval_idx", np.int32, (eval_rows,)), ("n_filled", np.int32, 1)]
+    # per-trajectory grids (every reference solve_ivp() call has its own Options.t_eval): the samples are time-major CSR
+    # records; a shard's records are one contiguous run of the batch-wide arrays, which the library places in the gather
+    rec_off = None
+    if options.t_eval_per_trajectory is not None:
+        if permutation is not None:
+            raise ValueError("t_eval_per_trajectory with a permutation: permute the grids and the batch yourself")
+        if len(options.t_eval_per_trajectory) != B:
+            raise ValueError(f"t_eval_per_trajectory needs one grid per trajectory ({B})")
+        sizes = np.array([len(g) for g in options.t_eval_per_trajectory], dtype=np.int64) + (1 if f.n_events() else 0)
+        rec_off = np.zeros(B + 1, dtype=np.int64)
+        rec_off[1:] = np.cumsum(sizes)
+        fields += [("n_filled", np.int32, 1)]
     if log:
         fields += [("n_log", np.int32, 1)]
     shape_of = lambda rows, cols: (n, cols) if rows is None else ((cols,) if rows == 1 else tuple(rows) + (cols,))
@@ -386,6 +398,10 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
         a0 = cut(t0v) if api._is_torch(t0v) else torch.as_tensor([t0v], dtype=torch.float64, device=dev)
         a1 = cut(t1v) if api._is_torch(t1v) else torch.as_tensor([t1v], dtype=torch.float64, device=dev)
         res = {name: torch.zeros(shape_of(rows, m), dtype=tdt[dt], device=dev) for name, dt, rows in fields}
+        if rec_off is not None:
+            recs = max(int(rec_off[hi] - rec_off[lo]), 1)
+            res["y_eval"] = torch.zeros((recs, n), dtype=torch.float64, device=dev)
+            res["eval_idx"] = torch.zeros(recs, dtype=torch.int32, device=dev)
         shard_res[k] = res
         keep += [ys, ps, a0, a1, res]
         S.y0, S.params, S.t0, S.t0_len, S.t1, S.t1_len = ptr(ys), ptr(ps), ptr(a0), a0.numel(), ptr(a1), a1.numel()
@@ -393,6 +409,9 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
             setattr(S.out, name, ptr(res[name]))
         S.hip_stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     g = {name: torch.zeros(shape_of(rows, B), dtype=tdt[dt], device=home) for name, dt, rows in fields}
+    if rec_off is not None:
+        g["y_eval"] = torch.zeros((max(int(rec_off[-1]), 1), n), dtype=torch.float64, device=home)
+        g["eval_idx"] = torch.zeros(max(int(rec_off[-1]), 1), dtype=torch.int32, device=home)
     gathered = _lib.BatchResultT()
     for name in g:
         setattr(gathered, name, ptr(g[name]))
@@ -436,7 +455,8 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
     return api.BatchSolution(y_end=g["y_end"], t_end=g["t_end"], status=g["status"], nfev=g["nfev"], nstep=g["nstep"],
                              naccpt=g["naccpt"], nrejct=g["nrejct"], h_next=g["h_next"], y_eval=g.get("y_eval"),
                              eval_idx=g.get("eval_idx"), n_filled=g.get("n_filled"), n_log=g.get("n_log"),
-                             log_offsets=g.get("log_offsets"), t_log=g.get("t_log"), y_log=g.get("y_log"))
+                             log_offsets=g.get("log_offsets"), t_log=g.get("t_log"), y_log=g.get("y_log"),
+                             eval_offsets=None if rec_off is None else torch.as_tensor(rec_off, device=home))
 
 
 class OverlappedGather:

@@ -166,3 +166,30 @@ def test_column_form_jac_override_on_the_wave_per_trajectory_path():
     # integrates the same system to the same answer within the tolerance
     fd = ivp_amd.solve_ivp_batch(ivp_amd.DeviceIVP(LARGE_JAC_SRC.split("// column form")[0], n=K, params=(40.0,)), 0.0, 0.5, y0, scale, o)
     np.testing.assert_allclose(fd.y_end, r.y_end, rtol=1e-4, atol=1e-8)
+
+
+def test_per_trajectory_grids_through_the_host_pointer_and_the_multi_context_entry_points():
+    """ivp_options_t.t_eval_offsets on ivp_batch_solve (host arrays in, host arrays out) and on ivp_batch_solve_multi (here:
+    three contexts on one GPU, uneven shards): the library re-bases the offsets per shard and places every shard's CSR
+    sample records in the batch-wide arrays -- same bits as the single-context device entry point."""
+    import torch
+    B = 41
+    rng = np.random.default_rng(33)
+    y0 = np.stack([np.cos(rng.uniform(0, 1, B)), np.sin(rng.uniform(0, 1, B))])
+    t1 = rng.uniform(1.0, 4.0, B)
+    grids = [np.sort(rng.uniform(-0.1, t1[b] + 0.1, int(rng.integers(0, 7)))) for b in range(B)]
+    o = ivp_amd.Options(method="DOP853", rtol=1e-7, atol=1e-10, t_eval_per_trajectory=grids)
+    dev = torch.device("cuda:0")
+    ref = ivp_amd.solve_ivp_batch(ivp_amd.SHO(), 0.0, torch.as_tensor(t1, device=dev), torch.as_tensor(y0, device=dev), None, o)
+    host = ivp_amd.solve_ivp_batch(ivp_amd.SHO(), 0.0, t1, y0, None, o)                       # numpy in, numpy out
+    from ivp_amd.distributed import solve_ivp_batch_multi
+    multi = solve_ivp_batch_multi(ivp_amd.SHO(), 0.0, t1, y0, None, o, devices=[0, 0, 0])
+    total = int(ref.eval_offsets[-1])
+    assert total == sum(len(g) for g in grids) and total > 0
+    for other, to_np in ((host, lambda a: np.asarray(a)), (multi, lambda a: a.cpu().numpy())):
+        assert np.array_equal(to_np(other.eval_offsets), ref.eval_offsets.cpu().numpy())
+        assert np.array_equal(to_np(other.n_filled), ref.n_filled.cpu().numpy())
+        assert np.array_equal(to_np(other.y_end).view(np.uint64), ref.y_end.cpu().numpy().view(np.uint64))
+        for b in range(B):
+            (ia, ya), (ib, yb) = other.eval_of(b), ref.eval_of(b)
+            assert np.array_equal(to_np(ia), ib.cpu().numpy()) and np.array_equal(to_np(ya).view(np.uint64), yb.cpu().numpy().view(np.uint64)), b
