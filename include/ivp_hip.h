@@ -235,7 +235,8 @@ typedef struct {
     uint64_t *njev;     /* [B]                                                                  */
     uint64_t *nlu;      /* [B]                                                                  */
     /* Unbounded accepted-step log in CSR form (the reference's Solution.t / Solution.y are Vecs that grow with every
-     * accepted step, src/solve/solout.rs:387-428): an INPUT.  When non-NULL (device path only) it holds B+1 record
+     * accepted step, src/solve/solout.rs:387-428): an INPUT, like the other members a host array for ivp_batch_solve() /
+     * ivp_batch_solve_multi_host() and a device array for the device-pointer entry points.  When non-NULL it holds B+1 record
      * offsets; trajectory b's k-th record then lives at t_log[log_offsets[b] + k] and
      * y_log[(log_offsets[b] + k) * n + c] (time-major like Vec<Vec<f64>>), so the log takes sum(n_log) records
      * instead of max_log x B.  Two passes: a counting solve (options.count_log = 1, only n_log is written), an

@@ -96,6 +96,7 @@ struct ivp_ctx {
     // staging for the host-pointer entry point
     DevBuf st_y0, st_params, st_t0, st_t1;
     DevBuf st_out[24];
+    DevBuf st_logoff;   // this shard's CSR step-log offsets (host-pointer entry points)
     uint32_t *pinned = nullptr;  // host-pinned: active count + misc
     std::vector<hipEvent_t> events;
     ivp_run_stats_t stats{};
@@ -1159,7 +1160,17 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
     if (!y0 || !t0 || !t1 || !out) return fail(c0, IVP_ERR_BAD_ARGUMENT, "null y0/t0/t1/out");
     if (np > 0 && !params) return fail(c0, IVP_ERR_BAD_ARGUMENT, "params required (n_params=%d)", np);
     if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
-    if (out->log_offsets) return fail(c0, IVP_ERR_BAD_ARGUMENT, "the CSR step log (log_offsets) is available on the device-pointer entry points only");
+    // CSR step log through host pointers: out->log_offsets [B + 1] is READ here (the caller's exclusive scan of a counting
+    // pass's n_log); every shard gets device buffers of exactly its own record count and its slice of the offsets,
+    // re-based to 0, and its records return to the host arrays at the batch-wide offsets
+    const bool csr_log = out->log_offsets != nullptr;
+    if (csr_log && (!out->t_log || !out->y_log)) return fail(c0, IVP_ERR_BAD_ARGUMENT, "out.log_offsets needs out.t_log and out.y_log");
+    if (csr_log)
+        for (size_t b = 0; b < B; ++b)
+            if (out->log_offsets[b + 1] < out->log_offsets[b]) return fail(c0, IVP_ERR_BAD_ARGUMENT, "log_offsets must be non-decreasing");
+    auto is_log_member = [&](const MemberDesc &d) { return csr_log && (d.off == offsetof(ivp_batch_result_t, t_log) || d.off == offsetof(ivp_batch_result_t, y_log)); };
+    auto log_rec_bytes = [&](const MemberDesc &d) -> size_t { return d.off == offsetof(ivp_batch_result_t, y_log) ? 8u * (size_t)n : 8u; };
+    std::vector<unsigned long long> log_local;
     const bool grids = opt->t_eval_offsets && opt->t_eval;
     const bool grid_events = grids && result_shape(prob, opt, n).nev > 0;
     auto is_eval_member = [&](const MemberDesc &d) { return grids && (d.off == offsetof(ivp_batch_result_t, y_eval) || d.off == offsetof(ivp_batch_result_t, eval_idx)); };
@@ -1198,11 +1209,24 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
         S.t1 = (const double *)ctx->st_t1.p; S.t1_len = l1;
         for (int k = 0; k < kMembers; ++k) {   // device mirrors of every requested output
             const size_t bytes = is_eval_member(md[k]) ? std::max<size_t>(eval_run(opt, S.first, m, grid_events).count, 1) * eval_rec_bytes(md[k])
-                                                       : md[k].elem * md[k].rows * m;
+                                 : is_log_member(md[k]) ? std::max<size_t>((size_t)(out->log_offsets[S.first + m] - out->log_offsets[S.first]), 1) * log_rec_bytes(md[k])
+                                                        : md[k].elem * md[k].rows * m;
             if (member(out, md[k]) && bytes) {
                 HIP_TRY(c0, ctx->st_out[k].reserve(bytes));
                 member(&S.out, md[k]) = ctx->st_out[k].p;
             }
+        }
+    }
+    if (csr_log) {
+        for (int i = 0; i < n_ctx; ++i) {
+            ivp_shard_t &S = sh[i];
+            if (S.count == 0) continue;
+            HIP_TRY(c0, hipSetDevice(S.ctx->device));
+            log_local.resize(S.count + 1);
+            for (size_t k = 0; k <= S.count; ++k) log_local[k] = out->log_offsets[S.first + k] - out->log_offsets[S.first];
+            HIP_TRY(c0, S.ctx->st_logoff.reserve(sizeof(unsigned long long) * (S.count + 1)));
+            HIP_TRY(c0, hipMemcpy(S.ctx->st_logoff.p, log_local.data(), sizeof(unsigned long long) * (S.count + 1), hipMemcpyHostToDevice));
+            S.out.log_offsets = (const uint64_t *)S.ctx->st_logoff.p;
         }
     }
     rc = ivp_batch_solve_multi(sh.data(), n_ctx, prob, B, opt, 0, nullptr);
@@ -1214,6 +1238,12 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
         for (int k = 0; k < kMembers; ++k) {
             void *host = member(out, md[k]);
             const void *dev = member(&S.out, md[k]);
+            if (host && dev && is_log_member(md[k])) {   // CSR step log: one contiguous run of records per shard
+                const size_t rec = log_rec_bytes(md[k]);
+                const size_t first = (size_t)out->log_offsets[S.first], count = (size_t)(out->log_offsets[S.first + S.count] - out->log_offsets[S.first]);
+                if (count) HIP_TRY(c0, hipMemcpyAsync((char *)host + first * rec, dev, count * rec, hipMemcpyDeviceToHost, nullptr));
+                continue;
+            }
             if (host && dev && is_eval_member(md[k])) {   // CSR sample records: one contiguous run per shard
                 const EvalRun run = eval_run(opt, S.first, S.count, grid_events);
                 const size_t rec = eval_rec_bytes(md[k]);

@@ -193,3 +193,29 @@ def test_per_trajectory_grids_through_the_host_pointer_and_the_multi_context_ent
         for b in range(B):
             (ia, ya), (ib, yb) = other.eval_of(b), ref.eval_of(b)
             assert np.array_equal(to_np(ia), ib.cpu().numpy()) and np.array_equal(to_np(ya).view(np.uint64), yb.cpu().numpy().view(np.uint64)), b
+
+
+def test_csr_step_log_through_the_host_pointer_entry_point():
+    """Solution.t / Solution.y of every trajectory (every accepted step, src/solve/solout.rs:387-428) with host arrays in and
+    out: a counting call (Options.count_log), the caller's exclusive scan, and the filling call with out.log_offsets /
+    t_log / y_log as HOST arrays -- record for record what the device-pointer path (solve_ivp_batch_logged) returns."""
+    B = 23
+    y0, p, t0, t1 = W.cr3bp_batch(B)
+    t1 = 3.0
+    base = dict(method="DOPRI5", rtol=1e-7, atol=1e-10)
+    f = ivp_amd.CR3BP()
+    ref = ivp_amd.solve_ivp_batch_logged(f, t0, t1, y0, p, ivp_amd.Options(**base))
+    cnt = ivp_amd.solve_ivp_batch(f, t0, t1, y0, p, ivp_amd.Options(**base, count_log=True))
+    off = np.zeros(B + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(cnt.n_log.astype(np.uint64))
+    total = int(off[-1])
+    assert total == int(ref.log_offsets[-1]) and np.array_equal(off.astype(np.int64), ref.log_offsets.cpu().numpy())
+    out = ivp_amd.BatchSolution(y_end=cnt.y_end, t_end=cnt.t_end, status=cnt.status, nfev=cnt.nfev, nstep=cnt.nstep, naccpt=cnt.naccpt,
+                                nrejct=cnt.nrejct, h_next=cnt.h_next, njev=cnt.njev, nlu=cnt.nlu, n_log=cnt.n_log,
+                                t_log=np.full(total, np.nan), y_log=np.full((total, 6), np.nan), log_offsets=off)
+    res = ivp_amd.solve_ivp_batch(f, t0, t1, y0, p, ivp_amd.Options(**base), out=out)
+    assert np.array_equal(res.t_log.view(np.uint64), ref.t_log.cpu().numpy().view(np.uint64))
+    assert np.array_equal(res.y_log.view(np.uint64), ref.y_log.cpu().numpy().view(np.uint64))
+    assert np.array_equal(res.y_end.view(np.uint64), ref.y_end.cpu().numpy().view(np.uint64))
+    t, y = res.log_of(5)
+    assert t[0] == t0 and t[-1] == t1 and y.shape == (len(t), 6)
