@@ -385,7 +385,7 @@ int enqueue_round(ivp_ctx *ctx)
         ka.count_out = counts + (c & 3);
         // slot (c+1)&3 is the next launch's count_out: it was zeroed by the initial memset (c = 0) or has to
         // be reset now; nothing reads it during this launch.
-        if (c >= 3) HIP_TRY(ctx, hipMemsetAsync(counts + ((c + 1) & 3), 0, sizeof(uint32_t), s));
+        ka.count_next = counts + ((c + 1) & 3);   // reset by the kernel itself (a 4-byte hipMemsetAsync is a ~5 us kernel of its own)
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
         LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, lanes, use_hoist, use_coop));
@@ -721,8 +721,8 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         a.bdf_lu = (double *)ctx->bdf_lu.p;
         a.bdf_piv = (uint32_t *)ctx->bdf_piv.p;
     } else {
-        if (out->njev) HIP_TRY(ctx, hipMemsetAsync(out->njev, 0, sizeof(uint64_t) * B, s));   // njev = nlu = 0 for explicit RK
-        if (out->nlu) HIP_TRY(ctx, hipMemsetAsync(out->nlu, 0, sizeof(uint64_t) * B, s));
+        a.njev = (uint64_t *)out->njev;   // njev = nlu = 0 for explicit RK: written by the init kernel (NULL = not wanted)
+        a.nlu = (uint64_t *)out->nlu;
     }
     HIP_TRY(ctx, ctx->k1.reserve(sizeof(double) * n * B));
     HIP_TRY(ctx, ctx->facold.reserve(sizeof(double) * B));

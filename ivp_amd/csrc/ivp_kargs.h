@@ -125,6 +125,8 @@ struct IvpKArgs {
                               // UNION of its lanes' control flow; when the active set leaves SIMDs idle anyway, fewer lanes per
                               // wave on more SIMDs cost nothing and shrink that union (BDF: Newton iteration counts, D-rescaling,
                               // order adaptation, refactorisation and rejection differ from lane to lane on every attempt)
+    uint32_t *count_next;     // the count_out of the NEXT launch of the chain (nobody reads or writes it during this one): every
+                              // stepping kernel resets it, which saves a 4-byte fill kernel (~5 us of an idle GPU) per launch
     // ---- windowed bulk launches ----
     uint32_t window;          // != 0: only the first `window` entries of the input list take steps in this launch; the waves behind
                               // them pass their entries straight to the output list (where, having nothing else to do, they land

@@ -236,6 +236,7 @@ __device__ __forceinline__ void coop_chunk_body(const IvpKArgs &a)
 {
     const uint32_t lane = threadIdx.x, c = lane & 7u;
     const uint32_t count = a.perm_in ? *a.count_in : a.B;
+    if (a.count_next && blockIdx.x == 0 && threadIdx.x == 0) *a.count_next = 0u;   // before any early exit: both halves of a pair do it
     if (a.spec_cap && count > a.spec_cap) return;   // speculative launch declined: the set is still too large (uniform)
     if (blockIdx.x * 8u >= count) return;   // whole wave beyond the active set (stale grid bound)
     if (a.ran_out && blockIdx.x == 0 && threadIdx.x == 0) *a.ran_out = 1u;

@@ -1030,6 +1030,14 @@ IVP_HD bool so_needs_dense(const IvpKArgs &a, uint32_t j, const Lane<N, P> &L, d
     return a.t_log != nullptr && a.has_first_step && !(L.flags & IVP_F_FIRSTOUT);
 }
 
+// Solution.njev / Solution.nlu of an explicit method are 0 (tests/test_ivp.py:214-216): written by the init kernel when
+// the caller asked for them, instead of two fill kernels per solve
+IVP_HD void so_zero_implicit_counters(const IvpKArgs &a, uint32_t j)
+{
+    if (a.njev) a.njev[j] = 0;
+    if (a.nlu) a.nlu[j] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // hinit (src/methods/mod.rs:217-281)
 // ------------------------------------------------------------------------------------------------
@@ -1122,7 +1130,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         }
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 0;
-        a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+        a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
         return 0;
     }
 
@@ -1133,7 +1141,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, 0.0); }
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 3;
-        a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+        a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
         if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
         return 3;
     }
@@ -1154,7 +1162,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
             for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, 0.0); }
             a.x[j] = L.x0; a.h[j] = L.h; a.facold[j] = 0.0; a.hlamb[j] = 0.0; a.flags[j] = 0;
             a.status[j] = 0;
-            a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+            a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
             if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
             return 0;
         }
@@ -1171,7 +1179,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, L.k1[c]); }
     a.x[j] = L.x; a.h[j] = L.h; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = L.flags;
     a.status[j] = IVP_RUNNING;
-    a.nfev[j] = nfev; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0;
+    a.nfev[j] = nfev; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
     if (FULL) {
         a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;

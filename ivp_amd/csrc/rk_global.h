@@ -44,6 +44,7 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
     const uint32_t lpw = a.lpw ? a.lpw : (uint32_t)IVP_WAVE;   // trajectories per wave (thin waves: ivp_kargs.h)
     const uint32_t i = blockIdx.x * lpw + threadIdx.x;
     const uint32_t count = a.perm_in ? *a.count_in : a.B;
+    if (a.count_next && blockIdx.x == 0 && threadIdx.x == 0) *a.count_next = 0u;   // before any early exit: both halves of a pair do it
     if (a.spec_min && count <= a.spec_min) return;   // paired launch: the set is small enough for the cooperative kernel (uniform)
     if (blockIdx.x * lpw >= count) return;  // whole wave beyond the active set (stale grid bound)
     if (a.ran_out && blockIdx.x == 0 && threadIdx.x == 0) *a.ran_out = 1u;

@@ -181,6 +181,7 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
 {
     constexpr uint32_t NG = IVP_WAVE / G;
     const uint32_t count = a.perm_in ? *a.count_in : a.B;
+    if (a.count_next && blockIdx.x == 0 && threadIdx.x == 0) *a.count_next = 0u;   // before any early exit
     if (blockIdx.x * NG >= count) return;   // whole wave beyond the active set (stale grid bound)
     const uint32_t i = blockIdx.x * NG + threadIdx.x / G;
     uint32_t j = 0;

@@ -39,6 +39,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("err_flag", VP),
         ("slot_counter", VP),
         ("spec_cap", C.c_uint32), ("spec_min", C.c_uint32), ("ran_out", VP), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
+        ("count_next", VP),
         ("window", C.c_uint32),
     ]
 
