@@ -213,6 +213,7 @@ struct Tune {
     int bdf_occ2 = -1;               // BDF occupancy-2 build: -1 = automatic (batches wider than one wave per SIMD), 0 = never, 1 = always
     int window = 1;                  // windowed bulk launches (IvpKArgs.window): 1 = automatic, 0 = never, 2 = also for systems with fewer than four components
     int launches_per_poll = 3;       // bulk launches between two host polls
+    int launches_per_poll_set = 0;   // IVP_TUNE_LAUNCHES_PER_POLL given: taken literally (no extra hand-over pair)
     int lds_lu = 1;                  // large-n BDF: 0 = never keep the factors in LDS
     int bdf_lpw = 0;                 // trajectories per wave of the BDF chunk launches: 0 = auto (spread the active set over the SIMDs)
     Tune()
@@ -223,7 +224,7 @@ struct Tune {
         if (const char *e = getenv("IVP_TUNE_WINDOW")) window = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_LDS_LU")) lds_lu = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BDF_LPW")) bdf_lpw = (int)std::min(64l, std::max(0l, strtol(e, nullptr, 10)));
-        if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10)));
+        if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) { launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10))); launches_per_poll_set = 1; }
     }
 };
 const Tune &tune() { static const Tune t; return t; }
@@ -355,6 +356,10 @@ int enqueue_round(ivp_ctx *ctx)
     // launch that declines returns at once (~3 us).  Results never depend on where the hand-over falls.
     const bool paired = !tail && !use_coop && spec_ok;
     const uint32_t pair_threshold = (uint32_t)(coop_cap / 8u);
+    // one more pair per round: a cooperative partner looks at the count its own bulk launch STARTED from, so the pair after
+    // the launch that crossed the threshold is the one that hands over -- with it in the same round the hand-over needs no
+    // host poll (~40 us of an idle GPU); if the threshold was not crossed the extra launch is one more chunk of useful work
+    if (paired && tune().launches_per_poll_set == 0) launches_per_sync += 1;
     auto ran_slot = [&]() -> uint32_t * {   // profiling: which launch of a pair did the work
         if (!profile || !paired || P.step_ev.size() >= kMaxRanSlots) return nullptr;
         return (uint32_t *)ctx->ran.p + P.step_ev.size();

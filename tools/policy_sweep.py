@@ -68,12 +68,14 @@ def child():
         r = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts)
         r = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, out=r)
         torch.cuda.synchronize()
-        k = 4
-        t = time.perf_counter()
-        for _ in range(k):
-            r = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, out=r)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / k * 1e3
+        k, groups = 4, []
+        for _ in range(5):   # median of five groups of four solves: single groups scatter by +-5 % from process to process
+            t = time.perf_counter()
+            for _ in range(k):
+                r = ivp_amd.solve_ivp_batch(prob, t0, t1, y0d, pd, opts, out=r)
+            torch.cuda.synchronize()
+            groups.append((time.perf_counter() - t) / k * 1e3)
+        ms = sorted(groups)[2]
         print(json.dumps({"case": name, "ms": ms, "accepted": int(r.naccpt.sum().item()), "ok": bool((r.status == 0).all().item())}), flush=True)
 
 
@@ -81,7 +83,10 @@ def main():
     if "--child" in sys.argv:
         return child()
     table = {}
-    for label, env in GRID:
+    # the first process on a fresh box runs ~5 % slower than the same setting later (clocks, caches): one throw-away pass,
+    # and the automatic policy is measured twice (first and last; the table takes the mean)
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    for label, env in GRID + [("auto_again", {})]:
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=e, capture_output=True, text=True, timeout=900)
@@ -95,7 +100,10 @@ def main():
         print("done", label, flush=True)
     rows = []
     for case, v in table.items():
-        best = min(v, key=v.get)
+        if "auto_again" in v:
+            v["auto_first"] = v["auto"]
+            v["auto"] = 0.5 * (v["auto"] + v.pop("auto_again"))
+        best = min((k for k in v if k != 'auto_first'), key=v.get)
         rows.append({"case": case, "auto_ms": v.get("auto"), "best": best, "best_ms": v[best], "auto_over_best": v.get("auto", float("nan")) / v[best], "all": v})
         print(f"{case:45s} auto {v.get('auto', float('nan')):8.3f} ms   best {best:16s} {v[best]:8.3f} ms   auto/best {rows[-1]['auto_over_best']:.3f}")
     path = os.path.join(ROOT, "gpurun_out", "policy_sweep.json")
