@@ -63,6 +63,11 @@
 // that re-creates a constant (measured: ~100 of ~1350 slots per DOPRI5 attempt), and has registers to spare.
 #define KC_SCOPE const uint64_t ivp_kz = 0;   /* code outside the attempt loop (init kernel): plain literals */
 #define KC(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kz)
+#elif defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 1
+// resident build: plain literals (LLVM keeps what fits in registers); ivp_kz only travels to the power core, whose
+// coefficients are pinned in vector registers (ivp_pow_core_w)
+#define KC_SCOPE const uint64_t ivp_kz = 0; (void)ivp_kz;
+#define KC(c) (c)
 #else
 #define KC_SCOPE
 #define KC(c) (c)
@@ -72,6 +77,9 @@
 // IVP_KZ_ARG hands the partner on to helpers that have no Lane (ivp_pow).
 #if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 2
 #define KC_SCOPE_KZ(z) const uint64_t ivp_kz = (z);
+#define IVP_KZ_ARG ivp_kz
+#elif defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 1
+#define KC_SCOPE_KZ(z) const uint64_t ivp_kz = (z); (void)ivp_kz;
 #define IVP_KZ_ARG ivp_kz
 #else
 #define KC_SCOPE_KZ(z) KC_SCOPE
@@ -163,7 +171,15 @@ IVP_HD void ivp_pow_core_w(const double (&x)[W], const double (&e)[W], const int
     // emits `v_mov_b64 tmp, c; v_fmac_f64 tmp, p, z` per step (a copy to protect the pinned value), whereas an SGPR
     // operand gives the single three-address `v_fma_f64 p, p, z, s[..]` and the s_xor that re-creates it issues on the
     // scalar port beside the other wave's vector work.
-#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST != 2
+#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 1
+    // resident build (at most two waves per SIMD, since the windowed launches mostly ONE): a lone wave pays a full issue
+    // slot for each of the two s_xor that re-create a coefficient (~100 slots per DOPRI5 attempt), so here the 26
+    // coefficients are pinned in vector registers (XOR with the opaque zero defined before the attempt loop: hoisted, never
+    // re-materialised); the compiler picks the three-address v_fma_f64 for the Horner steps (no copy to protect the pinned
+    // value, and -- unlike an inline-asm fma -- no s_nop between dependent steps)
+#define KP(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ kz)
+#define PFMA(a, b, c) fma((a), (b), (c))
+#elif defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST != 2
     const uint64_t ivp_kzp = IVP_NS::ivp_opaque_zero();
 #define KP(c) IVP_NS::u2d(__builtin_bit_cast(uint64_t, (double)(c)) ^ ivp_kzp)
     // ... and the fused multiply-add is spelled out, because instruction selection otherwise turns fma(p, z, c) with a
@@ -1801,7 +1817,7 @@ IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     Lane<R::N, R::P> L;
     lane_load<R>(a, j, L, M == M_RK23 || M == M_RK4, FULL);
-#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST == 2
+#if defined(__HIP_DEVICE_COMPILE__) && IVP_HOIST >= 1
     L.kz = ivp_opaque_zero_v();
 #else
     L.kz = 0;
