@@ -305,8 +305,8 @@ int enqueue_round(ivp_ctx *ctx)
     // reference's operation sequence; FMA: the same sequence with the IVP_MA sites fused, written out in the source and
     // compiled without contraction), so the choice follows the shrinking active set: resident once at most two waves
     // per SIMD are left to run, cooperative for the tail.
-    const bool use_hoist = !P.has_settings &&   // run-time controller fields exist in the lean builds only
-                           (P.variant == 2 || (P.variant == 0 && (size_t)lanes <= 2 * (size_t)kOneWavePerSimd));
+    bool use_hoist = !P.has_settings &&   // run-time controller fields exist in the lean builds only
+                     (P.variant == 2 || (P.variant == 0 && (size_t)lanes <= 2 * (size_t)kOneWavePerSimd));
     // eight lanes per trajectory pay off once the cooperative waves fit two per SIMD, and only for systems
     // with enough components to share out (measured: break-even at n = 3, a loss at n = 2)
     const size_t coop_cap = coop_cap_lanes(ctx);
@@ -347,6 +347,8 @@ int enqueue_round(ivp_ctx *ctx)
         if (full >= 1 && full < 4 && (uint64_t)lanes * 5u < (uint64_t)(full + 1u) * kOneWavePerSimd * 4u) window = full * kOneWavePerSimd;
         // a round still covers `launches_per_poll` chunks of the WHOLE list (a host poll idles the GPU for ~50 us)
         if (window) launches_per_sync = (int)(((uint64_t)launches_per_sync * lanes + window - 1u) / window);
+        // what runs at once is the window, not the list: at most two waves per SIMD take the resident build
+        if (window && !P.has_settings && P.variant == 0 && (size_t)window <= 2 * (size_t)kOneWavePerSimd) use_hoist = true;
     }
     // Paired launches.  For a problem whose stragglers go to the lane-cooperative kernels, every bulk launch of a round
     // is followed by a cooperative launch on the SAME input / output lists: the bulk one works while more than T
