@@ -106,7 +106,7 @@ struct ivp_ctx {
         IvpKArgs a;
         ivp_problem_t prob;
         int method = 0, fp_mode = 0, variant = 0, profile = 0, n = 0;
-        bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false, lds_lu_ok = false;
+        bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false, lds_lu_ok = false, has_events = false;
         uint32_t chunk = 64, lanes = 0;
         uint32_t chunk_now = 64;    // attempts per bulk launch of the next round (adaptive: follows the decay of the active set)
         uint32_t quiet_rounds = 0;  // consecutive rounds that retired (almost) nobody
@@ -342,7 +342,10 @@ int enqueue_round(ivp_ctx *ctx)
     // pass their entries on; those land first in the output list, so every trajectory is at most one launch behind.
     // Results never depend on how attempts are cut into launches.
     uint32_t window = 0;
-    if (tune().window && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && (P.n >= 4 || tune().window == 2)) {
+    // (not for problems with event functions: the root-finding of a crossing is a long divergent stretch that a second wave
+    // on the SIMD hides; measured on C2 with the x-axis crossing event 4.5 ms with full launches, 5.0 with windows)
+    if (tune().window && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && !P.has_events &&
+        (P.n >= 4 || tune().window == 2)) {
         const uint32_t full = lanes / kOneWavePerSimd;
         if (full >= 1 && full < 4 && (uint64_t)lanes * 5u < (uint64_t)(full + 1u) * kOneWavePerSimd * 4u) window = full * kOneWavePerSimd;
         // a round still covers `launches_per_poll` chunks of the WHOLE list (a host poll idles the GPU for ~50 us)
@@ -836,6 +839,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.jit = prob->rhs_id == IVP_RHS_JIT;
     P.has_settings = opt->has_settings != 0;
     P.lds_lu_ok = lds_lu_ok;
+    P.has_events = n_events > 0;
     // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for problems with
     // n <= 8.  Results are bit-identical to the thread-per-trajectory kernels in both arithmetic modes, so the loop
     // switches to them for the latency-bound tail.
