@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -125,6 +126,16 @@ struct ivp_ctx {
 };
 
 namespace {
+
+// solves in flight in this process, over all contexts (several batches overlapped on streams, ivp_amd/pipeline.py): the launch
+// loop sizes its launches for an otherwise idle chip only when it is alone
+std::atomic<int> g_inflight{0};
+void set_active(ivp_ctx *ctx, bool on)
+{
+    if (ctx->pend.active == on) return;
+    ctx->pend.active = on;
+    g_inflight.fetch_add(on ? 1 : -1, std::memory_order_relaxed);
+}
 
 int fail(ivp_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -344,7 +355,7 @@ int enqueue_round(ivp_ctx *ctx)
     uint32_t window = 0;
     // (not for problems with event functions: the root-finding of a crossing is a long divergent stretch that a second wave
     // on the SIMD hides; measured on C2 with the x-axis crossing event 4.5 ms with full launches, 5.0 with windows)
-    if (tune().window && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && !P.has_events &&
+    if (tune().window && g_inflight.load(std::memory_order_relaxed) <= 1 && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && !P.has_events &&
         (P.n >= 4 || tune().window == 2)) {
         const uint32_t full = lanes / kOneWavePerSimd;
         if (full >= 1 && full < 4 && (uint64_t)lanes * 5u < (uint64_t)(full + 1u) * kOneWavePerSimd * 4u) window = full * kOneWavePerSimd;
@@ -427,7 +438,7 @@ int finish_round(ivp_ctx *ctx, int *done)
     if (!P.err_checked) {
         P.err_checked = true;
         if (ctx->pinned[1] & 0x1u) {  // IVP_ERRFLAG_INVALID_STEP: RK4::solve's Err(InvalidStepSize), rk4.rs:81-87
-            P.active = false;
+            set_active(ctx, false);
             return fail(ctx, IVP_ERR_INVALID_STEP_SIZE, "RK4: step size is zero or its sign does not match xend - x0 for at least one trajectory");
         }
     }
@@ -453,7 +464,7 @@ int finish_round(ivp_ctx *ctx, int *done)
     }
     P.lanes = ctx->pinned[0];
     if (P.lanes != 0) return enqueue_round(ctx);
-    P.active = false;
+    set_active(ctx, false);
     *done = 1;
     if (P.profile) {
         hipStream_t s = P.stream;
@@ -549,12 +560,13 @@ int ivp_ctx_create(ivp_ctx_t **out, int device)
 void ivp_ctx_destroy(ivp_ctx_t *c)
 {
     if (!c) return;
+    set_active(c, false);   // a context destroyed with a solve in flight must not stay in the count
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->k1, &c->facold, &c->hlamb, &c->flags, &c->perm[0], &c->perm[1], &c->counts, &c->slot, &c->ran, &c->teval, &c->teval_off, &c->evcfg, &c->tolvec, &c->zero_off,
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
-                      &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1};
+                      &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1, &c->st_logoff};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -871,9 +883,9 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_INIT, ka, (uint32_t)B, false, false));
     if (profile) { P.ev_init1 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(P.ev_init1, s)); }
     ctx->stats.init_launches = 1;
-    P.active = true;
+    set_active(ctx, true);
     rc = enqueue_round(ctx);
-    if (rc != IVP_OK) P.active = false;
+    if (rc != IVP_OK) set_active(ctx, false);
     return rc;
 }
 
@@ -885,9 +897,9 @@ int ivp_batch_poll(ivp_ctx_t *ctx, int *done)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const hipError_t q = hipEventQuery(ctx->pend.round_done);
     if (q == hipErrorNotReady) { (void)hipGetLastError(); return IVP_OK; }
-    if (q != hipSuccess) { ctx->pend.active = false; return fail(ctx, IVP_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q)); }
+    if (q != hipSuccess) { set_active(ctx, false); return fail(ctx, IVP_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q)); }
     const int rc = finish_round(ctx, done);
-    if (rc != IVP_OK) ctx->pend.active = false;
+    if (rc != IVP_OK) set_active(ctx, false);
     return rc;
 }
 
@@ -897,10 +909,10 @@ int ivp_batch_wait(ivp_ctx_t *ctx)
     while (ctx->pend.active) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         const hipError_t e = hipEventSynchronize(ctx->pend.round_done);
-        if (e != hipSuccess) { ctx->pend.active = false; return fail(ctx, IVP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { set_active(ctx, false); return fail(ctx, IVP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e)); }
         int done = 0;
         const int rc = finish_round(ctx, &done);
-        if (rc != IVP_OK) { ctx->pend.active = false; return rc; }
+        if (rc != IVP_OK) { set_active(ctx, false); return rc; }
     }
     return IVP_OK;
 }
