@@ -127,14 +127,15 @@ struct ivp_ctx {
 
 namespace {
 
-// solves in flight in this process, over all contexts (several batches overlapped on streams, ivp_amd/pipeline.py): the launch
+// solves in flight in this process on each device, over all its contexts (several batches overlapped on streams, ivp_amd/pipeline.py): the launch
 // loop sizes its launches for an otherwise idle chip only when it is alone
-std::atomic<int> g_inflight{0};
+std::atomic<int> g_inflight[64];   // per device (zero-initialised: static storage)
+std::atomic<int> &inflight_on(int device) { return g_inflight[(unsigned)device & 63u]; }
 void set_active(ivp_ctx *ctx, bool on)
 {
     if (ctx->pend.active == on) return;
     ctx->pend.active = on;
-    g_inflight.fetch_add(on ? 1 : -1, std::memory_order_relaxed);
+    inflight_on(ctx->device).fetch_add(on ? 1 : -1, std::memory_order_relaxed);
 }
 
 int fail(ivp_ctx *ctx, int code, const char *fmt, ...)
@@ -355,7 +356,7 @@ int enqueue_round(ivp_ctx *ctx)
     uint32_t window = 0;
     // (not for problems with event functions: the root-finding of a crossing is a long divergent stretch that a second wave
     // on the SIMD hides; measured on C2 with the x-axis crossing event 4.5 ms with full launches, 5.0 with windows)
-    if (tune().window && g_inflight.load(std::memory_order_relaxed) <= 1 && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && !P.has_events &&
+    if (tune().window && inflight_on(ctx->device).load(std::memory_order_relaxed) <= 1 && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && !P.has_events &&
         (P.n >= 4 || tune().window == 2)) {
         const uint32_t full = lanes / kOneWavePerSimd;
         if (full >= 1 && full < 4 && (uint64_t)lanes * 5u < (uint64_t)(full + 1u) * kOneWavePerSimd * 4u) window = full * kOneWavePerSimd;
