@@ -356,7 +356,10 @@ int enqueue_round(ivp_ctx *ctx)
     uint32_t window = 0;
     // (not for problems with event functions: the root-finding of a crossing is a long divergent stretch that a second wave
     // on the SIMD hides; measured on C2 with the x-axis crossing event 4.5 ms with full launches, 5.0 with windows)
-    if (tune().window && inflight_on(ctx->device).load(std::memory_order_relaxed) <= 1 && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && !P.has_events &&
+    // (and only while this solve has the device to itself: with other solves in flight the SIMDs a ragged round leaves idle
+    // are not idle)
+    const bool alone = inflight_on(ctx->device).load(std::memory_order_relaxed) <= 1;
+    if (tune().window && alone && P.adaptive && !P.group && !use_coop && !tail && lpw == 0 && P.method != IVP_BDF && !P.has_events &&
         (P.n >= 4 || tune().window == 2)) {
         const uint32_t full = lanes / kOneWavePerSimd;
         if (full >= 1 && full < 4 && (uint64_t)lanes * 5u < (uint64_t)(full + 1u) * kOneWavePerSimd * 4u) window = full * kOneWavePerSimd;
@@ -405,9 +408,9 @@ int enqueue_round(ivp_ctx *ctx)
         }
         ka.perm_out = (uint32_t *)ctx->perm[c & 1].p;
         ka.count_out = counts + (c & 3);
-        // slot (c+1)&3 is the next launch's count_out: it was zeroed by the initial memset (c = 0) or has to
-        // be reset now; nothing reads it during this launch.
-        ka.count_next = counts + ((c + 1) & 3);   // reset by the kernel itself (a 4-byte hipMemsetAsync is a ~5 us kernel of its own)
+        // slot (c+1)&3 is the next launch's count_out; nothing reads it during this launch, which resets it itself
+        // (a 4-byte hipMemsetAsync is a ~5 us kernel of its own)
+        ka.count_next = counts + ((c + 1) & 3);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) { e0 = pend_event(ctx); HIP_TRY(ctx, hipEventRecord(e0, s)); }
         LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_CHUNK, ka, lanes, use_hoist, use_coop));
