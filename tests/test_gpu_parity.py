@@ -518,3 +518,22 @@ def test_windowed_bulk_launches_change_nothing(method, fma):
     for k in ("y_end", "t_end", "h_next", "nfev", "nstep", "naccpt", "nrejct"):
         assert np.array_equal(np.asarray(a[k])[..., idx], r[k]), k
     assert np.array_equal(a["y_eval"][:, :, idx].view(np.uint64), r["y_eval"].view(np.uint64))
+
+
+def test_windowed_bulk_launches_with_the_csr_step_log():
+    """The two-pass CSR step log (count, then fill at exact offsets) under windowed launches: a trajectory that waits
+    behind the window keeps its log cursor; records equal those of the plain launch loop, and the oracle's for a sample."""
+    import ivp_amd
+    B = 70_000
+    y0, p, t0, t1 = W.cr3bp_batch(B)
+    t1 = 2.5
+    f = ivp_amd.CR3BP()
+    a = ivp_amd.solve_ivp_batch_logged(f, t0, t1, y0, p, ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9))
+    b = ivp_amd.solve_ivp_batch_logged(f, t0, t1, y0, p, ivp_amd.Options(method="DOPRI5", rtol=1e-6, atol=1e-9, chunk_attempts=64))
+    import torch
+    assert torch.equal(a.log_offsets, b.log_offsets) and torch.equal(a.t_log.view(torch.int64), b.t_log.view(torch.int64))
+    assert torch.equal(a.y_log.view(torch.int64), b.y_log.view(torch.int64)) and torch.equal(a.y_end.view(torch.int64), b.y_end.view(torch.int64))
+    for j in (0, 17, 65_535, 65_536, 69_999):
+        s = O.solve_ivp("cr3bp", t0, t1, y0[:, j], params=p[:, j], detpow=True, method="DOPRI5", rtol=1e-6, atol=1e-9)
+        t, y = a.log_of(j)
+        assert np.array_equal(t.cpu().numpy(), s.t) and np.array_equal(y.cpu().numpy(), s.y), j
