@@ -358,6 +358,13 @@ def main():
             if args.workload != "c2":
                 modes = [m for m in modes if m != "events"]
             res["outputs"] = output_mode_numbers(ivp_amd, prob, wl, t0, t1, y0d, pd, fp, ctx, args, modes, ms_per_step)
+        if "outputs" in res and isinstance(res["outputs"].get("csr_log"), dict) and "ms_per_solve" in res["outputs"]["csr_log"]:
+            # the reference's own default contract next to the end-state headline: every accepted step returned (Solution.t / .y)
+            c = res["outputs"]["csr_log"]
+            res["full_contract"] = {"what": "Solution.t / Solution.y of every trajectory (every accepted step, CSR, device-resident) from ONE integration",
+                                    "ms_per_step": c["ms_per_solve"], "value": total_acc / (c["ms_per_solve"] * 1e-3), "unit": "steps/s",
+                                    "records": c["records"], "bytes": c["bytes_written"], "vs_end_state": c["ms_per_solve"] / ms_per_step,
+                                    "two_pass_ms_per_step": c["two_pass_ms_per_solve"], "passes": c["log_info"].get("passes")}
         if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline(y0, p, t0, t1)
             res["accuracy"] = accuracy_vs_truth(ivp_amd, prob, mk_opts(0), ctx, dev)
@@ -443,18 +450,27 @@ def output_mode_numbers(ivp_amd, prob, wl, t0, t1, y0d, pd, fp, ctx, args, modes
                 byts = rec * (n * 8 + 4)
                 res[mode] = {"samples_per_trajectory": ne, "records": rec}
             elif mode == "csr_log":
+                # The reference's DEFAULT contract: no t_eval => every accepted step in Solution.t / Solution.y
+                # (solout.rs:387-428).  Headline form: ONE integration into the page pool + the gather kernel
+                # (ivp_batch_solve_logged_device), result buffers reused like every other mode here (`out=`).  Beside it: the
+                # same call allocating its result (records fetched from the pool into fresh buffers of exactly `total`), and
+                # the older counted two-pass form (counting solve + scan + filling solve).
                 o = ivp_amd.Options(**base)
-                torch.cuda.synchronize()
-                ivp_amd.solve_ivp_batch_logged(prob, t0, t1d, y0d, pd, o, ctx)
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(k):
-                    out = ivp_amd.solve_ivp_batch_logged(prob, t0, t1d, y0d, pd, o, ctx)
-                torch.cuda.synchronize()
-                ms = (time.perf_counter() - t) / k * 1e3
+                ms, out = timed(lambda prev: ivp_amd.solve_ivp_batch_logged(prob, t0, t1d, y0d, pd, o, ctx, out=prev))
+                info = dict(out.log_info)
                 rec = int(out.t_log.shape[0])
+                del out
+                ms_fresh, out = timed(lambda prev: ivp_amd.solve_ivp_batch_logged(prob, t0, t1d, y0d, pd, o, ctx))
+                del out
+                ms_two, out = timed(lambda prev: ivp_amd.solve_ivp_batch_logged(prob, t0, t1d, y0d, pd, o, ctx, two_pass=True))
+                assert int(out.t_log.shape[0]) == rec
+                del out
+                torch.cuda.empty_cache()
                 byts = rec * (n + 1) * 8
-                res[mode] = {"records": rec, "passes": "counting solve + exclusive scan + filling solve (allocation of the log included)"}
+                res[mode] = {"records": rec, "form": "one integration: page pool + gather kernel (ivp_batch_solve_logged_device), result buffers reused",
+                             "log_info": info, "ms_per_solve_allocating_the_result": ms_fresh,
+                             "two_pass_ms_per_solve": ms_two, "two_pass_form": "counting solve + exclusive scan + filling solve (round 3)",
+                             "gather_traffic_bytes": 2 * byts, "gather_hbm_floor_ms": 2 * byts / (HBM_PEAK_GBS * 1e9) * 1e3}
             elif mode == "dense":
                 ml = int(out_max_log(ivp_amd, prob, t0, t1d, y0d, pd, base, ctx))
                 o = ivp_amd.Options(dense_output=True, max_log=ml, **base)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IVP_HIP_ABI_VERSION 4
+#define IVP_HIP_ABI_VERSION 5
 
 /* Method: same order as `enum Method`, src/solve/options.rs:14-27. The explicit RK methods (RK23, DOPRI5,
  * DOP853, the fixed-step RK4) and the variable-order implicit BDF are on the accelerated path; RADAU returns
@@ -68,7 +68,8 @@ typedef enum {
     IVP_ERR_UNSUPPORTED_METHOD = -101,    /* RADAU: not on the accelerated path (every other method is, for every n) */
     IVP_ERR_NO_DEVICE = -102,             /* no HIP device: there is deliberately no CPU fallback    */
     IVP_ERR_HIP = -103,                   /* a HIP runtime call failed; see ivp_last_error_string()  */
-    IVP_ERR_JIT = -104                    /* hiprtc compilation of a user RHS failed                 */
+    IVP_ERR_JIT = -104,                   /* hiprtc compilation of a user RHS failed                 */
+    IVP_ERR_LOG_CAPACITY = -105           /* ivp_step_log_t: the caller's t / y hold fewer than `total` records (total is set) */
 } ivp_error_t;
 
 /* Right-hand sides that ship as device functors: the `impl IVP for ..` blocks of the reference's
@@ -330,6 +331,65 @@ int ivp_batch_poll(ivp_ctx_t *ctx, int *done);
 int ivp_batch_wait(ivp_ctx_t *ctx);
 
 /*
+ * Solution.t / Solution.y of B solve_ivp() calls in ONE call and ONE integration (ABI v5).
+ *
+ * Without Options.t_eval the reference records every accepted step while it integrates (DefaultSolOut mode 2,
+ * src/solve/solout.rs:387-428) and hands the two growing Vecs back as Solution.t / Solution.y
+ * (src/solve/solve_ivp.rs:288-312).  The entry points below do the same for a batch: the stepping kernels append each
+ * accepted step to per-trajectory chains of fixed-size pages drawn from a device pool, and once every trajectory has
+ * finished a gather kernel lays the records out as a CSR log in trajectory order:
+ *     trajectory b's k-th record:  t[offsets[b] + k],  y[(offsets[b] + k) * n + c]      (time-major like Vec<Vec<f64>>)
+ * with offsets[B] = total.  `out` takes the end-state members / statistics as in ivp_batch_solve (its t_log / y_log /
+ * log_offsets are ignored; n_log, if given, receives the counts); opt->t_eval must be NULL.  Everything else about the
+ * solve (events, first_step enforcement, dense_output segments, every method and state dimension) is unchanged, and the
+ * records are bit-identical to those of the dense [max_log] log and of the counted two-pass CSR log above.
+ *
+ * ivp_step_log_t -- who owns what:
+ *   offsets   [B + 1], ALWAYS the caller's (device memory for the *_device / *_multi forms, host memory for the host form)
+ *   t, y      the caller's buffers of `capacity` records, or both NULL: the library allocates exactly `total` records
+ *             (hipMalloc on the context's / gather device, malloc for the host form), sets owned = 1, and the caller
+ *             releases them with ivp_step_log_free() -- the C rendering of a Vec the callee returns
+ *   reserve   in, optional: expected total number of records; sizes the page pool.  0 = automatic (the previous logged
+ *             solve of this batch size on the context, else 512 records per trajectory, never more than half of the free
+ *             device memory).  A pool that runs dry is not an error: the solve is repeated as the counted fill pass
+ *             (passes = 2), so a log is never truncated
+ *   defer     in: 1 = integrate and count only (total, offsets and `out` are final on return); the records stay in the
+ *             context's pool until its next solve and are fetched with ivp_step_log_fetch_device() into buffers the
+ *             caller sizes from `total`
+ * Returns IVP_ERR_LOG_CAPACITY (with total and offsets set) when the caller's t / y are too small; the records are then
+ * still in the pool: enlarge the buffers and call ivp_step_log_fetch_device().
+ */
+typedef struct {
+    uint64_t *offsets;
+    double *t;
+    double *y;
+    uint64_t capacity;
+    uint64_t reserve;
+    int32_t defer;
+    /* ---- out ---- */
+    int32_t owned;        /* 1: t / y were allocated by the library                                           */
+    int32_t device;       /* HIP device of owned device memory, -1 for host memory                             */
+    uint32_t passes;      /* integrations it took: 1 (page pool) or 2 (the pool ran dry: counted fill pass)    */
+    uint64_t total;       /* number of records = offsets[B]                                                    */
+    uint64_t pool_pages;  /* pages the pool held / pages of 2^page_shift records the log used                  */
+    uint64_t pages_used;
+    uint32_t page_shift;
+} ivp_step_log_t;
+
+int ivp_batch_solve_logged_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0,
+                                  const double *params, const double *t0, size_t t0_len, const double *t1,
+                                  size_t t1_len, const ivp_options_t *opt, ivp_batch_result_t *out,
+                                  ivp_step_log_t *log, void *hip_stream);
+/* the records of the context's last logged solve (defer = 1, or after IVP_ERR_LOG_CAPACITY) into log->t / log->y
+ * (device memory, `capacity` records; both NULL: allocated here); log->offsets is not touched */
+int ivp_step_log_fetch_device(ivp_ctx_t *ctx, ivp_step_log_t *log, void *hip_stream);
+/* host pointers throughout (arguments as ivp_batch_solve; log->offsets / t / y are host memory) */
+int ivp_batch_solve_logged(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0,
+                           const double *params, const double *t0, size_t t0_len, const double *t1,
+                           size_t t1_len, const ivp_options_t *opt, ivp_batch_result_t *out, ivp_step_log_t *log);
+void ivp_step_log_free(ivp_step_log_t *log);
+
+/*
  * One batch over several devices.  The reference has no parallelism (a batch is B back-to-back solve_ivp() calls,
  * src/solve/solve_ivp.rs:99-313, with no coupling between them), so the batch shards by trajectory range: shard k is
  * integrated by its own context on its own device with no communication, and the only data movement is the final
@@ -373,6 +433,21 @@ int ivp_batch_solve_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_probl
 int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_problem_t *prob, size_t B,
                                const double *y0, const double *params, const double *t0, size_t t0_len,
                                const double *t1, size_t t1_len, const ivp_options_t *opt, ivp_batch_result_t *out);
+/*
+ * ivp_batch_solve_multi + the one-pass step log (BASELINE config C4's "gather of sol.y": Solution.y is every accepted
+ * step, src/solve/solution.rs:7-20): every shard integrates ONCE into its own context's page pool; afterwards each
+ * shard's chains are laid out as one contiguous run of the batch-wide CSR log on gather_device -- directly by the
+ * gather kernel for shards that live there, through a staging buffer and a peer copy (xGMI) otherwise -- in trajectory
+ * order, and log->offsets [B + 1] (device memory on gather_device) holds the batch-wide offsets.  `gathered` takes the
+ * SoA members as in ivp_batch_solve_multi (may be NULL); log->t / log->y as in ivp_batch_solve_logged_device
+ * (gather_device memory; NULL = allocated there).  A shard whose pool ran dry repeats its solve as the counted fill pass.
+ */
+int ivp_batch_solve_logged_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_problem_t *prob, size_t B,
+                                 const ivp_options_t *opt, int32_t gather_device, ivp_batch_result_t *gathered,
+                                 ivp_step_log_t *log);
+/* log->defer = 1 in the call above: the records of every shard into log->t / log->y now (same shards, problem, options) */
+int ivp_step_log_fetch_multi(ivp_shard_t *shards, int32_t n_shards, const ivp_problem_t *prob, size_t B,
+                             const ivp_options_t *opt, int32_t gather_device, ivp_step_log_t *log);
 
 /*
  * User-defined right-hand side: the device-side `impl IVP for T { fn ode(..) }` (src/ivp.rs:29).

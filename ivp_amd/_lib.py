@@ -51,6 +51,13 @@ class BatchResultT(C.Structure):
         "seg_cont", "seg_xold", "seg_h", "n_seg", "t_events", "y_events", "n_event_hits", "t_term", "njev", "nlu", "log_offsets")]
 
 
+class StepLogT(C.Structure):
+    """ivp_step_log_t: the CSR accepted-step log of ivp_batch_solve_logged*() (Solution.t / Solution.y of a batch)."""
+    _fields_ = [("offsets", C.c_void_p), ("t", C.c_void_p), ("y", C.c_void_p), ("capacity", C.c_uint64), ("reserve", C.c_uint64),
+                ("defer", C.c_int32), ("owned", C.c_int32), ("device", C.c_int32), ("passes", C.c_uint32), ("total", C.c_uint64),
+                ("pool_pages", C.c_uint64), ("pages_used", C.c_uint64), ("page_shift", C.c_uint32)]
+
+
 class ShardT(C.Structure):
     """ivp_shard_t: trajectories [first, first + count) of a batch, resident on ctx's device (SoA stride count)."""
     _fields_ = [("ctx", C.c_void_p), ("first", C.c_size_t), ("count", C.c_size_t),
@@ -74,13 +81,14 @@ EXPORTS = (
     "ivp_ctx_get_stats", "ivp_options_default", "ivp_options_method_defaults", "ivp_rhs_dims", "ivp_rhs_n_events", "ivp_batch_solve",
     "ivp_batch_solve_device", "ivp_batch_submit_device", "ivp_batch_poll", "ivp_batch_wait", "ivp_batch_solve_multi", "ivp_batch_solve_multi_host",
     "ivp_rhs_compile", "ivp_rhs_compile_events", "ivp_rhs_compile_ex", "ivp_rhs_free",
+    "ivp_batch_solve_logged", "ivp_batch_solve_logged_device", "ivp_step_log_fetch_device", "ivp_step_log_free", "ivp_batch_solve_logged_multi", "ivp_step_log_fetch_multi",
 )
 
 ERRORS = {
     0: "IVP_OK", -1: "IVP_ERR_MUST_BE_POSITIVE", -2: "IVP_ERR_OUT_OF_RANGE", -3: "IVP_ERR_NEGATIVE_TOLERANCE",
     -4: "IVP_ERR_TOLERANCE_SIZE_MISMATCH", -5: "IVP_ERR_INVALID_STEP_SIZE", -6: "IVP_ERR_INVALID_SCALE_FACTORS",
     -100: "IVP_ERR_BAD_ARGUMENT", -101: "IVP_ERR_UNSUPPORTED_METHOD", -102: "IVP_ERR_NO_DEVICE",
-    -103: "IVP_ERR_HIP", -104: "IVP_ERR_JIT",
+    -103: "IVP_ERR_HIP", -104: "IVP_ERR_JIT", -105: "IVP_ERR_LOG_CAPACITY",
 }
 
 _lib = None
@@ -145,6 +153,19 @@ def load():
                                         C.c_int32, C.POINTER(BatchResultT)]
     L.ivp_batch_solve_multi_host.restype = C.c_int
     L.ivp_batch_solve_multi_host.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + solve_args[1:]
+    L.ivp_batch_solve_logged.restype = C.c_int
+    L.ivp_batch_solve_logged.argtypes = solve_args + [C.POINTER(StepLogT)]
+    L.ivp_batch_solve_logged_device.restype = C.c_int
+    L.ivp_batch_solve_logged_device.argtypes = solve_args + [C.POINTER(StepLogT), C.c_void_p]
+    L.ivp_step_log_fetch_device.restype = C.c_int
+    L.ivp_step_log_fetch_device.argtypes = [C.c_void_p, C.POINTER(StepLogT), C.c_void_p]
+    L.ivp_step_log_free.restype = None
+    L.ivp_step_log_free.argtypes = [C.POINTER(StepLogT)]
+    L.ivp_batch_solve_logged_multi.restype = C.c_int
+    L.ivp_batch_solve_logged_multi.argtypes = [C.POINTER(ShardT), C.c_int32, C.POINTER(ProblemT), C.c_size_t, C.POINTER(OptionsT),
+                                               C.c_int32, C.POINTER(BatchResultT), C.POINTER(StepLogT)]
+    L.ivp_step_log_fetch_multi.restype = C.c_int
+    L.ivp_step_log_fetch_multi.argtypes = [C.POINTER(ShardT), C.c_int32, C.POINTER(ProblemT), C.c_size_t, C.POINTER(OptionsT), C.c_int32, C.POINTER(StepLogT)]
     L.ivp_rhs_compile.restype = C.c_int
     L.ivp_rhs_compile.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.ivp_rhs_compile_events.restype = C.c_int

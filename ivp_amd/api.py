@@ -683,6 +683,8 @@ class BatchSolution:
     log_offsets: object = None   # CSR step log (solve_ivp_batch_logged): [B+1] record offsets; t_log [total], y_log [total, n]
     stats: dict = field(default_factory=dict)
     event_overflow: bool = False  # some trajectory detected more occurrences of an event than max_events could store
+    log_info: dict = field(default_factory=dict)   # solve_ivp_batch_logged: passes (1 = page pool, 2 = counted fill pass), pages, ...
+    _log_buffers: object = None   # the full-capacity t / y buffers behind t_log / y_log (reused through `out=`)
 
     def eval_of(self, b: int):
         """(index into trajectory b's own t_eval grid, y) of its emitted samples (per-trajectory grids); index -1 marks the
@@ -764,7 +766,7 @@ class PendingBatch:
 
 
 def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ctx: Context = None,
-                    out: BatchSolution = None, wait: bool = True):
+                    out: BatchSolution = None, wait: bool = True, _steplog=None):
     """B independent ``solve_ivp(f, t0[b], t1[b], y0[:, b], options)`` calls on the GPU.
 
     ``y0``: ``[n, B]`` float64, numpy (host path: staged through the library) or a CUDA torch tensor
@@ -894,7 +896,7 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         res.eval_offsets = __import__("torch").as_tensor(offs, device=y0.device) if on_device else offs
     if options.count_log and res.n_log is None:
         res.n_log = xp_zeros((B,), u32)
-    if options.t_eval is None and ml > 0 and res.t_log is None and res.log_offsets is None:
+    if options.t_eval is None and ml > 0 and res.t_log is None and res.log_offsets is None and _steplog is None:
         res.t_log = xp_zeros((ml, B), f64)
         res.y_log = xp_zeros((ml, n, B), f64)
         res.n_log = xp_zeros((B,), u32)
@@ -937,7 +939,16 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
         if rc != 0:
             raise ConfigError(rc, ctx.last_error())
         return PendingBatch(ctx, res, bool(options.profile), keep + [y0, params, t0a, t1a, copt, r])
-    if on_device:
+    if _steplog is not None:   # solve_ivp_batch_logged: ONE integration that also records every accepted step (page pool + gather)
+        import torch
+        if not on_device:
+            raise ValueError("the one-pass step log takes device arrays")
+        stream = C.c_void_p(torch.cuda.current_stream(y0.device).cuda_stream)
+        rc = ctx.lib.ivp_batch_solve_logged_device(ctx.handle, C.byref(prob), B, ptr(y0), ptr(params), ptr(t0a), t0_len,
+                                                   ptr(t1a), t1_len, C.byref(copt), C.byref(r), C.byref(_steplog), stream)
+        if rc == -105:   # IVP_ERR_LOG_CAPACITY: the integration is complete, the records wait in the pool for larger buffers
+            rc = 0
+    elif on_device:
         import torch
         stream = C.c_void_p(torch.cuda.current_stream(y0.device).cuda_stream)
         rc = ctx.lib.ivp_batch_solve_device(ctx.handle, C.byref(prob), B, ptr(y0), ptr(params), ptr(t0a), t0_len,
@@ -953,21 +964,25 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
     return res
 
 
-def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = None, ctx: Context = None) -> BatchSolution:
-    """``Solution.t`` / ``Solution.y`` of B independent solves -- every accepted step of every trajectory -- in CSR form.
+def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = None, ctx: Context = None,
+                           out: BatchSolution = None, reserve: int = 0, two_pass: bool = False) -> BatchSolution:
+    """``Solution.t`` / ``Solution.y`` of B independent solves -- every accepted step of every trajectory -- in CSR form,
+    from ONE integration (``ivp_batch_solve_logged_device``).
 
-    The reference pushes one record per accepted step into growing Vecs (src/solve/solout.rs:387-428).  A dense
-    ``[max_log, n, B]`` buffer sized for the longest trajectory wastes memory on all others, so this runs two passes on
-    the device: a counting solve (``Options.count_log``: the device DefaultSolOut runs, nothing is stored), an
-    exclusive scan of the counts, and the filling solve that writes record k of trajectory b at ``offsets[b] + k``.
-    The integration is deterministic, so both passes take identical steps.  Memory: ``sum(n_log) * (n + 1) * 8`` bytes.
+    The reference pushes one record per accepted step into growing Vecs while it integrates (src/solve/solout.rs:387-428)
+    and returns them (src/solve/solve_ivp.rs:288-312).  Here the stepping kernels append the records to per-trajectory
+    chains of pages drawn from a device pool; once every count is known a gather kernel lays them out in trajectory order.
+    ``reserve``: expected total number of records (sizes the pool; default: what the context learnt from its last logged
+    solve of this batch size, else 512 per trajectory).  A pool that runs dry costs a second integration, never records.
+    ``out``: a previous result of this function whose buffers are reused when they are large enough (one library call, no
+    allocation).  ``two_pass=True`` runs the older counted form (counting solve + scan + filling solve) instead.
 
     Returns a BatchSolution with ``log_offsets`` [B+1], ``t_log`` [total], ``y_log`` [total, n] (time-major like the
-    reference's ``Vec<Vec<f64>>``), ``n_log`` and the end-state members; ``log_of(b)`` slices one trajectory.
-    ``y0`` may be a numpy array (moved to the context's device) or a CUDA tensor."""
+    reference's ``Vec<Vec<f64>>``), ``n_log``, the end-state members and ``log_info``; ``log_of(b)`` slices one
+    trajectory.  ``y0`` may be a numpy array (moved to the context's device) or a CUDA tensor."""
     import torch
     options = options or Options()
-    if options.t_eval is not None:
+    if options.t_eval is not None or options.t_eval_per_trajectory is not None:
         raise ValueError("the accepted-step log is what solve_ivp records when t_eval is None")
     ctx = ctx or default_context(y0.device.index or 0 if _is_torch(y0) else 0)
     dev = y0.device if _is_torch(y0) else torch.device("cuda", ctx.device)
@@ -977,16 +992,61 @@ def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = N
     t0d, t1d = tt(t0), tt(t1)
     n, B = int(y0d.shape[0]), int(y0d.shape[1])
     base = {k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log", "profile")}
-    cnt = solve_ivp_batch(f, t0d, t1d, y0d, pd, Options(**base, max_log=options.max_log if options.dense_output else 0, count_log=True), ctx)
-    offsets = torch.zeros(B + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(cnt.n_log.to(torch.int64), 0, out=offsets[1:])
-    total = int(offsets[-1].item())
-    out = BatchSolution(y_end=cnt.y_end, t_end=cnt.t_end, status=cnt.status, nfev=cnt.nfev, nstep=cnt.nstep, naccpt=cnt.naccpt,
-                        nrejct=cnt.nrejct, h_next=cnt.h_next, njev=cnt.njev, nlu=cnt.nlu, n_log=cnt.n_log,
-                        t_log=torch.empty(max(total, 1), dtype=torch.float64, device=dev),
-                        y_log=torch.empty((max(total, 1), n), dtype=torch.float64, device=dev), log_offsets=offsets)
-    res = solve_ivp_batch(f, t0d, t1d, y0d, pd, Options(**base, max_log=options.max_log if options.dense_output else 0, profile=options.profile), ctx, out)
-    res.t_log, res.y_log = res.t_log[:total], res.y_log[:total]
+    ml = options.max_log if options.dense_output else 0
+    if two_pass:
+        cnt = solve_ivp_batch(f, t0d, t1d, y0d, pd, Options(**base, max_log=ml, count_log=True), ctx)
+        offsets = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(cnt.n_log.to(torch.int64), 0, out=offsets[1:])
+        total = int(offsets[-1].item())
+        o2 = BatchSolution(y_end=cnt.y_end, t_end=cnt.t_end, status=cnt.status, nfev=cnt.nfev, nstep=cnt.nstep, naccpt=cnt.naccpt,
+                           nrejct=cnt.nrejct, h_next=cnt.h_next, njev=cnt.njev, nlu=cnt.nlu, n_log=cnt.n_log,
+                           t_log=torch.empty(max(total, 1), dtype=torch.float64, device=dev),
+                           y_log=torch.empty((max(total, 1), n), dtype=torch.float64, device=dev), log_offsets=offsets)
+        res = solve_ivp_batch(f, t0d, t1d, y0d, pd, Options(**base, max_log=ml, profile=options.profile), ctx, o2)
+        res.t_log, res.y_log = res.t_log[:total], res.y_log[:total]
+        res.log_info = {"passes": 2, "form": "counting solve + scan + filling solve"}
+        return res
+
+    sl = _lib.StepLogT()
+    offsets = out.log_offsets if (out is not None and out.log_offsets is not None and tuple(out.log_offsets.shape) == (B + 1,)) \
+        else torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    sl.offsets = C.c_void_p(offsets.data_ptr())
+    sl.reserve = int(reserve)
+    bufs = getattr(out, "_log_buffers", None) if out is not None else None
+    if bufs is not None and (bufs[0].device != dev or bufs[1].shape[1] != n):
+        bufs = None
+    if bufs is not None:
+        sl.t, sl.y, sl.capacity = C.c_void_p(bufs[0].data_ptr()), C.c_void_p(bufs[1].data_ptr()), int(bufs[0].shape[0])
+    else:
+        sl.defer = 1     # integrate and count; the records are fetched into buffers of exactly `total` records below
+    if out is not None:
+        keep = ("y_end", "t_end", "status", "nfev", "nstep", "naccpt", "nrejct", "h_next", "njev", "nlu", "n_log", "seg_cont", "seg_xold",
+                "seg_h", "n_seg", "t_events", "y_events", "n_event_hits", "t_term")
+        o1 = BatchSolution(**{k: getattr(out, k) for k in keep})
+    else:
+        o1 = BatchSolution(y_end=torch.zeros((n, B), dtype=torch.float64, device=dev), t_end=torch.zeros(B, dtype=torch.float64, device=dev),
+                           status=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int64, device=dev),
+                           nstep=torch.zeros(B, dtype=torch.int64, device=dev), naccpt=torch.zeros(B, dtype=torch.int64, device=dev),
+                           nrejct=torch.zeros(B, dtype=torch.int64, device=dev), h_next=torch.zeros(B, dtype=torch.float64, device=dev))
+    if o1.n_log is None:
+        o1.n_log = torch.zeros(B, dtype=torch.int32, device=dev)
+    opts1 = Options(**base, max_log=ml, profile=options.profile)
+    res = solve_ivp_batch(f, t0d, t1d, y0d, pd, opts1, ctx, o1, _steplog=sl)
+    total = int(sl.total)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if bufs is None or sl.capacity < total:
+        # first call / grown log: buffers of exactly `total` records, filled from the pool (no second integration)
+        bufs = (torch.empty(max(total, 1), dtype=torch.float64, device=dev), torch.empty((max(total, 1), n), dtype=torch.float64, device=dev))
+        sl.t, sl.y, sl.capacity, sl.defer = C.c_void_p(bufs[0].data_ptr()), C.c_void_p(bufs[1].data_ptr()), max(total, 1), 0
+        rc = ctx.lib.ivp_step_log_fetch_device(ctx.handle, C.byref(sl), stream)
+        if rc != 0:   # the pool had run dry: integrate again -- its size now follows the counted total
+            res = solve_ivp_batch(f, t0d, t1d, y0d, pd, opts1, ctx, o1, _steplog=sl)
+            sl.passes += 1
+    res.log_offsets = offsets
+    res._log_buffers = bufs
+    res.t_log, res.y_log = bufs[0][:total], bufs[1][:total]
+    res.log_info = {"passes": int(sl.passes), "records": total, "page_records": 1 << int(sl.page_shift), "pool_pages": int(sl.pool_pages),
+                    "pages_used": int(sl.pages_used), "form": "page pool + gather (one integration)" if sl.passes == 1 else "the pool ran dry: second integration"}
     return res
 
 

@@ -377,11 +377,12 @@ __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32
     L.x0 = a.t0[(size_t)j * a.t0_stride];
     L.xend = a.t1[(size_t)j * a.t1_stride];
     L.flags = 0;
-    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_page = IVP_NO_PAGE;
     auto store_so = [&]() {
         if (FULL) {
             a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
             a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+            if (a.log_cur) a.log_cur[j] = L.log_page;
         }
     };
     a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; a.njev[j] = 0; a.nlu[j] = 0;
@@ -809,8 +810,9 @@ __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint
     if (FULL) {
         L.next_idx = a.next_idx[j]; L.n_filled = a.n_filled[j]; L.n_log = a.n_log[j];
         L.n_seg = a.n_seg[j]; L.t_last = a.t_last[j];
+        L.log_page = a.log_cur ? a.log_cur[j] : IVP_NO_PAGE;
     } else {
-        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_page = IVP_NO_PAGE;
     }
     uint32_t it = 0;
     bool run = true;
@@ -844,6 +846,7 @@ __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint
     if (FULL) {
         a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+        if (a.log_cur) a.log_cur[j] = L.log_page;
     }
     status_out = S.status;
     return it;

@@ -22,6 +22,9 @@
 #include "ivp_jit.h"
 #include "ivp_kargs.h"
 #include "rk_launch.h"
+#include "ivp_ctx.h"
+
+using namespace ivp_host;
 
 namespace {
 
@@ -58,72 +61,7 @@ MethodSettings settings_of(const ivp_options_t *opt)
 
 int ncoef_of(int method) { return method == IVP_DOPRI5 ? 5 : method == IVP_DOP853 ? 8 : method == IVP_BDF ? 7 : 4; }
 
-// grow-only device buffer
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes;
-        return e;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
 }  // namespace
-
-struct ivp_ctx {
-    int device = 0;
-    // the part's geometry (hipDeviceProp_t): the launch policy sizes everything from it.  CDNA compute units have
-    // 4 SIMDs and wave64; multiProcessorCount is 256 on MI355X, 304 on MI300X, fewer on a partitioned device.
-    uint32_t cus = 256, simds = 1024;
-    uint32_t one_wave_per_simd() const { return simds * (uint32_t)IVP_WAVE; }   // lanes that fill every SIMD with one wave
-    std::string err;
-    // scratch (device)
-    DevBuf k1, facold, hlamb, flags, perm[2], counts, slot, ran, teval, teval_off, evcfg, tolvec, zero_off;
-    DevBuf sc_y, sc_x, sc_h, sc_status, sc_nfev, sc_nstep, sc_naccpt, sc_nrejct;
-    DevBuf sc_next_idx, sc_n_filled, sc_n_log, sc_n_seg, sc_t_last;
-    DevBuf bdf_d, bdf_jac, bdf_lu, bdf_piv, sc_njev, sc_nlu, prev_event, sc_n_ev;
-    // staging for the host-pointer entry point
-    DevBuf st_y0, st_params, st_t0, st_t1;
-    DevBuf st_out[24];
-    DevBuf st_logoff;   // this shard's CSR step-log offsets (host-pointer entry points)
-    uint32_t *pinned = nullptr;  // host-pinned: active count + misc
-    std::vector<hipEvent_t> events;
-    ivp_run_stats_t stats{};
-    // ---- the solve in flight (ivp_batch_submit_device .. ivp_batch_poll / ivp_batch_wait) ----
-    struct Pending {
-        bool active = false;
-        IvpKArgs a;
-        ivp_problem_t prob;
-        int method = 0, fp_mode = 0, variant = 0, profile = 0, n = 0;
-        bool full = false, group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false, lds_lu_ok = false, has_events = false;
-        uint32_t chunk = 64, lanes = 0;
-        uint32_t chunk_now = 64;    // attempts per bulk launch of the next round (adaptive: follows the decay of the active set)
-        uint32_t quiet_rounds = 0;  // consecutive rounds that retired (almost) nobody
-        size_t B = 0;
-        uint64_t c = 0;             // chunk launches so far
-        bool spec = false;          // the last launch of the round in flight was a speculative cooperative one
-        bool err_checked = false;
-        hipStream_t stream = nullptr;
-        hipEvent_t round_done = nullptr;
-        size_t ev_used = 0;
-        hipEvent_t ev_t0 = nullptr, ev_init1 = nullptr;
-        std::vector<std::pair<hipEvent_t, hipEvent_t>> step_ev;
-        std::vector<char> step_is_coop;
-        std::vector<uint32_t> step_lanes;   // active count the host knew when it enqueued the launch (profiling trace)
-    } pend;
-};
 
 namespace {
 
@@ -138,29 +76,11 @@ void set_active(ivp_ctx *ctx, bool on)
     inflight_on(ctx->device).fetch_add(on ? 1 : -1, std::memory_order_relaxed);
 }
 
-int fail(ivp_ctx *ctx, int code, const char *fmt, ...)
-{
-    if (ctx) {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        ctx->err = buf;
-    }
-    return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                       \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) return fail((ctx), IVP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
 // Options validation: the checks XXX::solve() makes before integrating
 // (dopri5.rs:143-198, dop853.rs:135-193, rk23.rs:102-129) for the fields solve_ivp() can set, plus
 // the Tolerance length rule (mod.rs:156-161).
-int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_options_t *opt, int *n_out, int *p_out)
+}  // namespace
+int ivp_host::validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_options_t *opt, int *n_out, int *p_out)
 {
     if (!prob || !opt) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "null problem/options");
     int n, p;
@@ -216,6 +136,7 @@ int validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const ivp_option
     *p_out = p;
     return IVP_OK;
 }
+namespace {
 
 // Launch-policy knobs.  The defaults are the measured optimum for the BASELINE configs on MI355X; the environment
 // overrides exist for tuning runs (tools/tune_policy.py) and are read once per process.
@@ -244,12 +165,6 @@ const Tune &tune() { static const Tune t; return t; }
 // IVP_TRACE_LAUNCHES=1 with Options.profile: one stderr line per stepping-kernel launch (kind, ran / declined, duration)
 bool trace_launches() { static const bool on = getenv("IVP_TRACE_LAUNCHES") != nullptr; return on; }
 size_t coop_cap_lanes(const ivp_ctx *ctx) { return tune().coop_cap_lanes ? tune().coop_cap_lanes : 2u * (size_t)ctx->one_wave_per_simd(); }
-// restores the caller's current HIP device when a multi-device entry point returns
-struct DeviceGuard {
-    int dev = -1;
-    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
-    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
-};
 
 constexpr uint32_t kMaxRanSlots = 1u << 16;   // profiled launches whose "did work" flag is recorded
 
@@ -430,7 +345,7 @@ int enqueue_round(ivp_ctx *ctx)
         }
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((P.c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (!P.err_checked) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!P.err_checked || P.paged) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(P.round_done, s));
     return IVP_OK;
 }
@@ -470,6 +385,10 @@ int finish_round(ivp_ctx *ctx, int *done)
     if (P.lanes != 0) return enqueue_round(ctx);
     set_active(ctx, false);
     *done = 1;
+    if (P.paged) {   // one-pass step log: the pool holds every record unless it ran dry on the way (ivp_log.cpp decides what follows)
+        ctx->log_state.overflow = (ctx->pinned[1] & 0x2u) != 0;   // IVP_ERRFLAG_LOG_OVERFLOW
+        ctx->log_state.valid = !ctx->log_state.overflow;
+    }
     if (P.profile) {
         hipStream_t s = P.stream;
         hipEvent_t ev_end = pend_event(ctx);
@@ -570,7 +489,8 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
                       &c->sc_y, &c->sc_x, &c->sc_h, &c->sc_status, &c->sc_nfev, &c->sc_nstep, &c->sc_naccpt, &c->sc_nrejct,
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
-                      &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1, &c->st_logoff};
+                      &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1, &c->st_logoff,
+                      &c->log_pool, &c->log_cur, &c->log_off, &c->log_bsum, &c->st_log_t, &c->st_log_y};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -647,12 +567,18 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     if ((t0_len != 1 && t0_len != B) || (t1_len != 1 && t1_len != B)) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "t0/t1 length must be 1 or B");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)hip_stream;
+    // one-pass step log: ivp_log.cpp set the plan for THIS submit (Solution.t / Solution.y into the page pool)
+    const bool paged = ctx->log_plan.want;
+    const uint64_t log_reserve = ctx->log_plan.reserve;
+    ctx->log_plan = ivp_ctx::LogPlan{};
+    if (paged) { ctx->log_state.valid = false; ctx->log_state.overflow = false; }
+    if (paged && opt->t_eval) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "the accepted-step log is what solve_ivp records when t_eval is None");
 
     const bool want_eval = opt->t_eval != nullptr;
-    const bool csr_log = !want_eval && out->log_offsets && out->t_log && out->y_log;    // fill pass of the CSR step log
-    const bool count_log = !want_eval && opt->count_log != 0 && !csr_log;               // counting pass: n_log only
+    const bool csr_log = !paged && !want_eval && out->log_offsets && out->t_log && out->y_log;    // fill pass of the CSR step log
+    const bool count_log = !paged && !want_eval && opt->count_log != 0 && !csr_log;               // counting pass: n_log only
     if (opt->count_log && !out->n_log) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "count_log needs out.n_log");
-    const bool want_log = csr_log || count_log || (!want_eval && opt->max_log > 0 && out->t_log && out->y_log);
+    const bool want_log = paged || csr_log || count_log || (!want_eval && opt->max_log > 0 && out->t_log && out->y_log);
     const bool want_dense = opt->dense_output && opt->max_log > 0 && out->seg_cont && out->seg_xold && out->seg_h;
     const bool group = n > IVP_MAX_N;
     const int n_events = prob->rhs_id == IVP_RHS_JIT ? ivp_jit_n_events(prob->jit) : group ? 0 : kRhsEvents[prob->rhs_id];
@@ -756,7 +682,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     HIP_TRY(ctx, ctx->flags.reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[0].reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[1].reserve(sizeof(uint32_t) * B));
-    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 8));  // [0..3] active-count ring, [4] error flags
+    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 8));  // [0..3] active-count ring, [4] error flags, [5] pages handed out by the step-log pool
     a.k1 = (double *)ctx->k1.p;
     a.facold = (double *)ctx->facold.p;
     a.hlamb = (double *)ctx->hlamb.p;
@@ -808,7 +734,36 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         a.next_idx = (int32_t *)ctx->sc_next_idx.p;
         a.t_last = (double *)ctx->sc_t_last.p;
         a.max_log = (want_log || want_dense) ? opt->max_log : 0;
-        if (count_log) {
+        if (paged) {
+            // One-pass step log (ivp_kargs.h): pages of R records, R chosen so that a page is ~2 KB (two contiguous copies per
+            // page in the gather, half a page wasted per trajectory), drawn from a pool sized from the caller's estimate, the
+            // last logged solve of this batch size on this context, or 512 records per trajectory -- a pool that turns out too
+            // small costs a second integration (the counted fill pass), never a wrong or truncated log.
+            uint32_t shift = 0;
+            while (shift < 6 && ((size_t)(n + 1) << (shift + 1)) * 8 <= 2048) ++shift;
+            const size_t R = (size_t)1 << shift, page_bytes = (1 + (size_t)(n + 1) * R) * 8;
+            ivp_ctx::LogState &LS = ctx->log_state;
+            uint64_t recs = log_reserve ? log_reserve : (LS.total && LS.last_B == B ? LS.total + LS.total / 8 : (uint64_t)B * 512u);
+            uint64_t pages = recs / R + B + 64;
+            if (pages * page_bytes > ctx->log_pool.cap) {   // growing: never ask for more than half of what the device can give
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    const uint64_t most = (uint64_t)(free_b + ctx->log_pool.cap) / 2 / page_bytes;
+                    if (pages > most) pages = std::max<uint64_t>(most, ctx->log_pool.cap / page_bytes);
+                }
+            }
+            pages = std::min<uint64_t>(std::max<uint64_t>(pages, 1), 0xFFFFFFF0ull);
+            HIP_TRY(ctx, ctx->log_pool.reserve((size_t)pages * page_bytes));
+            HIP_TRY(ctx, ctx->log_cur.reserve(sizeof(uint32_t) * B));
+            a.log_pool = (double *)ctx->log_pool.p;
+            a.log_page_shift = shift;
+            a.log_pool_pages = (uint32_t)std::min<uint64_t>(ctx->log_pool.cap / page_bytes, 0xFFFFFFF0ull);
+            a.log_pool_next = (uint32_t *)ctx->counts.p + 5;
+            a.log_cur = (uint32_t *)ctx->log_cur.p;
+            a.t_log = a.log_pool;   // "mode 2" marker of the device DefaultSolOut (so_sample); the records go to the pages
+            a.y_log = a.log_pool;
+            LS.B = B; LS.n = n; LS.shift = shift; LS.pool_pages = a.log_pool_pages; LS.n_log = a.n_log;
+        } else if (count_log) {
             // counting pass = a CSR log whose offsets are all zero: so_sample runs (t_log != NULL), every record finds
             // capacity 0 and only n_log advances
             HIP_TRY(ctx, ctx->zero_off.reserve(sizeof(unsigned long long) * (B + 1)));
@@ -856,6 +811,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.has_settings = opt->has_settings != 0;
     P.lds_lu_ok = lds_lu_ok;
     P.has_events = n_events > 0;
+    P.paged = paged;
     // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for problems with
     // n <= 8.  Results are bit-identical to the thread-per-trajectory kernels in both arithmetic modes, so the loop
     // switches to them for the latency-bound tail.
@@ -940,12 +896,7 @@ int ivp_batch_solve(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const d
 
 }  // extern "C"
 
-namespace {
-
-// Every member of ivp_batch_result_t as (offset, element size, rows): a member is `rows` SoA rows of B elements.
-struct MemberDesc { size_t off, elem, rows; };
-struct ResultShape { size_t n, ne_rows, ml, nc, nev, mev; };
-ResultShape result_shape(const ivp_problem_t *prob, const ivp_options_t *opt, int n)
+ivp_host::ResultShape ivp_host::result_shape(const ivp_problem_t *prob, const ivp_options_t *opt, int n)
 {
     ResultShape r;
     r.n = (size_t)n;
@@ -957,8 +908,7 @@ ResultShape result_shape(const ivp_problem_t *prob, const ivp_options_t *opt, in
     r.mev = opt->max_events;
     return r;
 }
-constexpr int kMembers = 24;
-void member_table(const ResultShape &r, MemberDesc (&m)[kMembers])
+void ivp_host::member_table(const ResultShape &r, MemberDesc (&m)[kMembers])
 {
 #define M(field, elem, rows) MemberDesc{offsetof(ivp_batch_result_t, field), (size_t)(elem), (size_t)(rows)}
     const MemberDesc t[kMembers] = {
@@ -972,11 +922,8 @@ void member_table(const ResultShape &r, MemberDesc (&m)[kMembers])
 #undef M
     for (int i = 0; i < kMembers; ++i) m[i] = t[i];
 }
-inline void *&member(ivp_batch_result_t *r, const MemberDesc &d) { return *(void **)((char *)r + d.off); }
-inline void *member(const ivp_batch_result_t *r, const MemberDesc &d) { return *(void *const *)((const char *)r + d.off); }
-
 // rows x (count elements) between two SoA arrays of different stride
-hipError_t copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t elem, size_t count, size_t rows,
+hipError_t ivp_host::copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t elem, size_t count, size_t rows,
                      hipMemcpyKind kind, hipStream_t s)
 {
     if (!rows || !count) return hipSuccess;
@@ -986,7 +933,7 @@ hipError_t copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_s
 
 // device -> device, possibly across devices: peer-enabled 2-D copy (xGMI) when the runtime allows it, else one
 // hipMemcpyPeerAsync per row
-hipError_t copy_rows_peer(void *dst, int dst_dev, size_t dst_stride, const void *src, int src_dev, size_t src_stride, size_t elem,
+hipError_t ivp_host::copy_rows_peer(void *dst, int dst_dev, size_t dst_stride, const void *src, int src_dev, size_t src_stride, size_t elem,
                           size_t count, size_t rows, hipStream_t s)
 {
     if (!rows || !count) return hipSuccess;
@@ -1007,6 +954,8 @@ hipError_t copy_rows_peer(void *dst, int dst_dev, size_t dst_stride, const void 
     }
     return hipSuccess;
 }
+
+namespace {
 
 // per-trajectory t_eval grids: the sample records of trajectories [first, first + count) in the batch-wide CSR arrays
 struct EvalRun { size_t first, count; };

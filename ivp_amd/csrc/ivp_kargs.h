@@ -133,4 +133,18 @@ struct IvpKArgs {
                               // FIRST, so the next launch's window starts with them).  A thread-per-trajectory wave saturates the
                               // f64 pipe of its SIMD on its own, so a launch of 1563 waves on 1024 SIMDs lasts as long as one of
                               // 2048: the launch loop cuts such a launch down to whole multiples of one wave per SIMD.
+    // ---- one-pass accepted-step log (so_push_log): records go to fixed-size PAGES drawn from a device pool ----
+    // The reference pushes every accepted step into growing Vecs (solout.rs:387-428); a GPU lane cannot grow a Vec, and a
+    // counting solve before the filling solve costs a whole second integration.  With log_pool != NULL a trajectory's records
+    // go to pages of R = 1 << log_page_shift records that are bump-allocated from the pool whenever the previous page is full
+    // (one atomicAdd per wave and allocation round).  A page is [header: 1 double][t: R doubles][y: R x n doubles, time-major];
+    // the header holds the id of the trajectory's PREVIOUS page (IVP_NO_PAGE for its first), log_cur[j] the id of its current
+    // (last) page: a chain per trajectory, any length.  Once every count is known a gather kernel (log_gather.hip) walks the
+    // chains and lays the records out as the CSR log (t_log [total], y_log [total][n]) with two contiguous copies per page.
+    double *log_pool;         // pages; NULL = the dense / two-pass CSR forms above
+    uint32_t log_page_shift;
+    uint32_t log_pool_pages;  // capacity in pages; beyond it records are counted but not stored (IVP_ERRFLAG_LOG_OVERFLOW)
+    uint32_t *log_pool_next;  // device counter: pages handed out so far
+    uint32_t *log_cur;        // [B] the page that takes the trajectory's next record (IVP_NO_PAGE: none yet / pool exhausted)
 };
+#define IVP_NO_PAGE 0xFFFFFFFFu

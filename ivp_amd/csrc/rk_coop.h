@@ -203,6 +203,9 @@ struct OutMap<CoopRhs<R>, void> {
         enum { NT = R::N };
         static __device__ __forceinline__ int gi(int) { return (int)coop_comp<R>(); }
         static __device__ __forceinline__ bool own(int) { return coop_comp<R>() < (uint32_t)NT; }
+        // the group's first lane acts for the trajectory (one-pass step log: page allocation), its seven partners read its result
+        static __device__ __forceinline__ bool leader() { return (threadIdx.x & 7u) == 0u; }
+        static __device__ __forceinline__ uint32_t bcast(uint32_t v) { return (uint32_t)__shfl((int)v, (int)(threadIdx.x & ~7u)); }
     };
 };
 template <class R>

@@ -130,6 +130,8 @@ __device__ __forceinline__ uint64_t ivp_opaque_zero_v()
 #endif
 // whole-call validation failures that can only be detected per trajectory (the reference's Err(Error::Config))
 #define IVP_ERRFLAG_INVALID_STEP 0x1u
+// the page pool of the one-pass accepted-step log ran dry (IvpKArgs.log_pool): records were counted but not all stored
+#define IVP_ERRFLAG_LOG_OVERFLOW 0x2u
 IVP_HD void ivp_flag_error(const IvpKArgs &a, uint32_t bit)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -516,6 +518,10 @@ struct IdMap {
     enum { NT = N };
     static IVP_HD int gi(int c) { return c; }
     static IVP_HD bool own(int) { return true; }
+    // lanes that hold one trajectory together (rk_coop.h, rk_group.h) elect one of them for per-trajectory side effects
+    // (a page allocation of the one-pass step log) and share its result; a lane that owns its trajectory is its own leader
+    static IVP_HD bool leader() { return true; }
+    static IVP_HD uint32_t bcast(uint32_t v) { return v; }
 };
 template <class R, class = void>
 struct OutMap { using type = IdMap<R::N>; };
@@ -563,6 +569,7 @@ struct Lane {
     int32_t next_idx, n_filled;
     uint32_t n_log, n_seg;
     double t_last;
+    uint32_t log_page;    // one-pass step log: the page that takes the next record (IvpKArgs.log_cur)
 };
 
 template <class R>
@@ -603,8 +610,9 @@ IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool r
         L.n_log = a.n_log[j];
         L.n_seg = a.n_seg[j];
         L.t_last = a.t_last[j];
+        L.log_page = a.log_cur ? a.log_cur[j] : IVP_NO_PAGE;
     } else {
-        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_page = IVP_NO_PAGE;
     }
 }
 
@@ -632,6 +640,7 @@ IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L,
         a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg;
         a.t_last[j] = L.t_last;
+        if (a.log_cur) a.log_cur[j] = L.log_page;
     }
 }
 
@@ -783,11 +792,54 @@ IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t t
     }
     L.n_filled += 1;
 }
+// One page of the one-pass step log from the pool (IvpKArgs.log_pool).  The lanes of a wave that need a page in the same
+// allocation round share ONE atomicAdd (ballot -> popcount -> the first of them adds -> rank among the set bits); lanes
+// that hold a trajectory together get the page their leader drew.  IVP_NO_PAGE once the pool is exhausted: the records
+// are still counted (n_log), the host sees IVP_ERRFLAG_LOG_OVERFLOW and falls back to the counted two-pass log.
+template <class MAP>
+IVP_HD uint32_t so_log_new_page(const IvpKArgs &a)
+{
+    uint32_t page = IVP_NO_PAGE;
+    if (MAP::leader()) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned long long m = __ballot(true);
+        const uint32_t lane = __lane_id();
+        const int first = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == first) base = atomicAdd(a.log_pool_next, (uint32_t)__popcll(m));
+        page = (uint32_t)__shfl((int)base, first) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+#else
+        page = (*a.log_pool_next)++;
+#endif
+        if (page >= a.log_pool_pages) {
+            page = IVP_NO_PAGE;
+            ivp_flag_error(a, IVP_ERRFLAG_LOG_OVERFLOW);
+        }
+    }
+    return MAP::bcast(page);
+}
 template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, const double *yv)
 {
     const size_t B = a.B;
-    if (a.log_off != nullptr) {
+    if (a.log_pool != nullptr) {
+        // one-pass log: record k of the trajectory goes to slot k mod R of its current page (ivp_kargs.h); a full page is
+        // followed by a fresh one from the pool, chained to its predecessor through the page header
+        const uint32_t slot = L.n_log & ((1u << a.log_page_shift) - 1u);
+        const size_t page_doubles = 1u + ((size_t)(MAP::NT + 1) << a.log_page_shift);
+        if (slot == 0u) {
+            const uint32_t fresh = so_log_new_page<MAP>(a);
+            if (fresh != IVP_NO_PAGE && MAP::leader()) *(uint32_t *)(a.log_pool + (size_t)fresh * page_doubles) = L.log_page;
+            L.log_page = fresh;
+        }
+        if (L.log_page != IVP_NO_PAGE) {
+            double *pg = a.log_pool + (size_t)L.log_page * page_doubles + 1;
+            pg[slot] = t;
+            double *py = pg + ((size_t)1 << a.log_page_shift) + (size_t)slot * MAP::NT;
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (MAP::own(c)) py[MAP::gi(c)] = yv[c];
+        }
+    } else if (a.log_off != nullptr) {
         // CSR log (two-pass count / fill): record k of trajectory j lives at log_off[j] + k, memory = sum of the counts
         const unsigned long long lo = a.log_off[j], cap = a.log_off[j + 1] - lo;
         if (L.n_log < cap) {
@@ -1118,7 +1170,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     L.flags = 0;
     L.facold = 1e-4;
     L.hlamb = 0.0;
-    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_page = IVP_NO_PAGE;
     uint64_t nfev = 0;
 
     if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
@@ -1143,6 +1195,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
             }
             a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
             a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+            if (a.log_cur) a.log_cur[j] = L.log_page;
         }
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 0;
@@ -1158,7 +1211,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 3;
         a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
-        if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
+        if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = IVP_NO_PAGE; }
         return 3;
     }
     L.posneg = rs_signum(L.xend - L.x0);
@@ -1179,7 +1232,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
             a.x[j] = L.x0; a.h[j] = L.h; a.facold[j] = 0.0; a.hlamb[j] = 0.0; a.flags[j] = 0;
             a.status[j] = 0;
             a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
-            if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
+            if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = IVP_NO_PAGE; }
             return 0;
         }
     } else if (a.has_first_step) {
@@ -1199,6 +1252,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     if (FULL) {
         a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
+        if (a.log_cur) a.log_cur[j] = L.log_page;
     }
     return IVP_RUNNING;
 }

@@ -111,6 +111,8 @@ struct OutMap<GroupRhs<R, G>, void> {
         enum { NT = R::N };
         static __device__ __forceinline__ int gi(int c) { return GroupRhs<R, G>::gl() + G * c; }
         static __device__ __forceinline__ bool own(int c) { return gi(c) < NT; }
+        static __device__ __forceinline__ bool leader() { return GroupRhs<R, G>::gl() == 0; }
+        static __device__ __forceinline__ uint32_t bcast(uint32_t v) { return (uint32_t)__shfl((int)v, (int)(threadIdx.x & ~(uint32_t)(G - 1))); }
     };
 };
 

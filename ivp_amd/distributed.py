@@ -207,10 +207,13 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
             dev_in = (torch.as_tensor(sh_t0, device=dev) if sh_t0.size > 1 else float(sh_t0[0]),
                       torch.as_tensor(sh_t1, device=dev) if sh_t1.size > 1 else float(sh_t1[0]),
                       torch.as_tensor(sh_y0, device=dev), None if sh_p is None else torch.as_tensor(sh_p, device=dev))
-            # with log=True this is the COUNTING pass of the CSR log (n_log, end states and statistics are final after it)
-            opts1 = options if not log else api.Options(**{**{k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log")},
-                                                           "count_log": True})
-            r = api.solve_ivp_batch(f, *dev_in, opts1, out=arena.solution() if in_place else None)
+            if log:
+                # ONE integration: end states and statistics into the arena, every accepted step into the context's page pool
+                # and from there into this shard's CSR run (api.solve_ivp_batch_logged -> ivp_batch_solve_logged_device)
+                r = api.solve_ivp_batch_logged(f, *dev_in, options, out=arena.solution() if in_place else None)
+                local_log = {"t_log": r.t_log.to(tdev), "y_log": r.y_log.to(tdev)}
+            else:
+                r = api.solve_ivp_batch(f, *dev_in, options, out=arena.solution() if in_place else None)
             if not in_place:
                 arena.store({k: getattr(r, k, None) for k, *_ in arena.fields}, m)
         else:
@@ -219,7 +222,7 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
     if not gather or world == 1:
         out = {k: v[..., :m] for k, v in arena.views.items()}
         if log:
-            out.update(_local_csr_log(f, dev_in, options, solve_fn, locals().get("shard_res"), out["n_log"], n, tdev))
+            out.update(_local_csr_log(solve_fn, locals().get("shard_res"), locals().get("local_log"), n, tdev))
         if world == 1:
             out = _unpermute_solution(out, perm, B)
             return _as_numpy(out) if as_numpy else out
@@ -241,7 +244,7 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
         bounds = np.cumsum([0] + counts)
         totals = [int(nl[bounds[r_]:bounds[r_ + 1]].sum().item()) for r_ in range(world)]
         cap = max(max(totals), 1)
-        mine = _local_csr_log(f, dev_in, options, solve_fn, locals().get("shard_res"), arena.views["n_log"][:m], n, tdev) if m > 0 else None
+        mine = _local_csr_log(solve_fn, locals().get("shard_res"), locals().get("local_log"), n, tdev) if m > 0 else None
         rec = torch.zeros(cap * (n + 1), dtype=torch.float64, device=tdev)     # [t_log | y_log], padded to the largest shard
         if mine is not None:
             tot = int(mine["t_log"].shape[0])
@@ -261,30 +264,14 @@ def solve_ivp_sharded(f: api.IVP, t0, t1, y0: np.ndarray, params: Optional[np.nd
     return _as_numpy(out) if as_numpy else out
 
 
-def _local_csr_log(f, dev_in, options, solve_fn, shard_res, n_log, n, tdev) -> dict:
-    """This rank's records in its own (shard) order: the FILL pass of the CSR log on the HIP path (offsets from the
-    counting pass), or the arrays the injected integrator returned."""
+def _local_csr_log(solve_fn, shard_res, local_log, n, tdev) -> dict:
+    """This rank's records in its own (shard) order: what the one-pass logged solve of the HIP path returned, or the arrays
+    the injected integrator returned."""
     import torch
     if solve_fn is not None:
         return {"t_log": torch.as_tensor(np.ascontiguousarray(shard_res["t_log"], dtype=np.float64)).to(tdev),
                 "y_log": torch.as_tensor(np.ascontiguousarray(shard_res["y_log"], dtype=np.float64)).reshape(-1, n).to(tdev)}
-    t0d, t1d, y0d, pd = dev_in
-    m = int(y0d.shape[1])
-    dev = y0d.device
-    offsets = torch.zeros(m + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(n_log.to(device=dev, dtype=torch.int64), 0, out=offsets[1:])
-    total = int(offsets[-1].item())
-    base = {k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log", "profile")}
-    i64, i32 = torch.int64, torch.int32
-    out = api.BatchSolution(y_end=torch.zeros((n, m), dtype=torch.float64, device=dev), t_end=torch.zeros(m, dtype=torch.float64, device=dev),
-                            status=torch.zeros(m, dtype=i32, device=dev), nfev=torch.zeros(m, dtype=i64, device=dev),
-                            nstep=torch.zeros(m, dtype=i64, device=dev), naccpt=torch.zeros(m, dtype=i64, device=dev),
-                            nrejct=torch.zeros(m, dtype=i64, device=dev), h_next=torch.zeros(m, dtype=torch.float64, device=dev),
-                            n_log=torch.zeros(m, dtype=i32, device=dev),
-                            t_log=torch.empty(max(total, 1), dtype=torch.float64, device=dev),
-                            y_log=torch.empty((max(total, 1), n), dtype=torch.float64, device=dev), log_offsets=offsets)
-    api.solve_ivp_batch(f, t0d, t1d, y0d, pd, api.Options(**base), out=out)
-    return {"t_log": out.t_log[:total].to(tdev), "y_log": out.y_log[:total].to(tdev)}
+    return local_log
 
 
 def _unpermute_solution(out: dict, perm, B: int) -> dict:
@@ -358,7 +345,7 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
     world = len(devices)
     keep: list = []
     base_opts = {k: v for k, v in options.__dict__.items() if k not in ("max_log", "count_log")}
-    copt = (api.Options(**base_opts, count_log=True) if log else options)._c(n, keep)
+    copt = (api.Options(**base_opts) if log else options)._c(n, keep)
     prob = api._problem_c(f)
     shards = (_lib.ShardT * world)()
     ptr = lambda a: None if a is None else C.c_void_p(a.data_ptr())
@@ -417,46 +404,40 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
         setattr(gathered, name, ptr(g[name]))
     for d in set(devices) | {gdev}:
         torch.cuda.synchronize(d)    # inputs were produced on torch streams; the shard streams may differ
-    rc = contexts[0].lib.ivp_batch_solve_multi(shards, world, C.byref(prob), B, C.byref(copt), gdev, C.byref(gathered))
-    if rc != 0:
-        raise api.ConfigError(rc, contexts[0].last_error())
-    if log:
-        # the counting pass is done (end states, statistics and n_log are final and gathered); FILL pass: every shard gets
-        # CSR buffers of exactly its own record count, offsets starting at 0, and the library re-bases them in the gather
-        total_all = int(g["n_log"].to(torch.int64).sum().item())
-        for k, d in enumerate(devices):
-            res = shard_res[k]
-            if res is None:
-                continue
-            dev = torch.device("cuda", d)
-            m = int(res["n_log"].shape[0])
-            off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(res["n_log"].to(torch.int64), 0, out=off[1:])
-            tot = int(off[-1].item())
-            res["log_offsets"] = off
-            res["t_log"] = torch.empty(max(tot, 1), dtype=torch.float64, device=dev)
-            res["y_log"] = torch.empty((max(tot, 1), n), dtype=torch.float64, device=dev)
-            for name in ("log_offsets", "t_log", "y_log"):
-                setattr(shards[k].out, name, ptr(res[name]))
-        g["log_offsets"] = torch.zeros(B + 1, dtype=torch.int64, device=home)
-        g["t_log"] = torch.empty(max(total_all, 1), dtype=torch.float64, device=home)
-        g["y_log"] = torch.empty((max(total_all, 1), n), dtype=torch.float64, device=home)
-        for name in ("log_offsets", "t_log", "y_log"):
-            setattr(gathered, name, ptr(g[name]))
-        copt = api.Options(**base_opts)._c(n, keep)
-        for d in set(devices) | {gdev}:
-            torch.cuda.synchronize(d)
+    log_info = {}
+    if not log:
         rc = contexts[0].lib.ivp_batch_solve_multi(shards, world, C.byref(prob), B, C.byref(copt), gdev, C.byref(gathered))
         if rc != 0:
             raise api.ConfigError(rc, contexts[0].last_error())
+    else:
+        # ONE integration per shard (ivp_batch_solve_logged_multi): every shard records into its own context's page pool; the
+        # call returns the batch-wide offsets and the total, the records are then fetched into buffers of exactly that size --
+        # each shard's chains become one contiguous run of the batch-wide CSR log on the gather device
+        g["log_offsets"] = torch.zeros(B + 1, dtype=torch.int64, device=home)
+        sl = _lib.StepLogT()
+        sl.offsets = ptr(g["log_offsets"])
+        sl.defer = 1
+        rc = contexts[0].lib.ivp_batch_solve_logged_multi(shards, world, C.byref(prob), B, C.byref(copt), gdev, C.byref(gathered), C.byref(sl))
+        if rc != 0:
+            raise api.ConfigError(rc, contexts[0].last_error())
+        total_all = int(sl.total)
+        g["t_log"] = torch.empty(max(total_all, 1), dtype=torch.float64, device=home)
+        g["y_log"] = torch.empty((max(total_all, 1), n), dtype=torch.float64, device=home)
+        sl.t, sl.y, sl.capacity, sl.defer = ptr(g["t_log"]), ptr(g["y_log"]), max(total_all, 1), 0
+        torch.cuda.synchronize(gdev)
+        rc = contexts[0].lib.ivp_step_log_fetch_multi(shards, world, C.byref(prob), B, C.byref(copt), gdev, C.byref(sl))
+        if rc != 0:
+            raise api.ConfigError(rc, contexts[0].last_error())
         g["t_log"], g["y_log"] = g["t_log"][:total_all], g["y_log"][:total_all]
+        log_info = {"passes": int(sl.passes), "records": total_all, "page_records": 1 << int(sl.page_shift), "pool_pages": int(sl.pool_pages),
+                    "pages_used": int(sl.pages_used)}
     if perm_t is not None:
         g = _unpermute_solution(g, permutation, B)
     return api.BatchSolution(y_end=g["y_end"], t_end=g["t_end"], status=g["status"], nfev=g["nfev"], nstep=g["nstep"],
                              naccpt=g["naccpt"], nrejct=g["nrejct"], h_next=g["h_next"], y_eval=g.get("y_eval"),
                              eval_idx=g.get("eval_idx"), n_filled=g.get("n_filled"), n_log=g.get("n_log"),
                              log_offsets=g.get("log_offsets"), t_log=g.get("t_log"), y_log=g.get("y_log"),
-                             eval_offsets=None if rec_off is None else torch.as_tensor(rec_off, device=home))
+                             eval_offsets=None if rec_off is None else torch.as_tensor(rec_off, device=home), log_info=log_info)
 
 
 class OverlappedGather:

@@ -68,6 +68,33 @@ int main(void)
         ivp_ctx_destroy(ctx2);
         printf("multi-context solve ok\n");
     }
+    /* Solution.t / Solution.y of the four calls in ONE call: every accepted step, CSR, t / y allocated by the library
+     * like the Vecs the reference returns (src/solve/solve_ivp.rs:288-312), released with ivp_step_log_free */
+    {
+        uint64_t offsets[B + 1];
+        uint32_t n_log[B];
+        ivp_step_log_t log;
+        memset(&log, 0, sizeof log);
+        log.offsets = offsets;
+        out.n_log = n_log;
+        rc = ivp_batch_solve_logged(ctx, &prob, B, y0, k, &t0, 1, t1, B, &opt, &out, &log);
+        if (rc != IVP_OK) { printf("logged solve failed: %d %s\n", rc, ivp_last_error_string(ctx)); return 17; }
+        if (!log.owned || !log.t || !log.y || log.total != offsets[B] || offsets[0] != 0) return 18;
+        for (int b = 0; b < B; ++b) {
+            const uint64_t lo = offsets[b], hi = offsets[b + 1];
+            /* the log starts at (t0, y0) and ends at the end state; trajectory 3 has a zero-length interval: one record */
+            if (hi - lo != n_log[b] || hi <= lo || log.t[lo] != t0 || log.y[lo] != y0[b] || log.t[hi - 1] != t_end[b] || log.y[hi - 1] != y_end[b]) {
+                printf("trajectory %d: bad step log [%llu, %llu)\n", b, (unsigned long long)lo, (unsigned long long)hi);
+                return 19;
+            }
+            if (b < 3 && hi - lo != naccpt[b] + 1) return 20;
+        }
+        if (offsets[4] - offsets[3] != 1) return 21;
+        ivp_step_log_free(&log);
+        if (log.owned || log.t || log.y) return 22;
+        out.n_log = NULL;
+        printf("logged solve ok: %llu records\n", (unsigned long long)log.total);
+    }
     opt.method = IVP_RADAU;
     if (ivp_batch_solve(ctx, &prob, B, y0, k, &t0, 1, t1, B, &opt, &out) != IVP_ERR_UNSUPPORTED_METHOD) return 12;
     ivp_ctx_destroy(ctx);

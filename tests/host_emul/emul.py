@@ -41,6 +41,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("spec_cap", C.c_uint32), ("spec_min", C.c_uint32), ("ran_out", VP), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
         ("count_next", VP),
         ("window", C.c_uint32),
+        ("log_pool", VP), ("log_page_shift", C.c_uint32), ("log_pool_pages", C.c_uint32), ("log_pool_next", VP), ("log_cur", VP),
     ]
 
 
@@ -74,7 +75,10 @@ def lib(fast=False):
 
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
                 first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False,
-                event_direction=None, event_terminal=None, max_events=16, settings=None):
+                event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None):
+    """``paged_log=(page_shift, pool_pages)``: the one-pass step log -- records go to page chains in a pool
+    (ivp_kargs.h); ``res['log_pool']``, ``res['log_cur']``, ``res['log_pages_used']`` and ``res['log_overflow']`` come
+    back next to ``n_log`` (``gather_pages`` below lays them out as the CSR log)."""
     L = lib(fast)
     rid = RHS[rhs]
     n, npar = RHS_DIMS[rid]
@@ -123,7 +127,7 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     a.chunk = chunk
     a.n_eval = -1
     ne_ev = RHS_NE.get(rid, 0)
-    full = t_eval is not None or max_log > 0 or ne_ev > 0
+    full = t_eval is not None or max_log > 0 or ne_ev > 0 or paged_log is not None
     keep = []
     if full:
         res["n_filled"] = np.zeros(B, dtype=np.int32)
@@ -139,6 +143,15 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
             res["y_eval"] = np.full((max(ne, 1), n, B), np.nan)
             res["eval_idx"] = np.full((max(ne, 1), B), -1, dtype=np.int32)
             a.y_eval, a.eval_idx = p(res["y_eval"]), p(res["eval_idx"])
+        elif paged_log is not None:
+            shift, pool_pages = paged_log
+            page_doubles = 1 + ((n + 1) << shift)
+            res["log_pool"] = np.full((pool_pages + 2) * page_doubles, np.nan)   # two guard pages the bodies are not told about
+            res["log_cur"] = np.full(B, 0xFFFFFFFF, dtype=np.uint32)
+            res["log_next"] = np.zeros(1, dtype=np.uint32)
+            a.log_pool, a.log_page_shift, a.log_pool_pages = p(res["log_pool"]), shift, pool_pages
+            a.log_pool_next, a.log_cur = p(res["log_next"]), p(res["log_cur"])
+            a.t_log = a.y_log = p(res["log_pool"])   # the "mode 2" marker, like the library sets it
         elif max_log > 0:
             res["t_log"] = np.full((max_log, B), np.nan)
             res["y_log"] = np.full((max_log, n, B), np.nan)
@@ -168,4 +181,33 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
         raise ValueError("IVP_ERR_INVALID_STEP_SIZE")
     assert rc == 0
     res["chunks"] = chunks.value
+    if paged_log is not None:
+        res["log_pages_used"] = int(res["log_next"][0])
+        res["log_overflow"] = res["log_pages_used"] > paged_log[1]
     return res
+
+
+def gather_pages(res, n, shift):
+    """What log_gather.hip does, in numpy: walk every trajectory's page chain from its last page back to the first and lay
+    the records out as the CSR log.  Returns (offsets [B+1], t [total], y [total, n])."""
+    cnt = res["n_log"].astype(np.int64)
+    off = np.zeros(cnt.size + 1, dtype=np.int64)
+    off[1:] = np.cumsum(cnt)
+    R = 1 << shift
+    pd = 1 + ((n + 1) << shift)
+    pool = res["log_pool"]
+    t = np.full(int(off[-1]), np.nan)
+    y = np.full((int(off[-1]), n), np.nan)
+    for j in range(cnt.size):
+        pages = (int(cnt[j]) + R - 1) >> shift
+        page = int(res["log_cur"][j])
+        for pi in range(pages - 1, -1, -1):
+            assert page != 0xFFFFFFFF
+            base = page * pd
+            recs = int(cnt[j]) - pi * R if pi == pages - 1 else R
+            q0 = int(off[j]) + pi * R
+            t[q0:q0 + recs] = pool[base + 1:base + 1 + recs]
+            y[q0:q0 + recs] = pool[base + 1 + R:base + 1 + R + recs * n].reshape(recs, n)
+            page = int(pool[base:base + 1].view(np.uint32)[0])
+        assert pages == 0 or page == 0xFFFFFFFF, "the chain must end at the first page"
+    return off, t, y

@@ -24,7 +24,7 @@ def test_c_client_compiles_links_and_runs_without_a_gpu(tmp_path):
     exe = _build(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
-    assert "abi v4 ok" in r.stdout or "device solve ok" in r.stdout
+    assert "abi v5 ok" in r.stdout or "device solve ok" in r.stdout
 
 
 @pytest.mark.gpu
@@ -34,3 +34,4 @@ def test_c_client_solves_on_the_gpu(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "device solve ok" in r.stdout
     assert "multi-context solve ok" in r.stdout   # ivp_batch_solve_multi_host: two contexts, bit-identical to one
+    assert "logged solve ok" in r.stdout          # ivp_batch_solve_logged: Solution.t / Solution.y in one call, library-owned Vecs

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ivp_abi_version() == 4
+    assert lib.ivp_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header(lib):
