@@ -350,8 +350,8 @@ int ivp_batch_wait(ivp_ctx_t *ctx);
  *             (hipMalloc on the context's / gather device, malloc for the host form), sets owned = 1, and the caller
  *             releases them with ivp_step_log_free() -- the C rendering of a Vec the callee returns
  *   reserve   in, optional: expected total number of records; sizes the page pool.  0 = automatic (the previous logged
- *             solve of this batch size on the context, else 512 records per trajectory, never more than half of the free
- *             device memory).  A pool that runs dry is not an error: the solve is repeated as the counted fill pass
+ *             solve of this batch size on the context, else 1024 records per trajectory and at least 256 MB, never more
+ *             than half of the free device memory).  A pool that runs dry is not an error: the solve is repeated as the counted fill pass
  *             (passes = 2), so a log is never truncated
  *   defer     in: 1 = integrate and count only (total, offsets and `out` are final on return); the records stay in the
  *             context's pool until its next solve and are fetched with ivp_step_log_fetch_device() into buffers the

@@ -859,8 +859,11 @@ def solve_ivp_batch(f: IVP, t0, t1, y0, params=None, options: Options = None, ct
             total = int(out.t_log.shape[0])
             want["t_log"], want["y_log"] = ((total,), f64), ((total, n), f64)
             want["log_offsets"] = ((B + 1,), u64)
-        if options.t_eval_per_trajectory is not None:   # CSR sample records: checked where they are bound below
-            want.pop("y_eval"); want.pop("eval_idx")
+        if options.t_eval_per_trajectory is not None:
+            # CSR sample records (time-major, one run per trajectory): y_eval [total, n], eval_idx [total] -- the same shape /
+            # dtype / placement / contiguity checks as every other member (they reach the kernels as raw pointers too)
+            tot_ = int(sum(len(g_) for g_ in options.t_eval_per_trajectory)) + (B if nev_ else 0)
+            want["y_eval"], want["eval_idx"] = ((max(tot_, 1), n), f64), ((max(tot_, 1),), i32)
         for name, (shape, dt) in want.items():
             v = getattr(out, name)
             if v is None:
@@ -973,7 +976,7 @@ def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = N
     and returns them (src/solve/solve_ivp.rs:288-312).  Here the stepping kernels append the records to per-trajectory
     chains of pages drawn from a device pool; once every count is known a gather kernel lays them out in trajectory order.
     ``reserve``: expected total number of records (sizes the pool; default: what the context learnt from its last logged
-    solve of this batch size, else 512 per trajectory).  A pool that runs dry costs a second integration, never records.
+    solve of this batch size, else 1024 per trajectory and at least 256 MB).  A pool that runs dry costs a second integration, never records.
     ``out``: a previous result of this function whose buffers are reused when they are large enough (one library call, no
     allocation).  ``two_pass=True`` runs the older counted form (counting solve + scan + filling solve) instead.
 
@@ -1040,6 +1043,7 @@ def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = N
         sl.t, sl.y, sl.capacity, sl.defer = C.c_void_p(bufs[0].data_ptr()), C.c_void_p(bufs[1].data_ptr()), max(total, 1), 0
         rc = ctx.lib.ivp_step_log_fetch_device(ctx.handle, C.byref(sl), stream)
         if rc != 0:   # the pool had run dry: integrate again -- its size now follows the counted total
+            sl.reserve = total
             res = solve_ivp_batch(f, t0d, t1d, y0d, pd, opts1, ctx, o1, _steplog=sl)
             sl.passes += 1
     res.log_offsets = offsets

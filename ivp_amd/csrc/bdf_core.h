@@ -391,7 +391,7 @@ struct BdfLane {
     bool over;
 };
 
-template <class R, bool FULL>
+template <class R, int FULL>
 IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
 {
     constexpr int N = R::N, P = R::P;
@@ -496,7 +496,7 @@ IVP_HD int32_t bdf_init_body(const IvpKArgs &a, uint32_t j)
 }
 
 // One pass of the main loop (bdf.rs:276-607). Returns false when the trajectory retired.
-template <class R, bool FULL>
+template <class R, int FULL>
 IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R::N, R::P> &L)
 {
     KC_SCOPE_KZ(L.kz)
@@ -780,7 +780,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
     return true;
 }
 
-template <class R, bool FULL>
+template <class R, int FULL>
 IVP_HD uint32_t bdf_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     constexpr int N = R::N, P = R::P;
@@ -870,13 +870,13 @@ IVP_HD uint32_t bdf_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_ou
 }
 
 // method dispatch used by the kernels (rk_global.h) and the CPU emulation harness
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 IVP_HD int32_t any_init_body(const IvpKArgs &a, uint32_t j)
 {
     if constexpr (M == M_BDF) return bdf_init_body<R, FULL>(a, j);
     else return init_body<M, R, FULL>(a, j);
 }
-template <int M, class R, bool FULL, bool CTL = false>
+template <int M, class R, int FULL, bool CTL = false>
 IVP_HD uint32_t any_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     if constexpr (M == M_BDF) return bdf_chunk_body<R, FULL>(a, j, status_out);

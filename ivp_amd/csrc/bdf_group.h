@@ -360,7 +360,7 @@ __device__ __forceinline__ double bdfg_rtol_min(const IvpKArgs &a)
     return fmax(r, 2.220446049250313e-16);
 }
 
-template <class R, bool FULL, int G>
+template <class R, int FULL, int G>
 __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32_t j)
 {
     using BG = BdfG<R, G>;
@@ -476,7 +476,7 @@ struct BdfGLane {
 };
 
 // One pass of the main loop (bdf.rs:276-607). Returns false when the trajectory retired.
-template <class R, bool FULL, int G>
+template <class R, int FULL, int G>
 __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j, BdfGLane<BdfG<R, G>::C> &S, Lane<BdfG<R, G>::C, R::P> &L,
                                                   double *jac, double *lu, uint32_t *piv)
 {
@@ -752,7 +752,7 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
 
 // largest n whose factors the LDSLU kernels keep in LDS (128 x 128 doubles = 128 KiB of the CU's 160)
 #define IVP_LDS_LU_MAX_N 128
-template <class R, bool FULL, int G, bool LDSLU>
+template <class R, int FULL, int G, bool LDSLU>
 __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     using BG = BdfG<R, G>;

@@ -128,7 +128,9 @@ int ivp_host::validate(ivp_ctx *ctx, const ivp_problem_t *prob, size_t B, const 
     if (opt->rtol_vec && opt->rtol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "rtol: expected %d, got %d", n, opt->rtol_vec_len);
     if (opt->atol_vec && opt->atol_vec_len != n) return fail(ctx, IVP_ERR_TOLERANCE_SIZE_MISMATCH, "atol: expected %d, got %d", n, opt->atol_vec_len);
     if (opt->t_eval && opt->n_eval < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative n_eval");
-    if (opt->t_eval && opt->n_eval > 0x7FFFFFFFll) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "n_eval too large");
+    // one shared grid: its length is a 32-bit kernel argument; per-trajectory grids: the concatenation may be longer, each
+    // trajectory's own grid may not (checked with the offsets)
+    if (opt->t_eval && !opt->t_eval_offsets && opt->n_eval > 0x7FFFFFFFll) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "n_eval too large");
     if (opt->fp_mode != IVP_FP_STRICT && opt->fp_mode != IVP_FP_FAST) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown fp_mode");
     if (opt->chunk_attempts < 0) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "negative chunk_attempts");
     if (opt->variant < 0 || opt->variant > 3) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "unknown kernel variant %d", opt->variant);
@@ -712,7 +714,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     }
     if (full) {
         if (want_eval) {
-            a.n_eval = (int32_t)opt->n_eval;
+            a.n_eval = (int32_t)std::min<int64_t>(opt->n_eval, 0x7FFFFFFF);   // per-trajectory grids: only its sign is read (lengths come from the offsets)
             HIP_TRY(ctx, ctx->teval.reserve(sizeof(double) * std::max<int64_t>(opt->n_eval, 1)));
             if (opt->n_eval > 0)
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->teval.p, opt->t_eval, sizeof(double) * opt->n_eval, hipMemcpyHostToDevice, s));
@@ -737,14 +739,18 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         if (paged) {
             // One-pass step log (ivp_kargs.h): pages of R records, R chosen so that a page is ~2 KB (two contiguous copies per
             // page in the gather, half a page wasted per trajectory), drawn from a pool sized from the caller's estimate, the
-            // last logged solve of this batch size on this context, or 512 records per trajectory -- a pool that turns out too
+            // last logged solve of this batch size on this context, or 1024 records per trajectory (at least 256 MB) -- a pool that turns out too
             // small costs a second integration (the counted fill pass), never a wrong or truncated log.
             uint32_t shift = 0;
             while (shift < 6 && ((size_t)(n + 1) << (shift + 1)) * 8 <= 2048) ++shift;
             const size_t R = (size_t)1 << shift, page_bytes = (1 + (size_t)(n + 1) * R) * 8;
             ivp_ctx::LogState &LS = ctx->log_state;
-            uint64_t recs = log_reserve ? log_reserve : (LS.total && LS.last_B == B ? LS.total + LS.total / 8 : (uint64_t)B * 512u);
+            const bool learnt = LS.total && LS.last_B == B;
+            uint64_t recs = log_reserve ? log_reserve : (learnt ? LS.total + LS.total / 8 : (uint64_t)B * 1024u);
             uint64_t pages = recs / R + B + 64;
+            // nothing known about the problem yet: a small batch of long trajectories (stiff problems, chaotic ones) should not
+            // run dry either -- 256 MB of pages cost nothing on a 288 GB part (the pool is reserved once per context, grow-only)
+            if (!log_reserve && !learnt) pages = std::max<uint64_t>(pages, ((uint64_t)256 << 20) / page_bytes);
             if (pages * page_bytes > ctx->log_pool.cap) {   // growing: never ask for more than half of what the device can give
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -805,7 +811,11 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.fp_mode = opt->fp_mode;
     P.profile = opt->profile;
     P.n = n;
-    P.full = full;
+    // the log-only flavour: every accepted step recorded and nothing else asked of DefaultSolOut (no t_eval, no first_step
+    // enforcement, no dense-output segments, no event functions) -- then no interpolant is ever evaluated, the kernels skip
+    // the dense-output coefficients and keep the registers (occupancy) of the end-state kernels
+    const bool log_only = want_log && !want_eval && !want_dense && n_events == 0 && !opt->has_first_step;
+    P.full = log_only ? 2 : (full ? 1 : 0);
     P.group = group;
     P.jit = prob->rhs_id == IVP_RHS_JIT;
     P.has_settings = opt->has_settings != 0;
@@ -1148,6 +1158,15 @@ int ivp_batch_solve_multi_host(ivp_ctx_t *const *ctxs, int32_t n_ctx, const ivp_
     auto log_rec_bytes = [&](const MemberDesc &d) -> size_t { return d.off == offsetof(ivp_batch_result_t, y_log) ? 8u * (size_t)n : 8u; };
     std::vector<unsigned long long> log_local;
     const bool grids = opt->t_eval_offsets && opt->t_eval;
+    if (opt->t_eval_offsets && !opt->t_eval) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets without t_eval");
+    if (grids) {   // checked HERE, before any staging size is derived from them (a malformed array must not underflow a size_t)
+        if (opt->t_eval_offsets[0] != 0 || opt->t_eval_offsets[B] != (uint64_t)opt->n_eval)
+            return fail(c0, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets must run from 0 to n_eval");
+        for (size_t b = 0; b < B; ++b) {
+            if (opt->t_eval_offsets[b + 1] < opt->t_eval_offsets[b]) return fail(c0, IVP_ERR_BAD_ARGUMENT, "t_eval_offsets must be non-decreasing");
+            if (opt->t_eval_offsets[b + 1] - opt->t_eval_offsets[b] > 0x7FFFFFFFull) return fail(c0, IVP_ERR_BAD_ARGUMENT, "a trajectory's t_eval grid is too long");
+        }
+    }
     const bool grid_events = grids && result_shape(prob, opt, n).nev > 0;
     auto is_eval_member = [&](const MemberDesc &d) { return grids && (d.off == offsetof(ivp_batch_result_t, y_eval) || d.off == offsetof(ivp_batch_result_t, eval_idx)); };
     auto eval_rec_bytes = [&](const MemberDesc &d) -> size_t { return d.off == offsetof(ivp_batch_result_t, y_eval) ? 8u * (size_t)n : 4u; };

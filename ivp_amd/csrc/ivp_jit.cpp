@@ -39,7 +39,7 @@ struct JitRhs {
     std::mutex mu;
     // (device, method, fp_mode, full, ctl): hipModuleLoadData binds a module to the device that is current when it is
     // loaded, so a handle shared by contexts on several GPUs keeps one module per device
-    std::map<std::tuple<int, int, int, bool, bool, bool>, JitModule> modules;   // ... , lane-cooperative module
+    std::map<std::tuple<int, int, int, int, bool, bool>, JitModule> modules;   // ... , lane-cooperative module
     std::string log;
 };
 
@@ -50,8 +50,11 @@ std::string join(const char *const *parts)
     return s;
 }
 
-std::string build_source(const JitRhs &r, int method, bool full, bool ctl, bool coop_only)
+std::string build_source(const JitRhs &r, int method, int full_in, bool ctl, bool coop_only)
 {
+    // kernel flavour (rk_launch.h): 2 = log-only exists for the adaptive explicit methods of problems without event functions
+    const int flavour = (full_in == 2 && r.ne == 0 && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? 2 : (full_in ? 1 : 0);
+    const char *full = flavour == 2 ? "2" : (flavour ? "1" : "0");
     std::string s;
     s += "typedef unsigned int uint32_t;\ntypedef int int32_t;\ntypedef unsigned long long uint64_t;\ntypedef long long int64_t;\n";
     s += "#define IVP_HD __device__ __forceinline__\n";
@@ -83,7 +86,7 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl, bool 
                       "}; }\n"
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_init(const IvpKArgs a) { ivp_jit::group_init_body<%d, ivp_jit::RhsUser, %s, %d>(a); }\n"
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_chunk(const IvpKArgs a) { ivp_jit::group_chunk_body<%d, ivp_jit::RhsUser, %s, %d>(a); }\n",
-                      r.n, r.np, method, full ? "true" : "false", ivp_group_width(r.n), method, full ? "true" : "false", ivp_group_width(r.n));
+                      r.n, r.np, method, full, ivp_group_width(r.n), method, full, ivp_group_width(r.n));
         s += buf;
         return s;
     }
@@ -104,7 +107,7 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl, bool 
         s += join(k_src_rk_coop_h);
         std::snprintf(buf, sizeof buf,
                       "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_coop(const IvpKArgs a)\n"
-                      "{ ivp_jit::coop_chunk_body<%d, ivp_jit::RhsUser, %s>(a); }\n", method, full ? "true" : "false");
+                      "{ ivp_jit::coop_chunk_body<%d, ivp_jit::RhsUser, %s>(a); }\n", method, full);
         s += buf;
         return s;
     }
@@ -113,7 +116,7 @@ std::string build_source(const JitRhs &r, int method, bool full, bool ctl, bool 
                   "{ const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x; if (i < a.B) ivp_jit::any_init_body<%d, ivp_jit::RhsUser, %s>(a, i); }\n"
                   "extern \"C\" __global__ __launch_bounds__(IVP_WAVE, IVP_MIN_WAVES) void ivp_jit_chunk(const IvpKArgs a)\n"
                   "{ ivp_jit::chunk_kernel_body<%d, ivp_jit::RhsUser, %s, %s>(a); }\n",
-                  method, full ? "true" : "false", method, full ? "true" : "false",
+                  method, full, method, full,
                   (ctl && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? "true" : "false");
     s += buf;
     return s;
@@ -152,7 +155,7 @@ int load_module(JitRhs &r, const std::vector<char> &code, JitModule *out, bool c
     return IVP_OK;
 }
 
-int compile_module(JitRhs &r, int method, int fp_mode, bool full, bool ctl, JitModule *out, bool coop_only = false)
+int compile_module(JitRhs &r, int method, int fp_mode, int full, bool ctl, JitModule *out, bool coop_only = false)
 {
     const std::string src = build_source(r, method, full, ctl, coop_only);
     const std::string opt_key = r.arch + (fp_mode == IVP_FP_FAST ? "|fast" : "|strict");
@@ -256,7 +259,7 @@ void ivp_jit_dims(void *handle, int *n, int *np)
     *np = r->np;
 }
 
-hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool full, const IvpKArgs &a, uint32_t lanes,
+hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, int full, const IvpKArgs &a, uint32_t lanes,
                           hipStream_t s)
 {
     JitRhs *r = (JitRhs *)handle;

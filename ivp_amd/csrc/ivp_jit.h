@@ -9,5 +9,5 @@ int ivp_jit_n_events(void *handle);
 void ivp_jit_free(void *handle);
 void ivp_jit_dims(void *handle, int *n, int *n_params);
 const char *ivp_jit_last_log(void *handle);   // hiprtc build log / load error of the most recent failure
-hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, bool full, const IvpKArgs &a,
+hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, int full, const IvpKArgs &a,
                           uint32_t lanes, hipStream_t s);

@@ -42,7 +42,7 @@ namespace {
 
 using namespace IVP_NS;
 
-template <class R, bool FULL>
+template <class R, int FULL>
 hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {
     const uint32_t per_wave = (what == IVP_LAUNCH_CHUNK && a.lpw) ? a.lpw : (uint32_t)IVP_WAVE;   // thin waves (ivp_kargs.h)
@@ -56,14 +56,14 @@ hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s
 }
 
 template <class R>
-hipError_t launch_rhs(int what, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+hipError_t launch_rhs(int what, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {
     return full ? launch_one<R, true>(what, a, lanes, s) : launch_one<R, false>(what, a, lanes, s);
 }
 
 }  // namespace
 
-hipError_t IVP_LAUNCH_NAME(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+hipError_t IVP_LAUNCH_NAME(int what, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {
     switch (rhs_id) {
     case 0: return launch_rhs<IVP_NS::RhsDecay>(what, full, a, lanes, s);

@@ -234,7 +234,7 @@ struct NormOps<CoopRhs<R>, void> {
 };
 
 // up to a.chunk step attempts for the 8 trajectories of this wave; controller fields from IvpKArgs (CTL = true)
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 __device__ __forceinline__ void coop_chunk_body(const IvpKArgs &a)
 {
     const uint32_t lane = threadIdx.x, c = lane & 7u;
@@ -270,8 +270,8 @@ __device__ __forceinline__ void coop_chunk_body(const IvpKArgs &a)
 // The FULL kernels (device DefaultSolOut on top of the integrator) may use the whole register file -- at most one wave per
 // SIMD -- instead of leaving a spill area in scratch; the end-state kernels keep the compiler's choice (DOPRI5 / CR3BP: 206
 // VGPRs, two waves per SIMD, which is what the 1588 waves arriving at C2's hand-over need).
-template <int M, class R, bool FULL>
-__global__ __launch_bounds__(IVP_WAVE) __attribute__((amdgpu_waves_per_eu(1, FULL ? 1 : 8)))
+template <int M, class R, int FULL>
+__global__ __launch_bounds__(IVP_WAVE) __attribute__((amdgpu_waves_per_eu(1, FULL == 1 ? 1 : 8)))
 void coop_chunk_kernel(const IvpKArgs a) { coop_chunk_body<M, R, FULL>(a); }
 
 }  // namespace IVP_NS

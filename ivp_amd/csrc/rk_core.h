@@ -1083,6 +1083,18 @@ IVP_HD bool solout_full(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, doub
     return false;
 }
 
+// FULL == 2, the LOG-ONLY flavour of the kernels: the reference's default output contract and nothing else -- no t_eval, no
+// first_step, no dense-output collection, no event functions (the host checks all four before it picks this flavour).
+// DefaultSolOut then reduces to "record (x, y) of every accepted step unless it repeats the last record" (solout.rs:422-427),
+// which needs no interpolant: the stepping kernels skip the dense-output coefficients altogether and keep the register
+// budget (and the occupancy) of the end-state kernels.
+template <class R>
+IVP_HD void so_log_accepted(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double x, const double *y)
+{
+    using MAP = typename OutMap<R>::type;
+    if (L.n_log == 0 || fabs(L.t_last - x) > 1e-12) so_push_log<0, R::N, R::P, MAP>(a, j, L, x, y);
+}
+
 // does the accepted step [xold, xph] need dense coefficients? (lazy DOP853 dense stages)
 template <int N, int P>
 IVP_HD bool so_needs_dense(const IvpKArgs &a, uint32_t j, const Lane<N, P> &L, double xold, double xph)
@@ -1153,7 +1165,7 @@ IVP_HD double hinit(const IvpKArgs &a, double x, const double *y, double posneg,
 //   (solve_ivp.rs:110-145 zero-interval short-circuit; dopri5.rs:201-263 / dop853.rs:196-269 /
 //    rk23.rs:138-186: f0, hinit or first_step, initial SolOut call)
 // ------------------------------------------------------------------------------------------------
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
 {
     constexpr int N = R::N, P = R::P;
@@ -1242,7 +1254,8 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         nfev += 2;  // f(x0, y0) and hinit's Euler probe
         L.h = hinit<R>(a, L.x, L.y, L.posneg, L.k1, L.p, M == M_DOPRI5 ? 5 : (M == M_DOP853 ? 8 : 3), L.hmax);
     }
-    if (FULL) (void)solout_full<M, R>(a, j, L, L.x, L.x, L.y, (const double *)L.y, (const double *)nullptr, 0.0, L.x);
+    if (FULL == 1) (void)solout_full<M, R>(a, j, L, L.x, L.x, L.y, (const double *)L.y, (const double *)nullptr, 0.0, L.x);
+    else if (FULL == 2) so_log_accepted<R>(a, j, L, L.x, L.y);
 
 #pragma unroll
     for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, L.k1[c]); }
@@ -1300,7 +1313,7 @@ IVP_HD bool stiff_tick(const IvpKArgs &a, uint32_t j, uint32_t &flags, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // DOPRI5 attempt (dopri5.rs:266-461).  Returns false when the trajectory retired.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool FULL, bool CTL = false>
+template <class R, int FULL, bool CTL = false>
 IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE_KZ(L.kz)
@@ -1363,8 +1376,8 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     R::ode(xph, y1, k2, p);  // k7 -> k2 (FSAL)
     L.d_nfev += 6;
 
-    double cont[FULL ? 5 * N : 1];
-    if (FULL) {
+    double cont[FULL == 1 ? 5 * N : 1];
+    if (FULL == 1) {
 { const double cD1 = KC(D1), cD3 = KC(D3), cD4 = KC(D4), cD5 = KC(D5), cD6 = KC(D6), cD7 = KC(D7);
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -1412,7 +1425,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
             IVP_STIFF_BOOKKEEPING(3.25)
             if (stiff_break) { L.h = h; L.status = 4; return false; }                  // ProbablyStiff
         }
-        if (FULL) {
+        if (FULL == 1) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const double ydiff = y1[i] - y[i];
@@ -1426,9 +1439,9 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
         for (int i = 0; i < N; ++i) { L.k1[i] = k2[i]; L.y[i] = y1[i]; }
         L.x = xph;
-        if (FULL) {   // ControlFlag::Interrupt => status = UserInterrupt, break before h = hnew (dopri5.rs:418-421)
+        if (FULL == 1) {   // ControlFlag::Interrupt => status = UserInterrupt, break before h = hnew (dopri5.rs:418-421)
             if (solout_full<M_DOPRI5, R>(a, j, L, x, xph, L.y, cont, cont, h, x)) { L.h = h; L.status = 1; return false; }
-        }
+        } else if (FULL == 2) so_log_accepted<R>(a, j, L, xph, L.y);
         if (last) { L.h = hnew; L.status = 0; return false; }                          // Success
         if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
         if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
@@ -1446,7 +1459,7 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 // ------------------------------------------------------------------------------------------------
 // DOP853 attempt (dop853.rs:272-653)
 // ------------------------------------------------------------------------------------------------
-template <class R, bool FULL, bool CTL = false>
+template <class R, int FULL, bool CTL = false>
 IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE_KZ(L.kz)
@@ -1644,9 +1657,9 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         // this step's interpolant is actually consumed, and always counts the 3 evaluations.
         L.d_nfev += 3;
         // the 8 x N dense block: staged through LDS when a lane holds more than one component (see ContStage)
-        typename ivp_cond<(FULL && N >= 2), ContStage<8 * N>, ContRegs<(FULL ? 8 * N : 1)>>::type cont;
-        const bool need_dense = FULL && (R::NE > 0 || so_needs_dense<N, P>(a, j, L, x, xph));
-        if (FULL && need_dense) {
+        typename ivp_cond<(FULL == 1 && N >= 2), ContStage<8 * N>, ContRegs<(FULL == 1 ? 8 * N : 1)>>::type cont;
+        const bool need_dense = FULL == 1 && (R::NE > 0 || so_needs_dense<N, P>(a, j, L, x, xph));
+        if (FULL == 1 && need_dense) {
 { const double cD41 = KC(D41), cD46 = KC(D46), cD47 = KC(D47), cD48 = KC(D48), cD49 = KC(D49), cD410 = KC(D410), cD411 = KC(D411), cD412 = KC(D412), cD51 = KC(D51), cD56 = KC(D56), cD57 = KC(D57), cD58 = KC(D58), cD59 = KC(D59), cD510 = KC(D510), cD511 = KC(D511), cD512 = KC(D512), cD61 = KC(D61), cD66 = KC(D66), cD67 = KC(D67), cD68 = KC(D68), cD69 = KC(D69), cD610 = KC(D610), cD611 = KC(D611), cD612 = KC(D612), cD71 = KC(D71), cD76 = KC(D76), cD77 = KC(D77), cD78 = KC(D78), cD79 = KC(D79), cD710 = KC(D710), cD711 = KC(D711), cD712 = KC(D712);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -1693,11 +1706,11 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
         for (int i = 0; i < N; ++i) { L.k1[i] = k4[i]; L.y[i] = k5[i]; }
         L.x = xph;
-        if (FULL) {
+        if (FULL == 1) {
             // `cont` is passed even when its dense rows were not computed (need_dense false): every reader is guarded
             // by exactly the conditions so_needs_dense() tests
             if (solout_full<M_DOP853, R>(a, j, L, x, xph, L.y, cont, cont, h, x)) { L.h = h; L.status = 1; return false; }
-        }
+        } else if (FULL == 2) so_log_accepted<R>(a, j, L, xph, L.y);
         if (last) { L.h = hnew; L.status = 0; return false; }
         if (fabs(hnew) > fabs(L.hmax)) hnew = L.posneg * fabs(L.hmax);
         if (L.flags & IVP_F_REJECT) { hnew = L.posneg * fmin(fabs(hnew), fabs(h)); L.flags &= ~IVP_F_REJECT; }
@@ -1715,7 +1728,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 // ------------------------------------------------------------------------------------------------
 // RK23 attempt (rk23.rs:189-307)
 // ------------------------------------------------------------------------------------------------
-template <class R, bool FULL, bool CTL = false>
+template <class R, int FULL, bool CTL = false>
 IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE_KZ(L.kz)
@@ -1770,7 +1783,7 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
         L.d_nstep += 1;
         L.d_naccpt += 1;
         const double xnew = x + h;
-        if (FULL) {
+        if (FULL == 1) {
             double cont[4 * N];
 { const double cD21 = KC(D21), cD22 = KC(D22), cD23 = KC(D23), cD24 = KC(D24), cD31 = KC(D31), cD32 = KC(D32), cD33 = KC(D33), cD34 = KC(D34);
 #pragma unroll
@@ -1789,6 +1802,7 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 #pragma unroll
             for (int i = 0; i < N; ++i) L.y[i] = yt[i];
             L.x = xnew;
+            if (FULL == 2) so_log_accepted<R>(a, j, L, xnew, L.y);
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) L.k1[i] = k4[i];
@@ -1813,7 +1827,7 @@ IVP_HD bool rk23_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 // RK4 step (rk4.rs:137-226): fixed step, no error control.  Quirks kept: steps.accepted stays 0, the last
 // step is not shortened (the final x is x0 + k*h), nfev counts 4 per step and not the initial evaluation.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool FULL>
+template <class R, int FULL>
 IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE_KZ(L.kz)
@@ -1850,7 +1864,8 @@ IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     L.x = xnew;
     L.d_nfev += 4;
     L.d_nstep += 1;
-    if (FULL) {
+    if (FULL == 2) so_log_accepted<R>(a, j, L, xnew, L.y);
+    if (FULL == 1) {
         double cont[4 * N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -1866,7 +1881,7 @@ IVP_HD bool rk4_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 }
 
 // One chunk of step attempts for one lane. Every lane leaves after at most `chunk` attempts.
-template <int M, class R, bool FULL, bool CTL = false>
+template <int M, class R, int FULL, bool CTL = false>
 IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
 {
     Lane<R::N, R::P> L;

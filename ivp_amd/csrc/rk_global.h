@@ -28,7 +28,7 @@ __device__ __forceinline__ void compact_append(const IvpKArgs &a, uint32_t j, bo
     if (still) a.perm_out[base + rank] = j;
 }
 
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 __global__ __launch_bounds__(IVP_WAVE) void init_kernel_t(const IvpKArgs a)
 {
     const uint32_t i = blockIdx.x * IVP_WAVE + threadIdx.x;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(IVP_WAVE) void init_kernel_t(const IvpKArgs a)
     if (a.perm_out) compact_append(a, i, valid && st == IVP_RUNNING);
 }
 
-template <int M, class R, bool FULL, bool CTL = false>
+template <int M, class R, int FULL, bool CTL = false>
 __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 {
     const uint32_t lpw = a.lpw ? a.lpw : (uint32_t)IVP_WAVE;   // trajectories per wave (thin waves: ivp_kargs.h)
@@ -81,8 +81,8 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 // scratch: BDF, and DOP853 with the device DefaultSolOut on systems of 5+ components (10 stage vectors + the SolOut state).
 // CTL = true: controller fields from IvpKArgs.ctl_* (a direct method call with non-default struct fields);
 // CTL = false keeps them compile-time constants, which is the path solve_ivp() takes.
-template <int M, class R, bool FULL, bool CTL = false>
-__global__ __launch_bounds__(IVP_WAVE, (M == M_BDF) ? IVP_BDF_MIN_WAVES : ((M == M_DOP853 && FULL && R::N >= 5) ? 1 : IVP_MIN_WAVES)) void chunk_kernel_t(const IvpKArgs a)
+template <int M, class R, int FULL, bool CTL = false>
+__global__ __launch_bounds__(IVP_WAVE, (M == M_BDF) ? IVP_BDF_MIN_WAVES : ((M == M_DOP853 && FULL == 1 && R::N >= 5) ? 1 : IVP_MIN_WAVES)) void chunk_kernel_t(const IvpKArgs a)
 {
     chunk_kernel_body<M, R, FULL, CTL>(a);
 }

@@ -161,13 +161,13 @@ struct NormOps<GroupRhs<R, G>, void> {
 };
 
 // BDF for large n (bdf_group.h, included after this header)
-template <class R, bool FULL, int G>
+template <class R, int FULL, int G>
 __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32_t j);
-template <class R, bool FULL, int G, bool LDSLU>
+template <class R, int FULL, int G, bool LDSLU>
 __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out);
 
 // init: one group of G lanes per trajectory, 64 / G trajectories per wavefront
-template <int M, class R, bool FULL, int G = IVP_WAVE>
+template <int M, class R, int FULL, int G = IVP_WAVE>
 __device__ __forceinline__ void group_init_body(const IvpKArgs &a)
 {
     const uint32_t j = blockIdx.x * (IVP_WAVE / G) + threadIdx.x / G;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void group_init_body(const IvpKArgs &a)
 
 // up to a.chunk step attempts for the trajectories of this wave; controller fields from IvpKArgs (CTL = true).
 // LDSLU (BDF only): the factors of (I - cJ) live in LDS for the whole launch (bdf_group.h).
-template <int M, class R, bool FULL, int G = IVP_WAVE, bool LDSLU = false>
+template <int M, class R, int FULL, int G = IVP_WAVE, bool LDSLU = false>
 __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
 {
     constexpr uint32_t NG = IVP_WAVE / G;
@@ -213,9 +213,9 @@ __device__ __forceinline__ void group_chunk_body(const IvpKArgs &a)
     }
 }
 
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 __global__ __launch_bounds__(IVP_WAVE) void group_init_kernel(const IvpKArgs a) { group_init_body<M, R, FULL>(a); }
-template <int M, class R, bool FULL, bool LDSLU = false>
+template <int M, class R, int FULL, bool LDSLU = false>
 __global__ __launch_bounds__(IVP_WAVE) void group_chunk_kernel(const IvpKArgs a) { group_chunk_body<M, R, FULL, IVP_WAVE, LDSLU>(a); }
 
 }  // namespace IVP_NS

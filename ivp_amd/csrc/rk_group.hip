@@ -26,7 +26,7 @@
 
 namespace {
 
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 hipError_t launch_group_one(int what, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     const dim3 grid(trajectories), block(IVP_WAVE);   // one wavefront per trajectory
@@ -47,7 +47,7 @@ hipError_t launch_group_one(int what, const IvpKArgs &a, uint32_t trajectories, 
 }
 
 template <class R>
-hipError_t launch_group(int what, int method, bool full, const IvpKArgs &a, uint32_t n, hipStream_t s)
+hipError_t launch_group(int what, int method, int full, const IvpKArgs &a, uint32_t n, hipStream_t s)
 {
     using namespace IVP_NS;
     switch (method) {
@@ -60,7 +60,7 @@ hipError_t launch_group(int what, int method, bool full, const IvpKArgs &a, uint
     return hipErrorInvalidValue;
 }
 
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 hipError_t launch_coop_one(const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     const dim3 grid((trajectories + 7) / 8), block(IVP_WAVE);   // eight lanes per trajectory
@@ -69,25 +69,29 @@ hipError_t launch_coop_one(const IvpKArgs &a, uint32_t trajectories, hipStream_t
     hipLaunchKernelGGL((IVP_NS::coop_chunk_kernel<M, R, FULL>), grid, block, 0, s, a);
     return hipGetLastError();
 }
-template <class R>
-hipError_t launch_coop(int method, bool full, const IvpKArgs &a, uint32_t n, hipStream_t s)
+template <int M, class R>
+hipError_t launch_coop_flavour(int full, const IvpKArgs &a, uint32_t n, hipStream_t s)
 {
-    using namespace IVP_NS;
     if constexpr (R::NE > 0) {   // a problem with event functions always runs its FULL kernels
         if (!full) return hipErrorInvalidValue;
-        if (method == M_DOPRI5) return launch_coop_one<M_DOPRI5, R, true>(a, n, s);
-        if (method == M_DOP853) return launch_coop_one<M_DOP853, R, true>(a, n, s);
-        return hipErrorInvalidValue;
+        return launch_coop_one<M, R, 1>(a, n, s);
     } else {
-        if (method == M_DOPRI5) return full ? launch_coop_one<M_DOPRI5, R, true>(a, n, s) : launch_coop_one<M_DOPRI5, R, false>(a, n, s);
-        if (method == M_DOP853) return full ? launch_coop_one<M_DOP853, R, true>(a, n, s) : launch_coop_one<M_DOP853, R, false>(a, n, s);
-        return hipErrorInvalidValue;
+        if (full == 2) return launch_coop_one<M, R, 2>(a, n, s);   // log-only flavour (rk_core.h so_log_accepted)
+        return full ? launch_coop_one<M, R, 1>(a, n, s) : launch_coop_one<M, R, 0>(a, n, s);
     }
+}
+template <class R>
+hipError_t launch_coop(int method, int full, const IvpKArgs &a, uint32_t n, hipStream_t s)
+{
+    using namespace IVP_NS;
+    if (method == M_DOPRI5) return launch_coop_flavour<M_DOPRI5, R>(full, a, n, s);
+    if (method == M_DOP853) return launch_coop_flavour<M_DOP853, R>(full, a, n, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-hipError_t IVP_COOP_LAUNCH_NAME(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+hipError_t IVP_COOP_LAUNCH_NAME(int method, int rhs_id, int full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     switch (rhs_id) {
     case 0: return launch_coop<IVP_NS::RhsDecay>(method, full, a, trajectories, s);
@@ -110,7 +114,7 @@ hipError_t IVP_COOP_LAUNCH_NAME(int method, int rhs_id, bool full, const IvpKArg
     return hipErrorInvalidValue;
 }
 
-hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
+hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s)
 {
     switch (rhs_id) {
     case 100: return launch_group<IVP_NS::RhsLinearDecay100>(what, method, full, a, trajectories, s);

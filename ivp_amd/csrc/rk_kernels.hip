@@ -41,7 +41,7 @@ namespace {
 
 using namespace IVP_NS;
 
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {
     const dim3 grid((lanes + IVP_WAVE - 1) / IVP_WAVE), block(IVP_WAVE);
@@ -66,18 +66,24 @@ hipError_t launch_one(int what, const IvpKArgs &a, uint32_t lanes, hipStream_t s
     return hipGetLastError();
 }
 
+// flavour 2 (log-only) exists for the adaptive methods of problems without event functions; everything else runs it as 1
+template <int M, class R>
+hipError_t launch_flavour(int what, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+{
+    if constexpr (R::NE == 0 && M != M_RK4) {
+        if (full == 2) return launch_one<M, R, 2>(what, a, lanes, s);
+    }
+    return full ? launch_one<M, R, 1>(what, a, lanes, s) : launch_one<M, R, 0>(what, a, lanes, s);
+}
+
 template <class R>
-hipError_t launch_rhs(int what, int method, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+hipError_t launch_rhs(int what, int method, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {
     switch (method) {
-    case M_RK23:
-        return full ? launch_one<M_RK23, R, true>(what, a, lanes, s) : launch_one<M_RK23, R, false>(what, a, lanes, s);
-    case M_DOPRI5:
-        return full ? launch_one<M_DOPRI5, R, true>(what, a, lanes, s) : launch_one<M_DOPRI5, R, false>(what, a, lanes, s);
-    case M_DOP853:
-        return full ? launch_one<M_DOP853, R, true>(what, a, lanes, s) : launch_one<M_DOP853, R, false>(what, a, lanes, s);
-    case M_RK4:
-        return full ? launch_one<M_RK4, R, true>(what, a, lanes, s) : launch_one<M_RK4, R, false>(what, a, lanes, s);
+    case M_RK23: return launch_flavour<M_RK23, R>(what, full, a, lanes, s);
+    case M_DOPRI5: return launch_flavour<M_DOPRI5, R>(what, full, a, lanes, s);
+    case M_DOP853: return launch_flavour<M_DOP853, R>(what, full, a, lanes, s);
+    case M_RK4: return launch_flavour<M_RK4, R>(what, full, a, lanes, s);
     case M_BDF:
         return hipErrorInvalidValue;   // BDF lives in rk_bdf.hip (pinned-coefficient build only)
     }
@@ -86,7 +92,7 @@ hipError_t launch_rhs(int what, int method, bool full, const IvpKArgs &a, uint32
 
 }  // namespace
 
-hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
+hipError_t IVP_LAUNCH_NAME(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s)
 {
     switch (rhs_id) {
     case 0: return launch_rhs<IVP_NS::RhsDecay>(what, method, full, a, lanes, s);

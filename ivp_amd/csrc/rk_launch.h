@@ -10,23 +10,25 @@ static inline int ivp_group_width(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 :
 enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1, IVP_LAUNCH_COOP = 2 /* hiprtc modules only */ };
 
 // `lanes` = upper bound of trajectories the launch has to cover (grid = ceil(lanes / 64) one-wave blocks).
-hipError_t ivp_launch_strict(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
-hipError_t ivp_launch_strict_hoist(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
-hipError_t ivp_launch_fast_hoist(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
-hipError_t ivp_launch_fast(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+// `full` = flavour of the kernel: 0 end state only, 1 the whole device DefaultSolOut, 2 log-only (every accepted step recorded,
+// nothing else: no interpolant -- rk_core.h so_log_accepted); tables that do not carry flavour 2 run it as flavour 1.
+hipError_t ivp_launch_strict(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_strict_hoist(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_fast_hoist(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_fast(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 
 // wave-per-trajectory kernels (rk_group.hip): grid = `trajectories` one-wave blocks; RK23 / DOPRI5 / DOP853 / RK4
-hipError_t ivp_launch_group_strict(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
-hipError_t ivp_launch_group_fast(int what, int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+hipError_t ivp_launch_group_strict(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+hipError_t ivp_launch_group_fast(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
 
 // lane-cooperative chunk kernels (rk_coop.h): eight lanes per trajectory, grid = ceil(trajectories / 8) waves;
 // DOPRI5 / DOP853, built-in right-hand sides without events
-hipError_t ivp_launch_coop_strict(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
-hipError_t ivp_launch_coop_fast(int method, int rhs_id, bool full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+hipError_t ivp_launch_coop_strict(int method, int rhs_id, int full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
+hipError_t ivp_launch_coop_fast(int method, int rhs_id, int full, const IvpKArgs &a, uint32_t trajectories, hipStream_t s);
 
 // thread-per-trajectory BDF kernels (rk_bdf.hip: pinned-coefficient build, n <= 8)
-hipError_t ivp_launch_bdf_strict(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
-hipError_t ivp_launch_bdf_fast(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_bdf_strict(int what, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_bdf_fast(int what, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 // ... and the same source under __launch_bounds__(64, 2) for batches that over-subscribe the chip (see rk_bdf.hip)
-hipError_t ivp_launch_bdf_strict_occ2(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
-hipError_t ivp_launch_bdf_fast_occ2(int what, int rhs_id, bool full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_bdf_strict_occ2(int what, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
+hipError_t ivp_launch_bdf_fast_occ2(int what, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);

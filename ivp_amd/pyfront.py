@@ -156,23 +156,39 @@ def _device_problem(fun: str, n: int, args, events: list, jac, ctx) -> api.Devic
         src += "__device__ void events(double x, const double* y, double* g, const double* p) {\n" + body + "\n}\n"
     has_jac = jac is not None
     if has_jac:
+        jmat = None
         if isinstance(jac, str):
             jbody = jac
         else:
-            m = np.asarray(jac, dtype=np.float64)
-            if m.shape != (n, n):
+            jmat = np.asarray(jac, dtype=np.float64)
+            if jmat.shape != (n, n):
                 raise ValueError(f"jac must be a string or an ({n}, {n}) matrix")
-            jbody = "\n".join(f"  j[{r * n + c}] = {float(m[r, c])!r};" for r in range(n) for c in range(n))
+            jbody = "\n".join(f"  j[{r * n + c}] = {float(jmat[r, c])!r};" for r in range(n) for c in range(n))
         if "__device__" in jbody:
             src += jbody
         elif n <= api.MAX_LANE_N:
             src += "__device__ void jac(double x, const double* y, double* j, const double* p) {\n" + jbody + "\n}\n"
-        else:
-            # the wave-per-trajectory kernels take the Jacobian column by column: fill a local row-major matrix with the
-            # statement form and hand out the requested column
+        elif jmat is not None:
+            # a constant matrix on the wave-per-trajectory path (Jacobian column by column): one switch case per column with
+            # that column's non-zero entries -- O(nnz) code, O(column) work per call, no private storage
+            cases = []
+            for c in range(n):
+                rows = [r for r in range(n) if jmat[r, c] != 0.0]
+                if rows:
+                    cases.append(f"  case {c}: " + " ".join(f"column[{r}] = {float(jmat[r, c])!r};" for r in rows) + " break;")
             src += ("__device__ void jac_col(int ivp_c, double x, const double* y, double* column, const double* p) {\n"
-                    f"  double j[{n * n}];\n  for (int q = 0; q < {n * n}; ++q) j[q] = 0.0;\n" + jbody +
-                    f"\n  for (int r = 0; r < {n}; ++r) column[r] = j[r * {n} + ivp_c];\n}}\n")
+                    f"  for (int r = 0; r < {n}; ++r) column[r] = 0.0;\n  switch (ivp_c) {{\n" + "\n".join(cases) + "\n  default: break;\n  }\n}\n")
+        else:
+            # Statement form (`j[row * n + col] = ...;`) on the wave-per-trajectory path, which takes the Jacobian column by
+            # column: `j` is an O(1) PROXY, not an n x n private array (80 KB per lane at n = 100, 2 MB at n = 512) -- a write
+            # to an entry of the requested column lands in `column`, any other write goes to a dummy.  With constant indices
+            # the test folds at compile time, so only the requested column's statements survive per case of ivp_c.  The
+            # column starts zeroed (entries the body never writes are 0, like the reference's Matrix, bdf.rs:152).
+            # Limitation: a body that READS entries of j sees only the requested column (other entries read as 0).
+            src += ("struct ivp_jac_proxy {\n  double* column; int col; double sink;\n"
+                    f"  __device__ double& operator[](int idx) {{ sink = 0.0; return (idx % {n} == col) ? column[idx / {n}] : sink; }}\n}};\n"
+                    "__device__ void jac_col(int ivp_c, double x, const double* y, double* column, const double* p) {\n"
+                    f"  for (int r = 0; r < {n}; ++r) column[r] = 0.0;\n  ivp_jac_proxy j{{column, ivp_c, 0.0}};\n" + jbody + "\n}\n")
     params = () if args is None else tuple(float(a) for a in (args if isinstance(args, (tuple, list)) else (args,)))
     return api.DeviceIVP(src, n, params, ctx=ctx, events=[_event_config(e) for e in events], jac=has_jac)
 

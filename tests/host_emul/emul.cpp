@@ -18,7 +18,7 @@
 
 using namespace ivp_emul;
 
-template <int M, class R, bool FULL>
+template <int M, class R, int FULL>
 static void run_all(IvpKArgs a, uint64_t *chunks_out)
 {
     uint64_t chunks = 0;
@@ -35,15 +35,26 @@ static void run_all(IvpKArgs a, uint64_t *chunks_out)
     if (chunks_out) *chunks_out = chunks;
 }
 
+// full: kernel flavour as in rk_launch.h (0 end state, 1 whole DefaultSolOut, 2 log-only: adaptive explicit methods of
+// problems without event functions, everything else runs it as 1 -- the dispatch of rk_kernels.hip)
+template <int M, class R>
+static void run_flavour(int full, const IvpKArgs &a, uint64_t *chunks)
+{
+    if constexpr (R::NE == 0 && (M == M_RK23 || M == M_DOPRI5 || M == M_DOP853)) {
+        if (full == 2) { run_all<M, R, 2>(a, chunks); return; }
+    }
+    full ? run_all<M, R, 1>(a, chunks) : run_all<M, R, 0>(a, chunks);
+}
+
 template <class R>
-static int run_rhs(int method, bool full, const IvpKArgs &a, uint64_t *chunks)
+static int run_rhs(int method, int full, const IvpKArgs &a, uint64_t *chunks)
 {
     switch (method) {
-    case 0: full ? run_all<0, R, true>(a, chunks) : run_all<0, R, false>(a, chunks); return 0;
-    case 1: full ? run_all<1, R, true>(a, chunks) : run_all<1, R, false>(a, chunks); return 0;
-    case 2: full ? run_all<2, R, true>(a, chunks) : run_all<2, R, false>(a, chunks); return 0;
-    case 3: full ? run_all<3, R, true>(a, chunks) : run_all<3, R, false>(a, chunks); return 0;
-    case 5: full ? run_all<5, R, true>(a, chunks) : run_all<5, R, false>(a, chunks); return 0;
+    case 0: run_flavour<0, R>(full, a, chunks); return 0;
+    case 1: run_flavour<1, R>(full, a, chunks); return 0;
+    case 2: run_flavour<2, R>(full, a, chunks); return 0;
+    case 3: run_flavour<3, R>(full, a, chunks); return 0;
+    case 5: run_flavour<5, R>(full, a, chunks); return 0;
     }
     return -1;
 }

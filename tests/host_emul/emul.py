@@ -75,7 +75,7 @@ def lib(fast=False):
 
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
                 first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False,
-                event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None):
+                event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None, flavour_log_only=True):
     """``paged_log=(page_shift, pool_pages)``: the one-pass step log -- records go to page chains in a pool
     (ivp_kargs.h); ``res['log_pool']``, ``res['log_cur']``, ``res['log_pages_used']`` and ``res['log_overflow']`` come
     back next to ``n_log`` (``gather_pages`` below lays them out as the CSR log)."""
@@ -176,7 +176,11 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
         res["t_term"] = np.full(B, np.nan)
         a.t_events, a.y_events, a.n_ev, a.t_term = p(res["t_events"]), p(res["y_events"]), p(res["n_ev"]), p(res["t_term"])
     chunks = C.c_uint64(0)
-    rc = L.emul_solve(m, rid, int(full), C.byref(a), C.byref(chunks))
+    # the library's choice of kernel flavour (ivp_capi.cpp): log-only when every accepted step is recorded and nothing else is
+    # asked of the device DefaultSolOut
+    log_only = full and t_eval is None and not dense_output and ne_ev == 0 and first_step is None and (max_log > 0 or paged_log is not None)
+    flavour = 2 if (log_only and flavour_log_only) else int(full)
+    rc = L.emul_solve(m, rid, flavour, C.byref(a), C.byref(chunks))
     if rc == -5:
         raise ValueError("IVP_ERR_INVALID_STEP_SIZE")
     assert rc == 0

@@ -38,8 +38,13 @@ CASES = [
 def test_paged_log_equals_dense_log_and_oracle(name, rhs, make, opts, shift):
     y0, p, t0, t1 = make()
     n = y0.shape[0]
-    dense = emul_batch(rhs, y0, p, t0, t1, max_log=2048, **opts)
+    dense = emul_batch(rhs, y0, p, t0, t1, max_log=2048, flavour_log_only=False, **opts)   # the whole device DefaultSolOut (flavour 1)
     assert int(dense["n_log"].max()) <= 2048
+    lean = emul_batch(rhs, y0, p, t0, t1, max_log=2048, **opts)                               # the log-only flavour where it applies
+    for k in ("t_log", "y_log", "y_end", "t_end", "h_next"):
+        assert np.array_equal(_bits(lean[k]), _bits(dense[k])), k
+    for k in ("n_log", "nfev", "naccpt", "nrejct", "status"):
+        assert np.array_equal(lean[k], dense[k]), k
     pages = int(((dense["n_log"].astype(np.int64) + (1 << shift) - 1) >> shift).sum())
     paged = emul_batch(rhs, y0, p, t0, t1, paged_log=(shift, pages), chunk=7, **opts)
     assert not paged["log_overflow"] and paged["log_pages_used"] == pages    # exactly the pages the counts call for

@@ -373,3 +373,28 @@ def test_statement_form_with_more_than_eight_states_and_a_statement_jacobian():
     np.testing.assert_allclose(b.y[:, -1], exact, rtol=1e-4)
     with pytest.raises(RuntimeError, match="Solver failed"):
         solve_ivp("dydx[0] = this does not compile;", (0.0, 1.0), np.ones(n), method="RK45")
+
+
+@pytest.mark.gpu
+def test_large_statement_and_matrix_jacobians_cost_no_private_matrix():
+    """The advertised range of the statement form (n up to 512) without an n x n private array per lane: a 120-state
+    chain y_i' = -k (i + 1) y_i + c y_{i-1} through BDF with (a) the statement-form Jacobian (O(1) proxy: a write lands in
+    the requested column or in a sink), (b) the same Jacobian as a constant matrix (one switch case per column), (c) the
+    default forward differences.  (a) and (b) describe the same matrix, so BDF takes identical steps; all agree with the
+    closed-form first component and with each other to the tolerance of the run."""
+    from ivp_amd.pyfront import solve_ivp
+    n = 120
+    body = "dydx[0] = -p[0] * y[0];\n" + "\n".join(f"dydx[{i}] = -p[0] * {i + 1}.0 * y[{i}] + p[1] * y[{i - 1}];" for i in range(1, n))
+    jac_s = "j[0] = -p[0];\n" + "\n".join(f"j[{i * n + i}] = -p[0] * {i + 1}.0; j[{i * n + i - 1}] = p[1];" for i in range(1, n))
+    k, c = 0.05, 0.02
+    J = np.diag(-k * np.arange(1, n + 1)) + np.diag(np.full(n - 1, c), -1)
+    y0 = np.linspace(1.0, 2.0, n)
+    kw = dict(method="BDF", args=(k, c), rtol=1e-6, atol=1e-9)
+    a = solve_ivp(body, (0.0, 3.0), y0, jac=jac_s, **kw)
+    b = solve_ivp(body, (0.0, 3.0), y0, jac=J, **kw)
+    d = solve_ivp(body, (0.0, 3.0), y0, **kw)
+    assert a.status == 0 and b.status == 0 and d.status == 0 and a.njev >= 1
+    assert np.array_equal(a.t, b.t) and np.array_equal(a.y, b.y) and a.nfev == b.nfev and a.nlu == b.nlu
+    np.testing.assert_allclose(a.y[0, -1], y0[0] * np.exp(-k * 3.0), rtol=1e-4)
+    np.testing.assert_allclose(a.y[:, -1], d.y[:, -1], rtol=1e-4, atol=1e-8)
+    assert d.nfev > a.nfev     # the default Jacobian pays n + 1 right-hand-side sweeps per evaluation
