@@ -336,8 +336,9 @@ int ivp_batch_wait(ivp_ctx_t *ctx);
  * Without Options.t_eval the reference records every accepted step while it integrates (DefaultSolOut mode 2,
  * src/solve/solout.rs:387-428) and hands the two growing Vecs back as Solution.t / Solution.y
  * (src/solve/solve_ivp.rs:288-312).  The entry points below do the same for a batch: the stepping kernels append each
- * accepted step to per-trajectory chains of fixed-size pages drawn from a device pool, and once every trajectory has
- * finished a gather kernel lays the records out as a CSR log in trajectory order:
+ * accepted step to pages drawn from a device pool (one page per wavefront and 32 record slots, the records of one attempt
+ * side by side, chained per trajectory), and once every trajectory has finished a gather kernel lays the records out as a
+ * CSR log in trajectory order:
  *     trajectory b's k-th record:  t[offsets[b] + k],  y[(offsets[b] + k) * n + c]      (time-major like Vec<Vec<f64>>)
  * with offsets[B] = total.  `out` takes the end-state members / statistics as in ivp_batch_solve (its t_log / y_log /
  * log_offsets are ignored; n_log, if given, receives the counts); opt->t_eval must be NULL.  Everything else about the
@@ -371,9 +372,9 @@ typedef struct {
     int32_t device;       /* HIP device of owned device memory, -1 for host memory                             */
     uint32_t passes;      /* integrations it took: 1 (page pool) or 2 (the pool ran dry: counted fill pass)    */
     uint64_t total;       /* number of records = offsets[B]                                                    */
-    uint64_t pool_pages;  /* pages the pool held / pages of 2^page_shift records the log used                  */
-    uint64_t pages_used;
-    uint32_t page_shift;
+    uint64_t pool_bytes;       /* size of the page pool during the solve / bytes of it the pages took (records + the slots  */
+    uint64_t pool_used_bytes;  /* of rejected attempts and retired lanes + column headers)                                  */
+    uint32_t page_slots;       /* record slots per trajectory and page                                                      */
 } ivp_step_log_t;
 
 int ivp_batch_solve_logged_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, const double *y0,

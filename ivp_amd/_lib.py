@@ -55,7 +55,7 @@ class StepLogT(C.Structure):
     """ivp_step_log_t: the CSR accepted-step log of ivp_batch_solve_logged*() (Solution.t / Solution.y of a batch)."""
     _fields_ = [("offsets", C.c_void_p), ("t", C.c_void_p), ("y", C.c_void_p), ("capacity", C.c_uint64), ("reserve", C.c_uint64),
                 ("defer", C.c_int32), ("owned", C.c_int32), ("device", C.c_int32), ("passes", C.c_uint32), ("total", C.c_uint64),
-                ("pool_pages", C.c_uint64), ("pages_used", C.c_uint64), ("page_shift", C.c_uint32)]
+                ("pool_bytes", C.c_uint64), ("pool_used_bytes", C.c_uint64), ("page_slots", C.c_uint32)]
 
 
 class ShardT(C.Structure):

@@ -1049,8 +1049,8 @@ def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = N
     res.log_offsets = offsets
     res._log_buffers = bufs
     res.t_log, res.y_log = bufs[0][:total], bufs[1][:total]
-    res.log_info = {"passes": int(sl.passes), "records": total, "page_records": 1 << int(sl.page_shift), "pool_pages": int(sl.pool_pages),
-                    "pages_used": int(sl.pages_used), "form": "page pool + gather (one integration)" if sl.passes == 1 else "the pool ran dry: second integration"}
+    res.log_info = {"passes": int(sl.passes), "records": total, "page_slots": int(sl.page_slots), "pool_bytes": int(sl.pool_bytes),
+                    "pool_used_bytes": int(sl.pool_used_bytes), "form": "page pool + gather (one integration)" if sl.passes == 1 else "the pool ran dry: second integration"}
     return res
 
 

@@ -684,7 +684,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     HIP_TRY(ctx, ctx->flags.reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[0].reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[1].reserve(sizeof(uint32_t) * B));
-    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 8));  // [0..3] active-count ring, [4] error flags, [5] pages handed out by the step-log pool
+    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 8));  // [0..3] active-count ring, [4] error flags, [6..7] doubles handed out by the step-log pool (u64)
     a.k1 = (double *)ctx->k1.p;
     a.facold = (double *)ctx->facold.p;
     a.hlamb = (double *)ctx->hlamb.p;
@@ -737,38 +737,34 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         a.t_last = (double *)ctx->sc_t_last.p;
         a.max_log = (want_log || want_dense) ? opt->max_log : 0;
         if (paged) {
-            // One-pass step log (ivp_kargs.h): pages of R records, R chosen so that a page is ~2 KB (two contiguous copies per
-            // page in the gather, half a page wasted per trajectory), drawn from a pool sized from the caller's estimate, the
-            // last logged solve of this batch size on this context, or 1024 records per trajectory (at least 256 MB) -- a pool that turns out too
-            // small costs a second integration (the counted fill pass), never a wrong or truncated log.
-            uint32_t shift = 0;
-            while (shift < 6 && ((size_t)(n + 1) << (shift + 1)) * 8 <= 2048) ++shift;
-            const size_t R = (size_t)1 << shift, page_bytes = (1 + (size_t)(n + 1) * R) * 8;
+            // One-pass step log (ivp_kargs.h): wave pages drawn from a pool sized from the caller's estimate, the last logged
+            // solve of this batch size on this context, or 1024 records per trajectory (at least 256 MB) -- a pool that turns
+            // out too small costs a second integration (the counted fill pass), never a wrong or truncated log.  A page holds
+            // a slot for every ATTEMPT of every trajectory its wave steps, so the pool takes ~1.25x the doubles of the records
+            // (rejected attempts, retired lanes, column headers) -- 1.5x is reserved.
             ivp_ctx::LogState &LS = ctx->log_state;
             const bool learnt = LS.total && LS.last_B == B;
-            uint64_t recs = log_reserve ? log_reserve : (learnt ? LS.total + LS.total / 8 : (uint64_t)B * 1024u);
-            uint64_t pages = recs / R + B + 64;
-            // nothing known about the problem yet: a small batch of long trajectories (stiff problems, chaotic ones) should not
-            // run dry either -- 256 MB of pages cost nothing on a 288 GB part (the pool is reserved once per context, grow-only)
-            if (!log_reserve && !learnt) pages = std::max<uint64_t>(pages, ((uint64_t)256 << 20) / page_bytes);
-            if (pages * page_bytes > ctx->log_pool.cap) {   // growing: never ask for more than half of what the device can give
+            const uint64_t recs = log_reserve ? log_reserve : (learnt ? LS.total : (uint64_t)B * 1024u);
+            uint64_t doubles = recs * (uint64_t)(n + 1) / 2 * 3 + (uint64_t)B * (2u + 2u * (uint64_t)(n + 1)) + (1u << 16);
+            if (learnt && !log_reserve) doubles = std::max<uint64_t>(doubles, LS.pool_used + LS.pool_used / 8);   // what that solve really took
+            if (!log_reserve && !learnt) doubles = std::max<uint64_t>(doubles, ((uint64_t)256 << 20) / 8);
+            if (doubles * 8 > ctx->log_pool.cap) {   // growing: never ask for more than half of what the device can give
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                    const uint64_t most = (uint64_t)(free_b + ctx->log_pool.cap) / 2 / page_bytes;
-                    if (pages > most) pages = std::max<uint64_t>(most, ctx->log_pool.cap / page_bytes);
+                    const uint64_t most = (uint64_t)(free_b + ctx->log_pool.cap) / 2 / 8;
+                    if (doubles > most) doubles = std::max<uint64_t>(most, ctx->log_pool.cap / 8);
                 }
             }
-            pages = std::min<uint64_t>(std::max<uint64_t>(pages, 1), 0xFFFFFFF0ull);
-            HIP_TRY(ctx, ctx->log_pool.reserve((size_t)pages * page_bytes));
-            HIP_TRY(ctx, ctx->log_cur.reserve(sizeof(uint32_t) * B));
+            doubles = std::min<uint64_t>(std::max<uint64_t>(doubles, 4096), (uint64_t)1 << 46);
+            HIP_TRY(ctx, ctx->log_pool.reserve((size_t)doubles * 8));
+            HIP_TRY(ctx, ctx->log_cur.reserve(sizeof(unsigned long long) * B));
             a.log_pool = (double *)ctx->log_pool.p;
-            a.log_page_shift = shift;
-            a.log_pool_pages = (uint32_t)std::min<uint64_t>(ctx->log_pool.cap / page_bytes, 0xFFFFFFF0ull);
-            a.log_pool_next = (uint32_t *)ctx->counts.p + 5;
-            a.log_cur = (uint32_t *)ctx->log_cur.p;
+            a.log_pool_doubles = ctx->log_pool.cap / 8;
+            a.log_pool_next = (unsigned long long *)((uint32_t *)ctx->counts.p + 6);
+            a.log_cur = (unsigned long long *)ctx->log_cur.p;
             a.t_log = a.log_pool;   // "mode 2" marker of the device DefaultSolOut (so_sample); the records go to the pages
             a.y_log = a.log_pool;
-            LS.B = B; LS.n = n; LS.shift = shift; LS.pool_pages = a.log_pool_pages; LS.n_log = a.n_log;
+            LS.B = B; LS.n = n; LS.pool_doubles = a.log_pool_doubles; LS.n_log = a.n_log;
         } else if (count_log) {
             // counting pass = a CSR log whose offsets are all zero: so_sample runs (t_log != NULL), every record finds
             // capacity 0 and only n_log advances

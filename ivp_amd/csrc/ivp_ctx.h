@@ -68,8 +68,8 @@ struct ivp_ctx {
         bool overflow = false;      // ... the pool ran dry: n_log is exact, the records are not all there
         size_t B = 0;
         int n = 0;
-        uint32_t shift = 0;
-        uint32_t pool_pages = 0;
+        uint64_t pool_doubles = 0;  // capacity of the pool during that solve
+        uint64_t pool_used = 0;     // doubles its pages took
         uint64_t total = 0;         // records of the last logged solve (sizes the next pool)
         size_t last_B = 0;          // batch size `total` belongs to
         const uint32_t *n_log = nullptr;   // device: the counts of the last logged solve (the caller's out->n_log, or scratch):

@@ -133,18 +133,25 @@ struct IvpKArgs {
                               // FIRST, so the next launch's window starts with them).  A thread-per-trajectory wave saturates the
                               // f64 pipe of its SIMD on its own, so a launch of 1563 waves on 1024 SIMDs lasts as long as one of
                               // 2048: the launch loop cuts such a launch down to whole multiples of one wave per SIMD.
-    // ---- one-pass accepted-step log (so_push_log): records go to fixed-size PAGES drawn from a device pool ----
+    // ---- one-pass accepted-step log (so_push_log): records go to WAVE PAGES drawn from a device pool ----
     // The reference pushes every accepted step into growing Vecs (solout.rs:387-428); a GPU lane cannot grow a Vec, and a
-    // counting solve before the filling solve costs a whole second integration.  With log_pool != NULL a trajectory's records
-    // go to pages of R = 1 << log_page_shift records that are bump-allocated from the pool whenever the previous page is full
-    // (one atomicAdd per wave and allocation round).  A page is [header: 1 double][t: R doubles][y: R x n doubles, time-major];
-    // the header holds the id of the trajectory's PREVIOUS page (IVP_NO_PAGE for its first), log_cur[j] the id of its current
-    // (last) page: a chain per trajectory, any length.  Once every count is known a gather kernel (log_gather.hip) walks the
-    // chains and lays the records out as the CSR log (t_log [total], y_log [total][n]) with two contiguous copies per page.
-    double *log_pool;         // pages; NULL = the dense / two-pass CSR forms above
-    uint32_t log_page_shift;
-    uint32_t log_pool_pages;  // capacity in pages; beyond it records are counted but not stored (IVP_ERRFLAG_LOG_OVERFLOW)
-    uint32_t *log_pool_next;  // device counter: pages handed out so far
-    uint32_t *log_cur;        // [B] the page that takes the trajectory's next record (IVP_NO_PAGE: none yet / pool exhausted)
+    // counting solve before the filling solve costs a whole second integration.  With log_pool != NULL the stepping kernels
+    // record as they go.  Every IVP_LOG_SLOTS record slots (32 attempts of a log-only kernel, 16 of a full one, whose attempts
+    // may record twice) a WAVE bump-allocates one page for all its trajectories (one atomicAdd):
+    //     [cols x header (2 doubles)] [slot 0: cols records] [slot 1: cols records] ...      record = [t, y_0 .. y_{n-1}]
+    // cols = trajectories the wave is stepping, column = a trajectory's rank among them, slot = attempt index within the page
+    // (wave-uniform), so the records of one attempt are ONE contiguous run of cols x (n + 1) doubles: the wave's stores fill
+    // whole cache lines back to back (lanes that rejected leave holes).  Per-trajectory pages would touch one partly written
+    // line per trajectory and attempt -- 1M trajectories x 2 lines do not fit any cache: every 8-byte store became a partial
+    // HBM write (measured: BASELINE C3 28.9 ms with per-trajectory pages, end state 12.7).
+    // A column header is {prev: the trajectory's previous segment, k0: its record count when the page was opened, bits: which
+    // slots hold a record}; log_cur[j] names trajectory j's last segment: a chain per trajectory, any length.  A segment is
+    // (page offset in doubles) << 16 | cols << 8 | column.  Once every count is known a gather kernel (log_gather.hip) walks
+    // the chains and lays the records out as the CSR log (t_log [total], y_log [total][n]).
+    double *log_pool;                    // NULL = the dense / two-pass CSR forms above
+    unsigned long long log_pool_doubles; // capacity; beyond it records are counted but not stored (IVP_ERRFLAG_LOG_OVERFLOW)
+    unsigned long long *log_pool_next;   // device counter: doubles handed out so far
+    unsigned long long *log_cur;         // [B] last segment of every trajectory (IVP_NO_SEG: none)
 };
-#define IVP_NO_PAGE 0xFFFFFFFFu
+#define IVP_LOG_SLOTS 32u
+#define IVP_NO_SEG 0xFFFFFFFFFFFFFFFFull

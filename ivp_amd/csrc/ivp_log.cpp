@@ -3,11 +3,11 @@
 // src/solve/solve_ivp.rs:288-312).
 //
 // Flow of a logged solve on one context:
-//   1. ivp_batch_submit_device with ctx->log_plan.want: the stepping kernels append every accepted step to per-trajectory
-//      page chains in the context's pool (ivp_kargs.h, so_push_log in rk_core.h) and count them in n_log;
+//   1. ivp_batch_submit_device with ctx->log_plan.want: the stepping kernels append every accepted step to wave pages in the
+//      context's pool, chained per trajectory (ivp_kargs.h, so_log_open / so_push_log in rk_core.h), and count them in n_log;
 //   2. exclusive scan of n_log -> offsets, total (log_gather.hip); the total travels to the host (8 bytes);
 //   3. destination = the caller's buffers if they hold `total` records, else library-allocated;
-//   4. the gather kernel walks the chains and writes the CSR log (two contiguous copies per page).
+//   4. the gather kernel walks the chains and writes the CSR log.
 // If the pool ran dry on the way (IVP_ERRFLAG_LOG_OVERFLOW) the counts are still exact: step 4 is replaced by the counted
 // FILL pass of the two-pass CSR log (a second integration writing straight to the destination), and the next logged
 // solve of this batch size sizes its pool from the total it has learnt.  No arithmetic of the integration happens here.
@@ -30,13 +30,15 @@ int scan_counts(ivp_ctx *ctx, unsigned long long *offsets_dev, hipStream_t s, ui
     HIP_TRY(ctx, ctx->log_bsum.reserve(ivp_log_scan_scratch_bytes(LS.B)));
     HIP_TRY(ctx, ivp_log_scan(LS.n_log, LS.B, offsets_dev, ctx->log_bsum.p, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 8, offsets_dev + LS.B, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 10, (const uint32_t *)ctx->counts.p + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 10, (const uint32_t *)ctx->counts.p + 6, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     unsigned long long t;
     std::memcpy(&t, ctx->pinned + 8, sizeof t);
     *total = t;
     LS.total = t;
     LS.last_B = LS.B;
+    std::memcpy(&t, ctx->pinned + 10, sizeof t);
+    LS.pool_used = t;   // doubles the wave pages took (may exceed the capacity after an overflow: the counter keeps counting)
     return IVP_OK;
 }
 
@@ -44,9 +46,9 @@ void fill_log_info(const ivp_ctx *ctx, ivp_step_log_t *log)
 {
     const ivp_ctx::LogState &LS = ctx->log_state;
     log->total = LS.total;
-    log->page_shift = LS.shift;
-    log->pool_pages = LS.pool_pages;
-    log->pages_used = std::min<uint64_t>(ctx->pinned[10], LS.pool_pages);
+    log->page_slots = IVP_LOG_SLOTS;
+    log->pool_bytes = LS.pool_doubles * 8;
+    log->pool_used_bytes = std::min<uint64_t>(LS.pool_used, LS.pool_doubles) * 8;
 }
 
 // the caller's buffers, or exactly `total` records of device memory owned by the log (released by ivp_step_log_free)
@@ -74,7 +76,7 @@ int device_destination(ivp_ctx *ctx, ivp_step_log_t *log, uint64_t total, int n,
 int gather_pool(ivp_ctx *ctx, const unsigned long long *offsets_dev, uint64_t capacity, uint64_t dst_base, double *t, double *y, hipStream_t s)
 {
     const ivp_ctx::LogState &LS = ctx->log_state;
-    HIP_TRY(ctx, ivp_log_gather((const double *)ctx->log_pool.p, (const uint32_t *)ctx->log_cur.p, LS.n_log, offsets_dev, LS.B, LS.n, LS.shift,
+    HIP_TRY(ctx, ivp_log_gather((const double *)ctx->log_pool.p, (const unsigned long long *)ctx->log_cur.p, LS.n_log, offsets_dev, LS.B, LS.n,
                                 capacity, dst_base, t, y, s));
     return IVP_OK;
 }
@@ -91,7 +93,7 @@ int ivp_batch_solve_logged_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, siz
     if (!opt || !out || !log || !log->offsets) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "null options / out / log / log->offsets");
     if (opt->t_eval) return fail(ctx, IVP_ERR_BAD_ARGUMENT, "the accepted-step log is what solve_ivp records when t_eval is None");
     hipStream_t s = (hipStream_t)hip_stream;
-    log->owned = 0; log->device = -1; log->passes = 0; log->total = 0; log->pool_pages = 0; log->pages_used = 0; log->page_shift = 0;
+    log->owned = 0; log->device = -1; log->passes = 0; log->total = 0; log->pool_bytes = 0; log->pool_used_bytes = 0; log->page_slots = 0;
     ivp_options_t o = *opt;
     o.count_log = 0;
     ivp_batch_result_t r = *out;
@@ -212,7 +214,7 @@ int ivp_batch_solve_logged(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B, 
                                        (const double *)ctx->st_t0.p, l0, (const double *)ctx->st_t1.p, l1, opt, &dev, &dl, nullptr);
     if (rc != IVP_OK) return rc;
     const uint64_t total = dl.total;
-    log->total = total; log->page_shift = dl.page_shift; log->pool_pages = dl.pool_pages; log->pages_used = dl.pages_used;
+    log->total = total; log->page_slots = dl.page_slots; log->pool_bytes = dl.pool_bytes; log->pool_used_bytes = dl.pool_used_bytes;
     log->owned = 0; log->device = -1; log->passes = 1;
     HIP_TRY(ctx, hipMemcpyAsync(log->offsets, ctx->st_logoff.p, sizeof(unsigned long long) * (B + 1), hipMemcpyDeviceToHost, nullptr));
     for (int k = 0; k < kMembers; ++k) {
@@ -343,7 +345,7 @@ int ivp_batch_solve_logged_multi(ivp_shard_t *shards, int32_t n_shards, const iv
     if (opt->t_eval) return fail(c0, IVP_ERR_BAD_ARGUMENT, "the accepted-step log is what solve_ivp records when t_eval is None");
     if ((log->t == nullptr) != (log->y == nullptr)) return fail(c0, IVP_ERR_BAD_ARGUMENT, "ivp_step_log_t: t and y must both be given or both be NULL");
     DeviceGuard restore_device;
-    log->owned = 0; log->device = -1; log->passes = 1; log->total = 0; log->pool_pages = 0; log->pages_used = 0; log->page_shift = 0;
+    log->owned = 0; log->device = -1; log->passes = 1; log->total = 0; log->pool_bytes = 0; log->pool_used_bytes = 0; log->page_slots = 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || gather_device < 0 || gather_device >= ndev) return fail(c0, IVP_ERR_BAD_ARGUMENT, "gather_device %d", gather_device);
     ivp_options_t o = *opt;
@@ -382,9 +384,9 @@ int ivp_batch_solve_logged_multi(ivp_shard_t *shards, int32_t n_shards, const iv
         uint64_t tot = 0;
         rc = scan_counts(ctx, (unsigned long long *)ctx->log_off.p, s, &tot);
         if (rc != IVP_OK) return bail(rc);
-        log->pool_pages += ctx->log_state.pool_pages;
-        log->pages_used += std::min<uint64_t>(ctx->pinned[10], ctx->log_state.pool_pages);
-        log->page_shift = ctx->log_state.shift;
+        log->pool_bytes += ctx->log_state.pool_doubles * 8;
+        log->pool_used_bytes += std::min<uint64_t>(ctx->log_state.pool_used, ctx->log_state.pool_doubles) * 8;
+        log->page_slots = IVP_LOG_SLOTS;
         off.resize(sh.count + 1);
         if (hipMemcpyAsync(off.data(), ctx->log_off.p, (sh.count + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)

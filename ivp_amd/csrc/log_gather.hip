@@ -1,13 +1,16 @@
-// log_gather.hip -- second half of the one-pass accepted-step log (gfx950): page chains -> CSR.
+// log_gather.hip -- second half of the one-pass accepted-step log (gfx950): wave pages -> CSR.
 //
-// The stepping kernels leave every trajectory's records in a chain of pool pages (ivp_kargs.h, so_push_log in rk_core.h)
+// The stepping kernels leave every trajectory's records in a chain of segments (a segment = one column of a wave page: up to
+// 32 record slots, a bit per slot that holds a record; layout in ivp_kargs.h, writers so_log_open / so_push_log in rk_core.h)
 // and its record count in n_log.  Here:
 //   ivp_log_scan    offsets[b] = sum of n_log[0 .. b), offsets[B] = total          (three small launches)
-//   ivp_log_gather  one wavefront per trajectory walks its chain from the last page back to the first and copies each
-//                   page's t block and y block to their place in the CSR log -- two contiguous, coalesced copies per page:
-//                   t_log[offsets[b] + k], y_log[(offsets[b] + k) * n + c]  (time-major like the reference's
-//                   Solution.t / Solution.y, src/solve/solout.rs:387-428, src/solve/solve_ivp.rs:288-312).
-// Both are pure data movement: HBM-bound, 2 x 8 (n + 1) bytes per record.
+//   ivp_log_gather  a group of lanes per trajectory walks its chain from the last segment back to the first; a segment's
+//                   k-th record (k = rank of its slot among the set bits) goes to t_log[offsets[b] + k0 + k],
+//                   y_log[(offsets[b] + k0 + k) * n + c]  (time-major like the reference's Solution.t / Solution.y,
+//                   src/solve/solout.rs:387-428, src/solve/solve_ivp.rs:288-312).  Lane <-> double of the segment: the
+//                   n + 1 doubles of a record are read by adjacent lanes, the y part of consecutive records is written to
+//                   consecutive addresses.
+// Both are pure data movement: HBM-bound, ~2 x 8 (n + 1) bytes per record.
 #include <hip/hip_runtime.h>
 
 #include "ivp_kargs.h"
@@ -92,33 +95,57 @@ __global__ __launch_bounds__(kScanThreads) void log_scan_apply(const uint32_t *n
     }
 }
 
-// One wavefront per trajectory.  `capacity` = records the destination holds: a log that does not fit is left alone (the
-// host reports it; nothing is written out of bounds).
-__global__ __launch_bounds__(IVP_WAVE) void log_gather_kernel(const double *pool, const uint32_t *log_cur, const uint32_t *n_log,
-                                                              const unsigned long long *offsets, uint32_t B, uint32_t n, uint32_t shift,
+// G lanes per trajectory (64 / G trajectories per wavefront), NP1 = n + 1 as a compile-time constant where it is small
+// (0 = run-time).  `capacity` = records the destination holds: a log that does not fit is left alone (the host reports it;
+// nothing is written out of bounds).
+template <int G, int NP1>
+__global__ __launch_bounds__(IVP_WAVE) void log_gather_kernel(const double *pool, const unsigned long long *log_cur, const uint32_t *n_log,
+                                                              const unsigned long long *offsets, uint32_t B, uint32_t n_rt,
                                                               unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log)
 {
-    const uint32_t j = blockIdx.x, lane = threadIdx.x;
-    const uint32_t cnt = n_log[j];
-    if (cnt == 0u || offsets[B] > capacity) return;
+    const uint32_t np1 = NP1 ? (uint32_t)NP1 : n_rt + 1u, n = np1 - 1u;
+    const uint32_t gl = threadIdx.x & (G - 1);
+    const uint32_t j = blockIdx.x * (IVP_WAVE / G) + threadIdx.x / G;
+    if (j >= B || offsets[B] > capacity) return;
+    if (n_log[j] == 0u) return;
     const unsigned long long off = offsets[j] + dst_base;
-    const uint32_t R = 1u << shift;
-    const size_t page_doubles = 1u + ((size_t)(n + 1u) << shift);
-    const uint32_t pages = (cnt + R - 1u) >> shift;
-    uint32_t page = log_cur[j];
-    for (uint32_t p = pages; p-- > 0u;) {
-        const double *src = pool + (size_t)page * page_doubles;
-        const uint32_t prev = *(const uint32_t *)src;             // header: the trajectory's previous page
-        const uint32_t recs = (p + 1u == pages) ? cnt - (p << shift) : R;
-        const unsigned long long q0 = off + ((unsigned long long)p << shift);
-        const double *st = src + 1;
-        for (uint32_t i = lane; i < recs; i += IVP_WAVE) t_log[q0 + i] = st[i];
-        const double *sy = st + R;
-        double *dy = y_log + q0 * n;
-        const uint32_t m = recs * n;
-        for (uint32_t i = lane; i < m; i += IVP_WAVE) dy[i] = sy[i];
-        page = prev;
+    unsigned long long seg = log_cur[j];
+    const uint32_t elems = IVP_LOG_SLOTS * np1;
+    while (seg != IVP_NO_SEG) {
+        const size_t base = (size_t)(seg >> 16), cols = (size_t)((seg >> 8) & 0xFFu), col = (size_t)(seg & 0xFFu);
+        const double *hdr = pool + base + 2u * col;
+        const unsigned long long prev = *(const unsigned long long *)hdr;
+        const uint32_t k0 = ((const uint32_t *)hdr)[2], bits = ((const uint32_t *)hdr)[3];
+        const double *body = pool + base + 2u * cols + col * np1;
+        const size_t slot_stride = cols * np1;
+        const unsigned long long q0 = off + k0;
+        if (bits != 0u) {
+            for (uint32_t e = gl; e < elems; e += G) {
+                const uint32_t s = e / np1, c = e - s * np1;
+                if ((bits >> s) & 1u) {
+                    const unsigned long long q = q0 + (unsigned long long)__popc(bits & ((1u << s) - 1u));
+                    const double v = body[(size_t)s * slot_stride + c];
+                    if (c == 0u) t_log[q] = v;
+                    else y_log[q * n + (c - 1u)] = v;
+                }
+            }
+        }
+        seg = prev;
     }
+}
+
+template <int G>
+hipError_t launch_gather(const double *pool, const unsigned long long *log_cur, const uint32_t *n_log, const unsigned long long *offsets, size_t B, int n,
+                         unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log, hipStream_t s)
+{
+    const dim3 grid((uint32_t)((B + (IVP_WAVE / G) - 1) / (IVP_WAVE / G))), block(IVP_WAVE);
+#define IVP_GATHER_CASE(NP1) case NP1: hipLaunchKernelGGL((log_gather_kernel<G, NP1>), grid, block, 0, s, pool, log_cur, n_log, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
+    switch (n + 1) {
+        IVP_GATHER_CASE(2) IVP_GATHER_CASE(3) IVP_GATHER_CASE(4) IVP_GATHER_CASE(5) IVP_GATHER_CASE(6) IVP_GATHER_CASE(7) IVP_GATHER_CASE(8) IVP_GATHER_CASE(9)
+    default: hipLaunchKernelGGL((log_gather_kernel<G, 0>), grid, block, 0, s, pool, log_cur, n_log, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
+    }
+#undef IVP_GATHER_CASE
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -137,12 +164,16 @@ hipError_t ivp_log_scan(const uint32_t *n_log, size_t B, unsigned long long *off
     return hipGetLastError();
 }
 
-hipError_t ivp_log_gather(const double *pool, const uint32_t *log_cur, const uint32_t *n_log, const unsigned long long *offsets, size_t B,
-                          int n, uint32_t shift, unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log, hipStream_t s)
+hipError_t ivp_log_gather(const double *pool, const unsigned long long *log_cur, const uint32_t *n_log, const unsigned long long *offsets, size_t B,
+                          int n, unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log, hipStream_t s)
 {
     if (B == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(log_gather_kernel, dim3((uint32_t)B), dim3(IVP_WAVE), 0, s, pool, log_cur, n_log, offsets, (uint32_t)B, (uint32_t)n, shift,
-                       capacity, dst_base, t_log, y_log);
-    return hipGetLastError();
+    // a segment is 32 x (n + 1) doubles: as many lanes per trajectory as keep ~3 doubles per lane and segment in flight, and as
+    // many trajectories per wavefront as that leaves room for (the chain walk is a dependent load per segment: more
+    // independent chains per wave hide it)
+    const int elems = (int)IVP_LOG_SLOTS * (n + 1);
+    if (elems >= 192) return launch_gather<64>(pool, log_cur, n_log, offsets, B, n, capacity, dst_base, t_log, y_log, s);
+    if (elems >= 96) return launch_gather<32>(pool, log_cur, n_log, offsets, B, n, capacity, dst_base, t_log, y_log, s);
+    return launch_gather<16>(pool, log_cur, n_log, offsets, B, n, capacity, dst_base, t_log, y_log, s);
 }

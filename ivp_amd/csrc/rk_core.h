@@ -523,6 +523,8 @@ struct IdMap {
     static IVP_HD bool leader() { return true; }
     static IVP_HD uint32_t bcast(uint32_t v) { return v; }
 };
+template <class MAP>
+IVP_HD uint64_t map_bcast64(uint64_t v) { return ((uint64_t)MAP::bcast((uint32_t)(v >> 32)) << 32) | (uint64_t)MAP::bcast((uint32_t)v); }
 template <class R, class = void>
 struct OutMap { using type = IdMap<R::N>; };
 template <class R, class = void>
@@ -569,7 +571,10 @@ struct Lane {
     int32_t next_idx, n_filled;
     uint32_t n_log, n_seg;
     double t_last;
-    uint32_t log_page;    // one-pass step log: the page that takes the next record (IvpKArgs.log_cur)
+    // one-pass step log (IvpKArgs.log_pool): the trajectory's current segment (wave page + column), the slots of it that
+    // hold a record, the slot the next record of this attempt goes to
+    uint64_t log_seg;
+    uint32_t log_bits, log_slot;
 };
 
 template <class R>
@@ -610,10 +615,11 @@ IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool r
         L.n_log = a.n_log[j];
         L.n_seg = a.n_seg[j];
         L.t_last = a.t_last[j];
-        L.log_page = a.log_cur ? a.log_cur[j] : IVP_NO_PAGE;
+        L.log_seg = a.log_cur ? a.log_cur[j] : IVP_NO_SEG;
     } else {
-        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_page = IVP_NO_PAGE;
+        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_seg = IVP_NO_SEG;
     }
+    L.log_bits = 0; L.log_slot = 0;
 }
 
 template <class R>
@@ -640,7 +646,7 @@ IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L,
         a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg;
         a.t_last[j] = L.t_last;
-        if (a.log_cur) a.log_cur[j] = L.log_page;
+        if (a.log_cur) a.log_cur[j] = L.log_seg;
     }
 }
 
@@ -792,53 +798,83 @@ IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t t
     }
     L.n_filled += 1;
 }
-// One page of the one-pass step log from the pool (IvpKArgs.log_pool).  The lanes of a wave that need a page in the same
-// allocation round share ONE atomicAdd (ballot -> popcount -> the first of them adds -> rank among the set bits); lanes
-// that hold a trajectory together get the page their leader drew.  IVP_NO_PAGE once the pool is exhausted: the records
-// are still counted (n_log), the host sees IVP_ERRFLAG_LOG_OVERFLOW and falls back to the counted two-pass log.
-template <class MAP>
-IVP_HD uint32_t so_log_new_page(const IvpKArgs &a)
+// ---- one-pass step log: wave pages (layout and rationale: ivp_kargs.h) ----
+// so_log_flush: the slots of the current segment that hold a record go to its column header.
+template <class MAP, int N, int P>
+IVP_HD void so_log_flush(const IvpKArgs &a, const Lane<N, P> &L)
 {
-    uint32_t page = IVP_NO_PAGE;
+    // (log_bits == 0: nothing recorded into it by this launch -- either a fresh segment, whose header says 0 already, or the
+    // segment an earlier launch closed, whose header must not be touched)
+    if (L.log_seg != IVP_NO_SEG && L.log_bits != 0u && MAP::leader())
+        ((uint32_t *)(a.log_pool + (size_t)(L.log_seg >> 16) + 2u * (size_t)(L.log_seg & 0xFFu)))[3] = L.log_bits;
+}
+// so_log_open: every trajectory the wave is stepping gets a column of ONE fresh page of `slots` record slots.  Called at a
+// point all of them reach together (top of the attempt loop, top of the init body); the lanes present share one atomicAdd
+// (ballot -> popcount -> the first of them adds -> rank among the set bits = the column).  Lanes that hold a trajectory
+// together (rk_coop.h, rk_group.h) act through their leader.  Pool exhausted: IVP_NO_SEG -- the records are still counted
+// (n_log), the host sees IVP_ERRFLAG_LOG_OVERFLOW and falls back to the counted two-pass log.
+template <class MAP, int N, int P>
+IVP_HD void so_log_open(const IvpKArgs &a, Lane<N, P> &L, uint32_t slots)
+{
+    so_log_flush<MAP>(a, L);
+    uint64_t seg = IVP_NO_SEG;
     if (MAP::leader()) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned long long m = __ballot(true);
         const uint32_t lane = __lane_id();
         const int first = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if ((int)lane == first) base = atomicAdd(a.log_pool_next, (uint32_t)__popcll(m));
-        page = (uint32_t)__shfl((int)base, first) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t cols = (uint32_t)__popcll(m), col = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long page_doubles = (unsigned long long)cols * (2u + (unsigned long long)slots * (MAP::NT + 1));
+        unsigned long long base = 0;
+        if ((int)lane == first) base = atomicAdd(a.log_pool_next, page_doubles);
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), first) << 32) | (uint32_t)__shfl((int)(uint32_t)base, first);
 #else
-        page = (*a.log_pool_next)++;
+        const uint32_t cols = 1, col = 0;
+        const unsigned long long page_doubles = 2u + (unsigned long long)slots * (MAP::NT + 1);
+        const unsigned long long base = *a.log_pool_next;
+        *a.log_pool_next += page_doubles;
 #endif
-        if (page >= a.log_pool_pages) {
-            page = IVP_NO_PAGE;
+        if (base + page_doubles > a.log_pool_doubles) {
             ivp_flag_error(a, IVP_ERRFLAG_LOG_OVERFLOW);
+        } else {
+            seg = ((uint64_t)base << 16) | ((uint64_t)cols << 8) | (uint64_t)col;
+            double *hdr = a.log_pool + (size_t)base + 2u * (size_t)col;
+            *(uint64_t *)hdr = L.log_seg;              // the trajectory's previous segment
+            ((uint32_t *)hdr)[2] = L.n_log;            // its record count so far: where this segment's records go
+            ((uint32_t *)hdr)[3] = 0u;
         }
     }
-    return MAP::bcast(page);
+    L.log_seg = map_bcast64<MAP>(seg);
+    L.log_bits = 0;
+}
+// so_log_attempt: top of every step attempt of a recording kernel -- all trajectories the wave is still stepping pass here
+// together with the same attempt index `it`.  An attempt records at most once in the log-only flavour (FULL == 2:
+// so_log_accepted) and at most twice in the full one (first_step enforcement, solout.rs:392-421), so a page of
+// IVP_LOG_SLOTS slots lasts 32 / 16 attempts.
+template <class MAP, int FULL, int N, int P>
+IVP_HD void so_log_attempt(const IvpKArgs &a, Lane<N, P> &L, uint32_t it)
+{
+    constexpr uint32_t kPerAttempt = FULL == 2 ? 1u : 2u, kAttempts = IVP_LOG_SLOTS / kPerAttempt;
+    const uint32_t q = it & (kAttempts - 1u);
+    if (q == 0u) so_log_open<MAP>(a, L, IVP_LOG_SLOTS);
+    L.log_slot = q * kPerAttempt;
 }
 template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, const double *yv)
 {
     const size_t B = a.B;
     if (a.log_pool != nullptr) {
-        // one-pass log: record k of the trajectory goes to slot k mod R of its current page (ivp_kargs.h); a full page is
-        // followed by a fresh one from the pool, chained to its predecessor through the page header
-        const uint32_t slot = L.n_log & ((1u << a.log_page_shift) - 1u);
-        const size_t page_doubles = 1u + ((size_t)(MAP::NT + 1) << a.log_page_shift);
-        if (slot == 0u) {
-            const uint32_t fresh = so_log_new_page<MAP>(a);
-            if (fresh != IVP_NO_PAGE && MAP::leader()) *(uint32_t *)(a.log_pool + (size_t)fresh * page_doubles) = L.log_page;
-            L.log_page = fresh;
-        }
-        if (L.log_page != IVP_NO_PAGE) {
-            double *pg = a.log_pool + (size_t)L.log_page * page_doubles + 1;
-            pg[slot] = t;
-            double *py = pg + ((size_t)1 << a.log_page_shift) + (size_t)slot * MAP::NT;
+        // one-pass log: the record goes to this attempt's slot of the trajectory's column in the wave's current page
+        // (ivp_kargs.h) -- next to the records the other trajectories of the wave write in this attempt
+        if (L.log_seg != IVP_NO_SEG) {
+            const size_t cols = (size_t)((L.log_seg >> 8) & 0xFFu), col = (size_t)(L.log_seg & 0xFFu);
+            double *rec = a.log_pool + (size_t)(L.log_seg >> 16) + 2u * cols + ((size_t)L.log_slot * cols + col) * (MAP::NT + 1);
+            if (MAP::leader()) rec[0] = t;
 #pragma unroll
-            for (int c = 0; c < N; ++c) if (MAP::own(c)) py[MAP::gi(c)] = yv[c];
+            for (int c = 0; c < N; ++c) if (MAP::own(c)) rec[1 + MAP::gi(c)] = yv[c];
+            L.log_bits |= 1u << L.log_slot;
         }
+        L.log_slot += 1;
     } else if (a.log_off != nullptr) {
         // CSR log (two-pass count / fill): record k of trajectory j lives at log_off[j] + k, memory = sum of the counts
         const unsigned long long lo = a.log_off[j], cap = a.log_off[j + 1] - lo;
@@ -1182,7 +1218,9 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     L.flags = 0;
     L.facold = 1e-4;
     L.hlamb = 0.0;
-    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_page = IVP_NO_PAGE;
+    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    L.log_seg = IVP_NO_SEG; L.log_bits = 0; L.log_slot = 0;
+    if (FULL && a.log_pool != nullptr) so_log_open<MAP>(a, L, 2u);   // the initial callback records at most twice
     uint64_t nfev = 0;
 
     if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
@@ -1207,7 +1245,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
             }
             a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
             a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
-            if (a.log_cur) a.log_cur[j] = L.log_page;
+            if (a.log_cur) { so_log_flush<MAP>(a, L); a.log_cur[j] = L.log_seg; }
         }
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 0;
@@ -1223,7 +1261,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 3;
         a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
-        if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = IVP_NO_PAGE; }
+        if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = L.log_seg; }
         return 3;
     }
     L.posneg = rs_signum(L.xend - L.x0);
@@ -1244,7 +1282,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
             a.x[j] = L.x0; a.h[j] = L.h; a.facold[j] = 0.0; a.hlamb[j] = 0.0; a.flags[j] = 0;
             a.status[j] = 0;
             a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
-            if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = IVP_NO_PAGE; }
+            if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = L.log_seg; }
             return 0;
         }
     } else if (a.has_first_step) {
@@ -1265,7 +1303,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     if (FULL) {
         a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
-        if (a.log_cur) a.log_cur[j] = L.log_page;
+        if (a.log_cur) { so_log_flush<MAP>(a, L); a.log_cur[j] = L.log_seg; }
     }
     return IVP_RUNNING;
 }
@@ -1896,12 +1934,14 @@ IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
     uint32_t it = 0;
     bool run = true;
     while (run && it < a.chunk) {
+        if (FULL && a.log_pool != nullptr) so_log_attempt<typename OutMap<R>::type, FULL>(a, L, it);
         if constexpr (M == M_DOPRI5) run = dopri5_attempt<R, FULL, CTL>(a, j, L);
         else if constexpr (M == M_DOP853) run = dop853_attempt<R, FULL, CTL>(a, j, L);
         else if constexpr (M == M_RK4) run = rk4_attempt<R, FULL>(a, j, L);
         else run = rk23_attempt<R, FULL, CTL>(a, j, L);
         ++it;
     }
+    if (FULL && a.log_pool != nullptr) so_log_flush<typename OutMap<R>::type>(a, L);
     // Re-derive the store addresses from an opaque copy of j: otherwise the ~2 VGPRs per state array
     // that the loads' address arithmetic produced stay live across the whole attempt loop.
     uint32_t js = j;

@@ -429,8 +429,8 @@ def solve_ivp_batch_multi(f: api.IVP, t0, t1, y0, params=None, options: api.Opti
         if rc != 0:
             raise api.ConfigError(rc, contexts[0].last_error())
         g["t_log"], g["y_log"] = g["t_log"][:total_all], g["y_log"][:total_all]
-        log_info = {"passes": int(sl.passes), "records": total_all, "page_records": 1 << int(sl.page_shift), "pool_pages": int(sl.pool_pages),
-                    "pages_used": int(sl.pages_used)}
+        log_info = {"passes": int(sl.passes), "records": total_all, "page_slots": int(sl.page_slots), "pool_bytes": int(sl.pool_bytes),
+                    "pool_used_bytes": int(sl.pool_used_bytes)}
     if perm_t is not None:
         g = _unpermute_solution(g, permutation, B)
     return api.BatchSolution(y_end=g["y_end"], t_end=g["t_end"], status=g["status"], nfev=g["nfev"], nstep=g["nstep"],

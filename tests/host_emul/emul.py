@@ -41,7 +41,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("spec_cap", C.c_uint32), ("spec_min", C.c_uint32), ("ran_out", VP), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
         ("count_next", VP),
         ("window", C.c_uint32),
-        ("log_pool", VP), ("log_page_shift", C.c_uint32), ("log_pool_pages", C.c_uint32), ("log_pool_next", VP), ("log_cur", VP),
+        ("log_pool", VP), ("log_pool_doubles", C.c_uint64), ("log_pool_next", VP), ("log_cur", VP),
     ]
 
 
@@ -76,9 +76,10 @@ def lib(fast=False):
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
                 first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False,
                 event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None, flavour_log_only=True):
-    """``paged_log=(page_shift, pool_pages)``: the one-pass step log -- records go to page chains in a pool
-    (ivp_kargs.h); ``res['log_pool']``, ``res['log_cur']``, ``res['log_pages_used']`` and ``res['log_overflow']`` come
-    back next to ``n_log`` (``gather_pages`` below lays them out as the CSR log)."""
+    """``paged_log=pool_doubles``: the one-pass step log -- records go to wave pages in a pool of that many doubles, chained
+    per trajectory (ivp_kargs.h; on the host a "wave" is one lane, so every page has one column); ``res['log_pool']``,
+    ``res['log_cur']``, ``res['log_used']`` (doubles) and ``res['log_overflow']`` come back next to ``n_log``
+    (``gather_pages`` below lays them out as the CSR log)."""
     L = lib(fast)
     rid = RHS[rhs]
     n, npar = RHS_DIMS[rid]
@@ -144,12 +145,11 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
             res["eval_idx"] = np.full((max(ne, 1), B), -1, dtype=np.int32)
             a.y_eval, a.eval_idx = p(res["y_eval"]), p(res["eval_idx"])
         elif paged_log is not None:
-            shift, pool_pages = paged_log
-            page_doubles = 1 + ((n + 1) << shift)
-            res["log_pool"] = np.full((pool_pages + 2) * page_doubles, np.nan)   # two guard pages the bodies are not told about
-            res["log_cur"] = np.full(B, 0xFFFFFFFF, dtype=np.uint32)
-            res["log_next"] = np.zeros(1, dtype=np.uint32)
-            a.log_pool, a.log_page_shift, a.log_pool_pages = p(res["log_pool"]), shift, pool_pages
+            pool_doubles = int(paged_log)
+            res["log_pool"] = np.full(pool_doubles + 256, np.nan)   # 256 guard doubles the bodies are not told about
+            res["log_cur"] = np.full(B, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+            res["log_next"] = np.zeros(1, dtype=np.uint64)
+            a.log_pool, a.log_pool_doubles = p(res["log_pool"]), pool_doubles
             a.log_pool_next, a.log_cur = p(res["log_next"]), p(res["log_cur"])
             a.t_log = a.y_log = p(res["log_pool"])   # the "mode 2" marker, like the library sets it
         elif max_log > 0:
@@ -186,32 +186,41 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     assert rc == 0
     res["chunks"] = chunks.value
     if paged_log is not None:
-        res["log_pages_used"] = int(res["log_next"][0])
-        res["log_overflow"] = res["log_pages_used"] > paged_log[1]
+        res["log_used"] = int(res["log_next"][0])
+        res["log_overflow"] = res["log_used"] > int(paged_log)
     return res
 
 
-def gather_pages(res, n, shift):
-    """What log_gather.hip does, in numpy: walk every trajectory's page chain from its last page back to the first and lay
-    the records out as the CSR log.  Returns (offsets [B+1], t [total], y [total, n])."""
+LOG_SLOTS = 32
+NO_SEG = 0xFFFFFFFFFFFFFFFF
+
+
+def gather_pages(res, n):
+    """What log_gather.hip does, in numpy: walk every trajectory's segment chain from its last segment back to the first and
+    lay the records out as the CSR log.  Returns (offsets [B+1], t [total], y [total, n])."""
     cnt = res["n_log"].astype(np.int64)
     off = np.zeros(cnt.size + 1, dtype=np.int64)
     off[1:] = np.cumsum(cnt)
-    R = 1 << shift
-    pd = 1 + ((n + 1) << shift)
     pool = res["log_pool"]
     t = np.full(int(off[-1]), np.nan)
     y = np.full((int(off[-1]), n), np.nan)
+    filled = np.zeros(int(off[-1]), dtype=bool)
     for j in range(cnt.size):
-        pages = (int(cnt[j]) + R - 1) >> shift
-        page = int(res["log_cur"][j])
-        for pi in range(pages - 1, -1, -1):
-            assert page != 0xFFFFFFFF
-            base = page * pd
-            recs = int(cnt[j]) - pi * R if pi == pages - 1 else R
-            q0 = int(off[j]) + pi * R
-            t[q0:q0 + recs] = pool[base + 1:base + 1 + recs]
-            y[q0:q0 + recs] = pool[base + 1 + R:base + 1 + R + recs * n].reshape(recs, n)
-            page = int(pool[base:base + 1].view(np.uint32)[0])
-        assert pages == 0 or page == 0xFFFFFFFF, "the chain must end at the first page"
+        seg = int(res["log_cur"][j])
+        while seg != NO_SEG:
+            base, cols, col = seg >> 16, (seg >> 8) & 0xFF, seg & 0xFF
+            hdr = pool[base + 2 * col:base + 2 * col + 2]
+            prev = int(hdr[:1].view(np.uint64)[0])
+            k0, bits = (int(v) for v in hdr[1:2].view(np.uint32))
+            body = base + 2 * cols
+            r = 0
+            for s in range(LOG_SLOTS):
+                if (bits >> s) & 1:
+                    rec = pool[body + (s * cols + col) * (n + 1):body + (s * cols + col + 1) * (n + 1)]
+                    q = int(off[j]) + k0 + r
+                    assert q < off[j + 1] and not filled[q]
+                    t[q], y[q], filled[q] = rec[0], rec[1:], True
+                    r += 1
+            seg = prev
+    assert filled.all(), "every record of every trajectory must be in exactly one slot of its chain"
     return off, t, y
