@@ -379,12 +379,12 @@ __device__ __forceinline__ int32_t bdf_group_init_body(const IvpKArgs &a, uint32
     L.flags = 0;
     L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
     L.log_seg = IVP_NO_SEG; L.log_bits = 0; L.log_slot = 0; L.n_log = 0;
-    if (FULL && a.log_pool != nullptr) so_log_open<MAP>(a, L, 2u);   // the initial callback records at most twice
+    if (FULL && a.log_pool != nullptr) so_log_open<MAP>(a, j, L, 2u, 0u, 1u);   // the initial callback records at most twice
     auto store_so = [&]() {
         if (FULL) {
             a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
             a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
-            if (a.log_cur) { so_log_flush<MAP>(a, L); a.log_cur[j] = L.log_seg; }
+            if (a.log_pool != nullptr) so_log_flush<MAP>(a, L);
         }
     };
     a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; a.njev[j] = 0; a.nlu[j] = 0;
@@ -812,15 +812,14 @@ __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint
     if (FULL) {
         L.next_idx = a.next_idx[j]; L.n_filled = a.n_filled[j]; L.n_log = a.n_log[j];
         L.n_seg = a.n_seg[j]; L.t_last = a.t_last[j];
-        L.log_seg = a.log_cur ? a.log_cur[j] : IVP_NO_SEG;
     } else {
-        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_seg = IVP_NO_SEG;
+        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
     }
-    L.log_bits = 0; L.log_slot = 0;
+    L.log_seg = IVP_NO_SEG; L.log_bits = 0; L.log_slot = 0;
     uint32_t it = 0;
     bool run = true;
     while (run && it < a.chunk) {
-        if (FULL && a.log_pool != nullptr) so_log_attempt<MAP, 1>(a, L, it);
+        if (FULL && a.log_pool != nullptr) so_log_attempt<MAP, 1>(a, j, L, it);
         run = bdf_group_attempt<R, FULL, G>(a, j, S, L, jac, lu, piv);
         ++it;
     }
@@ -851,7 +850,6 @@ __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint
     if (FULL) {
         a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
-        if (a.log_cur) a.log_cur[j] = L.log_seg;
     }
     status_out = S.status;
     return it;

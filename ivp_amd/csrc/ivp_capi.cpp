@@ -492,12 +492,13 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
                       &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1, &c->st_logoff,
-                      &c->log_pool, &c->log_cur, &c->log_off, &c->log_bsum, &c->st_log_t, &c->st_log_y};
+                      &c->log_pool, &c->log_alloc, &c->log_off, &c->log_bsum, &c->st_log_t, &c->st_log_y};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->pend.round_done) (void)hipEventDestroy(c->pend.round_done);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->alloc_host) (void)hipHostFree(c->alloc_host);
     delete c;
 }
 
@@ -684,7 +685,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     HIP_TRY(ctx, ctx->flags.reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[0].reserve(sizeof(uint32_t) * B));
     HIP_TRY(ctx, ctx->perm[1].reserve(sizeof(uint32_t) * B));
-    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 8));  // [0..3] active-count ring, [4] error flags, [6..7] doubles handed out by the step-log pool (u64)
+    HIP_TRY(ctx, ctx->counts.reserve(sizeof(uint32_t) * 8));  // [0..3] active-count ring, [4] error flags
     a.k1 = (double *)ctx->k1.p;
     a.facold = (double *)ctx->facold.p;
     a.hlamb = (double *)ctx->hlamb.p;
@@ -755,16 +756,16 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
                     if (doubles > most) doubles = std::max<uint64_t>(most, ctx->log_pool.cap / 8);
                 }
             }
-            doubles = std::min<uint64_t>(std::max<uint64_t>(doubles, 4096), (uint64_t)1 << 46);
+            doubles = std::min<uint64_t>(std::max<uint64_t>(doubles, (uint64_t)1 << 16), (uint64_t)1 << 45);
             HIP_TRY(ctx, ctx->log_pool.reserve((size_t)doubles * 8));
-            HIP_TRY(ctx, ctx->log_cur.reserve(sizeof(unsigned long long) * B));
+            HIP_TRY(ctx, ctx->log_alloc.reserve(sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->log_alloc.p, 0, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, s));
             a.log_pool = (double *)ctx->log_pool.p;
-            a.log_pool_doubles = ctx->log_pool.cap / 8;
-            a.log_pool_next = (unsigned long long *)((uint32_t *)ctx->counts.p + 6);
-            a.log_cur = (unsigned long long *)ctx->log_cur.p;
+            a.log_region = (ctx->log_pool.cap / 8) / IVP_LOG_SUBPOOLS;   // (a region stays below 2^40 doubles: the counters' low field)
+            a.log_alloc = (unsigned long long *)ctx->log_alloc.p;
             a.t_log = a.log_pool;   // "mode 2" marker of the device DefaultSolOut (so_sample); the records go to the pages
             a.y_log = a.log_pool;
-            LS.B = B; LS.n = n; LS.pool_doubles = a.log_pool_doubles; LS.n_log = a.n_log;
+            LS.B = B; LS.n = n; LS.pool_doubles = a.log_region * IVP_LOG_SUBPOOLS; LS.region = a.log_region; LS.n_log = a.n_log;
         } else if (count_log) {
             // counting pass = a CSR log whose offsets are all zero: so_sample runs (t_log != NULL), every record finds
             // capacity 0 and only n_log advances

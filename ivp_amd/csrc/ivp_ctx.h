@@ -58,7 +58,7 @@ struct ivp_ctx {
     ivp_host::DevBuf st_logoff;   // this shard's CSR step-log offsets (host-pointer entry points)
     // ---- one-pass accepted-step log (ivp_log.cpp): the page pool the stepping kernels fill, the per-trajectory chain heads,
     // the offsets / block sums of the scan, staging for the records of the host-pointer and multi-device forms ----
-    ivp_host::DevBuf log_pool, log_cur, log_off, log_bsum, st_log_t, st_log_y;
+    ivp_host::DevBuf log_pool, log_alloc, log_off, log_bsum, st_log_t, st_log_y;
     struct LogPlan {
         bool want = false;          // the next ivp_batch_submit_device on this context records into the page pool
         uint64_t reserve = 0;       // caller's estimate of the total number of records (0 = automatic)
@@ -69,13 +69,16 @@ struct ivp_ctx {
         size_t B = 0;
         int n = 0;
         uint64_t pool_doubles = 0;  // capacity of the pool during that solve
+        uint64_t region = 0;        // ... per sub-pool
         uint64_t pool_used = 0;     // doubles its pages took
+        uint32_t max_arenas = 0;    // largest directory count among the sub-pools (grid of the gather)
         uint64_t total = 0;         // records of the last logged solve (sizes the next pool)
         size_t last_B = 0;          // batch size `total` belongs to
         const uint32_t *n_log = nullptr;   // device: the counts of the last logged solve (the caller's out->n_log, or scratch):
                                            // must stay untouched until the records have been fetched
     } log_state;
     uint32_t *pinned = nullptr;  // host-pinned: active count + misc
+    unsigned long long *alloc_host = nullptr;   // host-pinned copy of the step-log sub-pool counters
     std::vector<hipEvent_t> events;
     ivp_run_stats_t stats{};
     // ---- the solve in flight (ivp_batch_submit_device .. ivp_batch_poll / ivp_batch_wait) ----

@@ -136,22 +136,26 @@ struct IvpKArgs {
     // ---- one-pass accepted-step log (so_push_log): records go to WAVE PAGES drawn from a device pool ----
     // The reference pushes every accepted step into growing Vecs (solout.rs:387-428); a GPU lane cannot grow a Vec, and a
     // counting solve before the filling solve costs a whole second integration.  With log_pool != NULL the stepping kernels
-    // record as they go.  Every IVP_LOG_SLOTS record slots (32 attempts of a log-only kernel, 16 of a full one, whose attempts
-    // may record twice) a WAVE bump-allocates one page for all its trajectories (one atomicAdd):
+    // record as they go.  A page belongs to ONE WAVE and covers IVP_LOG_SLOTS record slots of every trajectory the wave is
+    // stepping (32 attempts of a log-only kernel, 16 of a full one, whose attempts may record twice):
     //     [cols x header (2 doubles)] [slot 0: cols records] [slot 1: cols records] ...      record = [t, y_0 .. y_{n-1}]
-    // cols = trajectories the wave is stepping, column = a trajectory's rank among them, slot = attempt index within the page
-    // (wave-uniform), so the records of one attempt are ONE contiguous run of cols x (n + 1) doubles: the wave's stores fill
-    // whole cache lines back to back (lanes that rejected leave holes).  Per-trajectory pages would touch one partly written
-    // line per trajectory and attempt -- 1M trajectories x 2 lines do not fit any cache: every 8-byte store became a partial
-    // HBM write (measured: BASELINE C3 28.9 ms with per-trajectory pages, end state 12.7).
-    // A column header is {prev: the trajectory's previous segment, k0: its record count when the page was opened, bits: which
-    // slots hold a record}; log_cur[j] names trajectory j's last segment: a chain per trajectory, any length.  A segment is
-    // (page offset in doubles) << 16 | cols << 8 | column.  Once every count is known a gather kernel (log_gather.hip) walks
-    // the chains and lays the records out as the CSR log (t_log [total], y_log [total][n]).
+    // cols = trajectories the wave is stepping when it opens the page, column = a trajectory's rank among them, slot = attempt
+    // index within the page (wave-uniform), so the records of one attempt are ONE contiguous run of cols x (n + 1) doubles:
+    // the wave's stores fill whole cache lines back to back (lanes that rejected leave holes).  (Per-trajectory pages touch one
+    // partly written line per trajectory and attempt; 1M trajectories x 2 lines fit no cache and every 8-byte store became a
+    // partial HBM write -- measured on BASELINE C3: 28.9 ms against 12.7 for the end state.)
+    // A column header is {j: the trajectory, k0: its record count when the page was opened, bits: which slots hold a record},
+    // so a page describes itself: the gather kernel (log_gather.hip) takes one page per workgroup, reads it front to back
+    // (coalesced) and writes record (j, k0 + rank of the slot) to its place in the CSR log -- no per-trajectory chains.
+    // Allocation: the pool is cut into IVP_LOG_SUBPOOLS equal regions, each with its own 64-bit counter
+    // (pages << 40 | doubles): pages grow up from the start of a region, their directory entries (page offset << 8 | cols, one
+    // per page, what the gather enumerates) grow down from its end.  A wave draws up to four pages at a time (one atomicAdd
+    // on the counter blockIdx picks: 1563 waves that start a launch together do not queue on one address).
     double *log_pool;                    // NULL = the dense / two-pass CSR forms above
-    unsigned long long log_pool_doubles; // capacity; beyond it records are counted but not stored (IVP_ERRFLAG_LOG_OVERFLOW)
-    unsigned long long *log_pool_next;   // device counter: doubles handed out so far
-    unsigned long long *log_cur;         // [B] last segment of every trajectory (IVP_NO_SEG: none)
+    unsigned long long log_region;       // doubles per sub-pool region
+    unsigned long long *log_alloc;       // [IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE] counters (one per 128-byte line)
 };
 #define IVP_LOG_SLOTS 32u
+#define IVP_LOG_SUBPOOLS 64u
+#define IVP_LOG_ALLOC_STRIDE 16u
 #define IVP_NO_SEG 0xFFFFFFFFFFFFFFFFull

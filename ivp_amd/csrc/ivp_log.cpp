@@ -30,15 +30,22 @@ int scan_counts(ivp_ctx *ctx, unsigned long long *offsets_dev, hipStream_t s, ui
     HIP_TRY(ctx, ctx->log_bsum.reserve(ivp_log_scan_scratch_bytes(LS.B)));
     HIP_TRY(ctx, ivp_log_scan(LS.n_log, LS.B, offsets_dev, ctx->log_bsum.p, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 8, offsets_dev + LS.B, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 10, (const uint32_t *)ctx->counts.p + 6, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (!ctx->alloc_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->alloc_host, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, hipHostMallocDefault));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->alloc_host, ctx->log_alloc.p, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     unsigned long long t;
     std::memcpy(&t, ctx->pinned + 8, sizeof t);
     *total = t;
     LS.total = t;
     LS.last_B = LS.B;
-    std::memcpy(&t, ctx->pinned + 10, sizeof t);
-    LS.pool_used = t;   // doubles the wave pages took (may exceed the capacity after an overflow: the counter keeps counting)
+    // the sub-pools' counters (arenas << 40 | doubles): what the pages took, and the grid of the gather
+    LS.pool_used = 0;
+    LS.max_arenas = 0;
+    for (uint32_t q = 0; q < IVP_LOG_SUBPOOLS; ++q) {
+        const unsigned long long c = ctx->alloc_host[(size_t)q * IVP_LOG_ALLOC_STRIDE];
+        LS.pool_used += (c & ((1ull << 40) - 1ull)) + (c >> 40);
+        LS.max_arenas = std::max<uint32_t>(LS.max_arenas, (uint32_t)std::min<unsigned long long>(c >> 40, 0x3FFFFFFFull));
+    }
     return IVP_OK;
 }
 
@@ -76,7 +83,7 @@ int device_destination(ivp_ctx *ctx, ivp_step_log_t *log, uint64_t total, int n,
 int gather_pool(ivp_ctx *ctx, const unsigned long long *offsets_dev, uint64_t capacity, uint64_t dst_base, double *t, double *y, hipStream_t s)
 {
     const ivp_ctx::LogState &LS = ctx->log_state;
-    HIP_TRY(ctx, ivp_log_gather((const double *)ctx->log_pool.p, (const unsigned long long *)ctx->log_cur.p, LS.n_log, offsets_dev, LS.B, LS.n,
+    HIP_TRY(ctx, ivp_log_gather((const double *)ctx->log_pool.p, LS.region, (const unsigned long long *)ctx->log_alloc.p, LS.max_arenas, offsets_dev, LS.B, LS.n,
                                 capacity, dst_base, t, y, s));
     return IVP_OK;
 }

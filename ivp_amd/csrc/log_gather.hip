@@ -1,16 +1,15 @@
 // log_gather.hip -- second half of the one-pass accepted-step log (gfx950): wave pages -> CSR.
 //
-// The stepping kernels leave every trajectory's records in a chain of segments (a segment = one column of a wave page: up to
-// 32 record slots, a bit per slot that holds a record; layout in ivp_kargs.h, writers so_log_open / so_push_log in rk_core.h)
-// and its record count in n_log.  Here:
+// The stepping kernels leave the records in self-describing wave pages (layout in ivp_kargs.h, writers so_log_open /
+// so_push_log in rk_core.h) and every trajectory's record count in n_log.  Here:
 //   ivp_log_scan    offsets[b] = sum of n_log[0 .. b), offsets[B] = total          (three small launches)
-//   ivp_log_gather  a group of lanes per trajectory walks its chain from the last segment back to the first; a segment's
-//                   k-th record (k = rank of its slot among the set bits) goes to t_log[offsets[b] + k0 + k],
-//                   y_log[(offsets[b] + k0 + k) * n + c]  (time-major like the reference's Solution.t / Solution.y,
-//                   src/solve/solout.rs:387-428, src/solve/solve_ivp.rs:288-312).  Lane <-> double of the segment: the
-//                   n + 1 doubles of a record are read by adjacent lanes, the y part of consecutive records is written to
-//                   consecutive addresses.
-// Both are pure data movement: HBM-bound, ~2 x 8 (n + 1) bytes per record.
+//   ivp_log_gather  one workgroup per page: the column headers (trajectory j, first record index k0, slot bits) go to LDS,
+//                   then the page is read front to back -- consecutive lanes read consecutive doubles -- and the record in
+//                   slot s of column c goes to t_log[q], y_log[q * n + ..] with q = offsets[j] + k0 + (rank of s among the
+//                   column's set bits): time-major like the reference's Solution.t / Solution.y (src/solve/solout.rs:387-428,
+//                   src/solve/solve_ivp.rs:288-312).  A column's records land on consecutive addresses slot after slot, so
+//                   the scattered 8 (n + 1)-byte writes complete their cache lines while those are still in L2.
+// Both are pure data movement: HBM-bound, ~2 x 8 (n + 1) bytes per record (+ the holes rejected attempts leave in a page).
 #include <hip/hip_runtime.h>
 
 #include "ivp_kargs.h"
@@ -95,57 +94,54 @@ __global__ __launch_bounds__(kScanThreads) void log_scan_apply(const uint32_t *n
     }
 }
 
-// G lanes per trajectory (64 / G trajectories per wavefront), NP1 = n + 1 as a compile-time constant where it is small
-// (0 = run-time).  `capacity` = records the destination holds: a log that does not fit is left alone (the host reports it;
-// nothing is written out of bounds).
-template <int G, int NP1>
-__global__ __launch_bounds__(IVP_WAVE) void log_gather_kernel(const double *pool, const unsigned long long *log_cur, const uint32_t *n_log,
-                                                              const unsigned long long *offsets, uint32_t B, uint32_t n_rt,
-                                                              unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log)
+// One workgroup (4 wavefronts) per page: blockIdx.y = sub-pool, blockIdx.x = 4 * (arena's directory index) + page of the
+// arena.  NP1 = n + 1 as a compile-time constant where it is small (0 = run-time).  `capacity` = records the destination
+// holds: a log that does not fit is left alone (the host reports it; nothing is written out of bounds).
+constexpr int kGatherThreads = 256;
+template <int NP1>
+__global__ __launch_bounds__(kGatherThreads) void log_gather_kernel(const double *pool, unsigned long long region, const unsigned long long *alloc,
+                                                                    const unsigned long long *offsets, uint32_t B, uint32_t n_rt,
+                                                                    unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log)
 {
     const uint32_t np1 = NP1 ? (uint32_t)NP1 : n_rt + 1u, n = np1 - 1u;
-    const uint32_t gl = threadIdx.x & (G - 1);
-    const uint32_t j = blockIdx.x * (IVP_WAVE / G) + threadIdx.x / G;
-    if (j >= B || offsets[B] > capacity) return;
-    if (n_log[j] == 0u) return;
-    const unsigned long long off = offsets[j] + dst_base;
-    unsigned long long seg = log_cur[j];
-    const uint32_t elems = IVP_LOG_SLOTS * np1;
-    while (seg != IVP_NO_SEG) {
-        const size_t base = (size_t)(seg >> 16), cols = (size_t)((seg >> 8) & 0xFFu), col = (size_t)(seg & 0xFFu);
-        const double *hdr = pool + base + 2u * col;
-        const unsigned long long prev = *(const unsigned long long *)hdr;
-        const uint32_t k0 = ((const uint32_t *)hdr)[2], bits = ((const uint32_t *)hdr)[3];
-        const double *body = pool + base + 2u * cols + col * np1;
-        const size_t slot_stride = cols * np1;
-        const unsigned long long q0 = off + k0;
-        if (bits != 0u) {
-            for (uint32_t e = gl; e < elems; e += G) {
-                const uint32_t s = e / np1, c = e - s * np1;
-                if ((bits >> s) & 1u) {
-                    const unsigned long long q = q0 + (unsigned long long)__popc(bits & ((1u << s) - 1u));
-                    const double v = body[(size_t)s * slot_stride + c];
-                    if (c == 0u) t_log[q] = v;
-                    else y_log[q * n + (c - 1u)] = v;
-                }
+    const uint32_t sub = blockIdx.y, e = blockIdx.x >> 2, p = blockIdx.x & 3u;
+    if ((unsigned long long)e >= (alloc[(size_t)sub * IVP_LOG_ALLOC_STRIDE] >> 40) || offsets[B] > capacity) return;
+    const unsigned long long entry = ((const unsigned long long *)pool)[(size_t)(sub + 1u) * region - 1u - e];
+    if (p > (uint32_t)(entry & 3u)) return;
+    const size_t acols = (size_t)((entry >> 2) & 0x3Fu) + 1u;
+    const size_t page = (size_t)(entry >> 8) + (size_t)p * (1u + acols * (2u + (size_t)IVP_LOG_SLOTS * np1));
+    const uint32_t cols = *(const uint32_t *)(pool + page);
+    if (cols == 0u) return;   // a page of the arena its wave never opened
+    __shared__ uint32_t s_bits[IVP_WAVE];
+    __shared__ unsigned long long s_q0[IVP_WAVE];
+    __shared__ uint32_t s_used;
+    if (threadIdx.x == 0) s_used = 0u;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        const uint32_t *hdr = (const uint32_t *)(pool + page + 1u + 2u * (size_t)threadIdx.x);
+        const uint32_t bits = hdr[2];
+        s_bits[threadIdx.x] = bits;
+        s_q0[threadIdx.x] = offsets[hdr[0]] + hdr[1] + dst_base;
+        if (bits) atomicOr(&s_used, bits);
+    }
+    __syncthreads();
+    const uint32_t used = s_used;
+    const double *body = pool + page + 1u + 2u * (size_t)cols;
+    const uint32_t row = cols * np1, tx = threadIdx.x & (IVP_WAVE - 1), ty = threadIdx.x / IVP_WAVE;
+    for (uint32_t sl = ty; sl < IVP_LOG_SLOTS; sl += kGatherThreads / IVP_WAVE) {
+        if (!((used >> sl) & 1u)) continue;   // an attempt nobody accepted
+        const double *src = body + (size_t)sl * row;
+        for (uint32_t x = tx; x < row; x += IVP_WAVE) {
+            const uint32_t col = x / np1, c = x - col * np1;
+            const uint32_t bits = s_bits[col];
+            if ((bits >> sl) & 1u) {
+                const unsigned long long q = s_q0[col] + (unsigned long long)__popc(bits & ((1u << sl) - 1u));
+                const double v = src[x];
+                if (c == 0u) t_log[q] = v;
+                else y_log[q * n + (c - 1u)] = v;
             }
         }
-        seg = prev;
     }
-}
-
-template <int G>
-hipError_t launch_gather(const double *pool, const unsigned long long *log_cur, const uint32_t *n_log, const unsigned long long *offsets, size_t B, int n,
-                         unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log, hipStream_t s)
-{
-    const dim3 grid((uint32_t)((B + (IVP_WAVE / G) - 1) / (IVP_WAVE / G))), block(IVP_WAVE);
-#define IVP_GATHER_CASE(NP1) case NP1: hipLaunchKernelGGL((log_gather_kernel<G, NP1>), grid, block, 0, s, pool, log_cur, n_log, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
-    switch (n + 1) {
-        IVP_GATHER_CASE(2) IVP_GATHER_CASE(3) IVP_GATHER_CASE(4) IVP_GATHER_CASE(5) IVP_GATHER_CASE(6) IVP_GATHER_CASE(7) IVP_GATHER_CASE(8) IVP_GATHER_CASE(9)
-    default: hipLaunchKernelGGL((log_gather_kernel<G, 0>), grid, block, 0, s, pool, log_cur, n_log, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
-    }
-#undef IVP_GATHER_CASE
-    return hipGetLastError();
 }
 
 }  // namespace
@@ -164,16 +160,18 @@ hipError_t ivp_log_scan(const uint32_t *n_log, size_t B, unsigned long long *off
     return hipGetLastError();
 }
 
-hipError_t ivp_log_gather(const double *pool, const unsigned long long *log_cur, const uint32_t *n_log, const unsigned long long *offsets, size_t B,
-                          int n, unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log, hipStream_t s)
+hipError_t ivp_log_gather(const double *pool, unsigned long long region, const unsigned long long *alloc, uint32_t max_arenas,
+                          const unsigned long long *offsets, size_t B, int n, unsigned long long capacity, unsigned long long dst_base,
+                          double *t_log, double *y_log, hipStream_t s)
 {
-    if (B == 0) return hipSuccess;
+    if (B == 0 || max_arenas == 0) return hipSuccess;
     (void)hipGetLastError();
-    // a segment is 32 x (n + 1) doubles: as many lanes per trajectory as keep ~3 doubles per lane and segment in flight, and as
-    // many trajectories per wavefront as that leaves room for (the chain walk is a dependent load per segment: more
-    // independent chains per wave hide it)
-    const int elems = (int)IVP_LOG_SLOTS * (n + 1);
-    if (elems >= 192) return launch_gather<64>(pool, log_cur, n_log, offsets, B, n, capacity, dst_base, t_log, y_log, s);
-    if (elems >= 96) return launch_gather<32>(pool, log_cur, n_log, offsets, B, n, capacity, dst_base, t_log, y_log, s);
-    return launch_gather<16>(pool, log_cur, n_log, offsets, B, n, capacity, dst_base, t_log, y_log, s);
+    const dim3 grid(4u * max_arenas, IVP_LOG_SUBPOOLS), block(kGatherThreads);
+#define IVP_GATHER_CASE(NP1) case NP1: hipLaunchKernelGGL((log_gather_kernel<NP1>), grid, block, 0, s, pool, region, alloc, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
+    switch (n + 1) {
+        IVP_GATHER_CASE(2) IVP_GATHER_CASE(3) IVP_GATHER_CASE(4) IVP_GATHER_CASE(5) IVP_GATHER_CASE(6) IVP_GATHER_CASE(7) IVP_GATHER_CASE(8) IVP_GATHER_CASE(9)
+    default: hipLaunchKernelGGL((log_gather_kernel<0>), grid, block, 0, s, pool, region, alloc, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
+    }
+#undef IVP_GATHER_CASE
+    return hipGetLastError();
 }

@@ -571,8 +571,9 @@ struct Lane {
     int32_t next_idx, n_filled;
     uint32_t n_log, n_seg;
     double t_last;
-    // one-pass step log (IvpKArgs.log_pool): the trajectory's current segment (wave page + column), the slots of it that
-    // hold a record, the slot the next record of this attempt goes to
+    // one-pass step log (IvpKArgs.log_pool): the trajectory's column in the wave's current page
+    // (page offset << 18 | (arena cols - 1) << 12 | (cols - 1) << 6 | column), the slots of it that hold a record, the slot
+    // the next record of this attempt goes to
     uint64_t log_seg;
     uint32_t log_bits, log_slot;
 };
@@ -615,11 +616,10 @@ IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool r
         L.n_log = a.n_log[j];
         L.n_seg = a.n_seg[j];
         L.t_last = a.t_last[j];
-        L.log_seg = a.log_cur ? a.log_cur[j] : IVP_NO_SEG;
     } else {
-        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0; L.log_seg = IVP_NO_SEG;
+        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
     }
-    L.log_bits = 0; L.log_slot = 0;
+    L.log_seg = IVP_NO_SEG; L.log_bits = 0; L.log_slot = 0;
 }
 
 template <class R>
@@ -646,7 +646,6 @@ IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L,
         a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg;
         a.t_last[j] = L.t_last;
-        if (a.log_cur) a.log_cur[j] = L.log_seg;
     }
 }
 
@@ -799,49 +798,79 @@ IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t t
     L.n_filled += 1;
 }
 // ---- one-pass step log: wave pages (layout and rationale: ivp_kargs.h) ----
-// so_log_flush: the slots of the current segment that hold a record go to its column header.
+// a lane's "segment": page offset (doubles) << 18 | (arena cols - 1) << 12 | (cols - 1) << 6 | column
+#define IVP_SEG_BASE(seg) ((size_t)((seg) >> 18))
+#define IVP_SEG_ACOLS(seg) ((size_t)(((seg) >> 12) & 0x3Fu) + 1u)
+#define IVP_SEG_COLS(seg) ((size_t)(((seg) >> 6) & 0x3Fu) + 1u)
+#define IVP_SEG_COL(seg) ((size_t)((seg) & 0x3Fu))
+// so_log_flush: the slots of the current page column that hold a record go to its header (a column nobody recorded into
+// keeps the 0 it was opened with).
 template <class MAP, int N, int P>
 IVP_HD void so_log_flush(const IvpKArgs &a, const Lane<N, P> &L)
 {
-    // (log_bits == 0: nothing recorded into it by this launch -- either a fresh segment, whose header says 0 already, or the
-    // segment an earlier launch closed, whose header must not be touched)
     if (L.log_seg != IVP_NO_SEG && L.log_bits != 0u && MAP::leader())
-        ((uint32_t *)(a.log_pool + (size_t)(L.log_seg >> 16) + 2u * (size_t)(L.log_seg & 0xFFu)))[3] = L.log_bits;
+        ((uint32_t *)(a.log_pool + IVP_SEG_BASE(L.log_seg) + 1u + 2u * IVP_SEG_COL(L.log_seg)))[2] = L.log_bits;
 }
 // so_log_open: every trajectory the wave is stepping gets a column of ONE fresh page of `slots` record slots.  Called at a
-// point all of them reach together (top of the attempt loop, top of the init body); the lanes present share one atomicAdd
-// (ballot -> popcount -> the first of them adds -> rank among the set bits = the column).  Lanes that hold a trajectory
-// together (rk_coop.h, rk_group.h) act through their leader.  Pool exhausted: IVP_NO_SEG -- the records are still counted
+// point all of them reach together (top of the attempt loop, top of the init body) with the same `page_no` (the page's number
+// within this launch) and `arena` (pages drawn per allocation: 1, 2 or 4).  The lanes present form the columns (ballot ->
+// popcount = cols, rank among the set bits = column).  Every `arena`-th page the first of them draws the next arena with ONE
+// atomicAdd on its sub-pool's counter, writes the arena's directory entry and marks its pages "not opened"; the pages in
+// between follow at the arena's page stride (and may be narrower: trajectories retire).  Lanes that hold a trajectory
+// together (rk_coop.h, rk_group.h) act through their leader.  Region exhausted: IVP_NO_SEG -- the records are still counted
 // (n_log), the host sees IVP_ERRFLAG_LOG_OVERFLOW and falls back to the counted two-pass log.
 template <class MAP, int N, int P>
-IVP_HD void so_log_open(const IvpKArgs &a, Lane<N, P> &L, uint32_t slots)
+IVP_HD void so_log_open(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, uint32_t slots, uint32_t page_no, uint32_t arena)
 {
     so_log_flush<MAP>(a, L);
     uint64_t seg = IVP_NO_SEG;
     if (MAP::leader()) {
+        const unsigned long long per_col = 2u + (unsigned long long)slots * (MAP::NT + 1);
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned long long m = __ballot(true);
         const uint32_t lane = __lane_id();
-        const int first = __ffsll((long long)m) - 1;
+        const uint32_t first = (uint32_t)(__ffsll((long long)m) - 1);
         const uint32_t cols = (uint32_t)__popcll(m), col = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        const unsigned long long page_doubles = (unsigned long long)cols * (2u + (unsigned long long)slots * (MAP::NT + 1));
-        unsigned long long base = 0;
-        if ((int)lane == first) base = atomicAdd(a.log_pool_next, page_doubles);
-        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), first) << 32) | (uint32_t)__shfl((int)(uint32_t)base, first);
+        const uint32_t sub = blockIdx.x & (IVP_LOG_SUBPOOLS - 1u);
 #else
-        const uint32_t cols = 1, col = 0;
-        const unsigned long long page_doubles = 2u + (unsigned long long)slots * (MAP::NT + 1);
-        const unsigned long long base = *a.log_pool_next;
-        *a.log_pool_next += page_doubles;
+        const uint32_t cols = 1, col = 0, lane = 0, first = 0, sub = j & (IVP_LOG_SUBPOOLS - 1u);
 #endif
-        if (base + page_doubles > a.log_pool_doubles) {
+        const uint32_t p_local = page_no & (arena - 1u);
+        unsigned long long base = 0;
+        uint32_t acols = cols;
+        bool ok;
+        if (p_local == 0u) {   // a new arena: `arena` pages of the width the wave has now
+            const unsigned long long stride = 1u + (unsigned long long)cols * per_col, need = (unsigned long long)arena * stride;
+            unsigned long long old = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (lane == first) old = atomicAdd(a.log_alloc + (size_t)sub * IVP_LOG_ALLOC_STRIDE, (1ull << 40) | need);
+            old = ((unsigned long long)(uint32_t)__shfl((int)(old >> 32), (int)first) << 32) | (uint32_t)__shfl((int)(uint32_t)old, (int)first);
+#else
+            old = a.log_alloc[(size_t)sub * IVP_LOG_ALLOC_STRIDE];
+            a.log_alloc[(size_t)sub * IVP_LOG_ALLOC_STRIDE] = old + ((1ull << 40) | need);
+#endif
+            const unsigned long long used = old & ((1ull << 40) - 1ull), dir_idx = old >> 40;
+            ok = used + need + dir_idx + 1u <= a.log_region;   // pages grow up from the region's start, the directory down from its end
+            base = (unsigned long long)sub * a.log_region + used;
+            if (ok && lane == first) {
+                ((unsigned long long *)a.log_pool)[(size_t)(sub + 1u) * a.log_region - 1u - (size_t)dir_idx] =
+                    (base << 8) | ((unsigned long long)(cols - 1u) << 2) | (unsigned long long)(arena - 1u);
+                for (uint32_t q = 1; q < arena; ++q) *(uint32_t *)(a.log_pool + (size_t)(base + q * stride)) = 0u;   // "not opened"
+            }
+        } else {               // the next page of the arena this lane's current page belongs to
+            ok = L.log_seg != IVP_NO_SEG;
+            acols = (uint32_t)IVP_SEG_ACOLS(L.log_seg);
+            base = IVP_SEG_BASE(L.log_seg) + 1u + (unsigned long long)acols * per_col;
+        }
+        if (!ok) {
             ivp_flag_error(a, IVP_ERRFLAG_LOG_OVERFLOW);
         } else {
-            seg = ((uint64_t)base << 16) | ((uint64_t)cols << 8) | (uint64_t)col;
-            double *hdr = a.log_pool + (size_t)base + 2u * (size_t)col;
-            *(uint64_t *)hdr = L.log_seg;              // the trajectory's previous segment
-            ((uint32_t *)hdr)[2] = L.n_log;            // its record count so far: where this segment's records go
-            ((uint32_t *)hdr)[3] = 0u;
+            seg = ((uint64_t)base << 18) | ((uint64_t)(acols - 1u) << 12) | ((uint64_t)(cols - 1u) << 6) | (uint64_t)col;
+            if (lane == first) *(uint32_t *)(a.log_pool + (size_t)base) = cols;   // page header: opened, this many columns
+            uint32_t *hdr = (uint32_t *)(a.log_pool + (size_t)base + 1u + 2u * (size_t)col);
+            hdr[0] = j;            // the trajectory,
+            hdr[1] = L.n_log;      // its record count so far: where this column's records go in its log,
+            hdr[2] = 0u;           // the slots that hold a record (so_log_flush)
         }
     }
     L.log_seg = map_bcast64<MAP>(seg);
@@ -852,11 +881,19 @@ IVP_HD void so_log_open(const IvpKArgs &a, Lane<N, P> &L, uint32_t slots)
 // so_log_accepted) and at most twice in the full one (first_step enforcement, solout.rs:392-421), so a page of
 // IVP_LOG_SLOTS slots lasts 32 / 16 attempts.
 template <class MAP, int FULL, int N, int P>
-IVP_HD void so_log_attempt(const IvpKArgs &a, Lane<N, P> &L, uint32_t it)
+IVP_HD void so_log_attempt(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, uint32_t it)
 {
     constexpr uint32_t kPerAttempt = FULL == 2 ? 1u : 2u, kAttempts = IVP_LOG_SLOTS / kPerAttempt;
     const uint32_t q = it & (kAttempts - 1u);
-    if (q == 0u) so_log_open<MAP>(a, L, IVP_LOG_SLOTS);
+    if (q == 0u) {
+        // pages per allocation: what this launch can use (a.chunk attempts), at most four (a wave that retires early leaves
+        // the rest of its arena unopened)
+        const uint32_t want = (a.chunk + kAttempts - 1u) / kAttempts;
+        // (a launch shorter than a page -- chunk_attempts < 32 -- opens pages of just the slots it can use; arenas of more than
+        // one page exist only for launches of more than a page, whose pages all have IVP_LOG_SLOTS slots: the gather relies on it)
+        const uint32_t slots = want >= 2u ? IVP_LOG_SLOTS : (a.chunk * kPerAttempt < IVP_LOG_SLOTS ? a.chunk * kPerAttempt : IVP_LOG_SLOTS);
+        so_log_open<MAP>(a, j, L, slots, it / kAttempts, want >= 4u ? 4u : (want >= 2u ? 2u : 1u));
+    }
     L.log_slot = q * kPerAttempt;
 }
 template <int M, int N, int P, class MAP = IdMap<N>>
@@ -867,8 +904,8 @@ IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, 
         // one-pass log: the record goes to this attempt's slot of the trajectory's column in the wave's current page
         // (ivp_kargs.h) -- next to the records the other trajectories of the wave write in this attempt
         if (L.log_seg != IVP_NO_SEG) {
-            const size_t cols = (size_t)((L.log_seg >> 8) & 0xFFu), col = (size_t)(L.log_seg & 0xFFu);
-            double *rec = a.log_pool + (size_t)(L.log_seg >> 16) + 2u * cols + ((size_t)L.log_slot * cols + col) * (MAP::NT + 1);
+            const size_t cols = IVP_SEG_COLS(L.log_seg), col = IVP_SEG_COL(L.log_seg);
+            double *rec = a.log_pool + IVP_SEG_BASE(L.log_seg) + 1u + 2u * cols + ((size_t)L.log_slot * cols + col) * (MAP::NT + 1);
             if (MAP::leader()) rec[0] = t;
 #pragma unroll
             for (int c = 0; c < N; ++c) if (MAP::own(c)) rec[1 + MAP::gi(c)] = yv[c];
@@ -1220,7 +1257,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     L.hlamb = 0.0;
     L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
     L.log_seg = IVP_NO_SEG; L.log_bits = 0; L.log_slot = 0;
-    if (FULL && a.log_pool != nullptr) so_log_open<MAP>(a, L, 2u);   // the initial callback records at most twice
+    if (FULL && a.log_pool != nullptr) so_log_open<MAP>(a, j, L, 2u, 0u, 1u);   // the initial callback records at most twice
     uint64_t nfev = 0;
 
     if (fabs(L.xend - L.x0) < 1e-15) {  // solve_ivp.rs:110-145
@@ -1245,7 +1282,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
             }
             a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
             a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
-            if (a.log_cur) { so_log_flush<MAP>(a, L); a.log_cur[j] = L.log_seg; }
+            if (a.log_pool != nullptr) so_log_flush<MAP>(a, L);
         }
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 0;
@@ -1261,7 +1298,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
         a.x[j] = L.x0; a.h[j] = 0.0; a.facold[j] = L.facold; a.hlamb[j] = 0.0; a.flags[j] = 0;
         a.status[j] = 3;
         a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
-        if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = L.log_seg; }
+        if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
         return 3;
     }
     L.posneg = rs_signum(L.xend - L.x0);
@@ -1282,7 +1319,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
             a.x[j] = L.x0; a.h[j] = L.h; a.facold[j] = 0.0; a.hlamb[j] = 0.0; a.flags[j] = 0;
             a.status[j] = 0;
             a.nfev[j] = 0; a.nstep[j] = 0; a.naccpt[j] = 0; a.nrejct[j] = 0; so_zero_implicit_counters(a, j);
-            if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; if (a.log_cur) a.log_cur[j] = L.log_seg; }
+            if (FULL) { a.next_idx[j] = 0; a.n_filled[j] = 0; a.n_log[j] = 0; a.n_seg[j] = 0; a.t_last[j] = 0.0; }
             return 0;
         }
     } else if (a.has_first_step) {
@@ -1303,7 +1340,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     if (FULL) {
         a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_log[j] = L.n_log;
         a.n_seg[j] = L.n_seg; a.t_last[j] = L.t_last;
-        if (a.log_cur) { so_log_flush<MAP>(a, L); a.log_cur[j] = L.log_seg; }
+        if (a.log_pool != nullptr) so_log_flush<MAP>(a, L);
     }
     return IVP_RUNNING;
 }
@@ -1934,7 +1971,7 @@ IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
     uint32_t it = 0;
     bool run = true;
     while (run && it < a.chunk) {
-        if (FULL && a.log_pool != nullptr) so_log_attempt<typename OutMap<R>::type, FULL>(a, L, it);
+        if (FULL && a.log_pool != nullptr) so_log_attempt<typename OutMap<R>::type, FULL>(a, j, L, it);
         if constexpr (M == M_DOPRI5) run = dopri5_attempt<R, FULL, CTL>(a, j, L);
         else if constexpr (M == M_DOP853) run = dop853_attempt<R, FULL, CTL>(a, j, L);
         else if constexpr (M == M_RK4) run = rk4_attempt<R, FULL>(a, j, L);

@@ -41,9 +41,13 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("spec_cap", C.c_uint32), ("spec_min", C.c_uint32), ("ran_out", VP), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
         ("count_next", VP),
         ("window", C.c_uint32),
-        ("log_pool", VP), ("log_pool_doubles", C.c_uint64), ("log_pool_next", VP), ("log_cur", VP),
+        ("log_pool", VP), ("log_region", C.c_uint64), ("log_alloc", VP),
     ]
 
+
+LOG_SLOTS = 32
+LOG_SUBPOOLS = 64
+LOG_ALLOC_STRIDE = 16
 
 _libs = {}
 RHS = {"decay": 0, "sho": 1, "vdp": 2, "cr3bp": 3, "lorenz": 4, "zero": 5, "rational": 6, "exp2": 7,
@@ -145,12 +149,11 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
             res["eval_idx"] = np.full((max(ne, 1), B), -1, dtype=np.int32)
             a.y_eval, a.eval_idx = p(res["y_eval"]), p(res["eval_idx"])
         elif paged_log is not None:
-            pool_doubles = int(paged_log)
-            res["log_pool"] = np.full(pool_doubles + 256, np.nan)   # 256 guard doubles the bodies are not told about
-            res["log_cur"] = np.full(B, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
-            res["log_next"] = np.zeros(1, dtype=np.uint64)
-            a.log_pool, a.log_pool_doubles = p(res["log_pool"]), pool_doubles
-            a.log_pool_next, a.log_cur = p(res["log_next"]), p(res["log_cur"])
+            region = int(paged_log) // LOG_SUBPOOLS
+            res["log_region"] = region
+            res["log_pool"] = np.full(region * LOG_SUBPOOLS + 256, np.nan)   # 256 guard doubles the bodies are not told about
+            res["log_alloc"] = np.zeros(LOG_SUBPOOLS * LOG_ALLOC_STRIDE, dtype=np.uint64)
+            a.log_pool, a.log_region, a.log_alloc = p(res["log_pool"]), region, p(res["log_alloc"])
             a.t_log = a.y_log = p(res["log_pool"])   # the "mode 2" marker, like the library sets it
         elif max_log > 0:
             res["t_log"] = np.full((max_log, B), np.nan)
@@ -186,41 +189,50 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     assert rc == 0
     res["chunks"] = chunks.value
     if paged_log is not None:
-        res["log_used"] = int(res["log_next"][0])
-        res["log_overflow"] = res["log_used"] > int(paged_log)
+        cnt = res["log_alloc"][::LOG_ALLOC_STRIDE]
+        used = (cnt & np.uint64((1 << 40) - 1)).astype(np.int64) + (cnt >> np.uint64(40)).astype(np.int64)
+        res["log_used"] = int(used.sum())
+        res["log_overflow"] = bool((used > res["log_region"]).any())
     return res
 
 
 LOG_SLOTS = 32
-NO_SEG = 0xFFFFFFFFFFFFFFFF
+LOG_SUBPOOLS = 64
+LOG_ALLOC_STRIDE = 16
 
 
 def gather_pages(res, n):
-    """What log_gather.hip does, in numpy: walk every trajectory's segment chain from its last segment back to the first and
-    lay the records out as the CSR log.  Returns (offsets [B+1], t [total], y [total, n])."""
+    """What log_gather.hip does, in numpy: enumerate every sub-pool's directory, read each page's column headers
+    (trajectory, first record index, slot bits) and lay the records out as the CSR log.
+    Returns (offsets [B+1], t [total], y [total, n])."""
     cnt = res["n_log"].astype(np.int64)
     off = np.zeros(cnt.size + 1, dtype=np.int64)
     off[1:] = np.cumsum(cnt)
-    pool = res["log_pool"]
+    pool, region = res["log_pool"], res["log_region"]
+    words = pool.view(np.uint64)
     t = np.full(int(off[-1]), np.nan)
     y = np.full((int(off[-1]), n), np.nan)
     filled = np.zeros(int(off[-1]), dtype=bool)
-    for j in range(cnt.size):
-        seg = int(res["log_cur"][j])
-        while seg != NO_SEG:
-            base, cols, col = seg >> 16, (seg >> 8) & 0xFF, seg & 0xFF
-            hdr = pool[base + 2 * col:base + 2 * col + 2]
-            prev = int(hdr[:1].view(np.uint64)[0])
-            k0, bits = (int(v) for v in hdr[1:2].view(np.uint32))
-            body = base + 2 * cols
-            r = 0
-            for s in range(LOG_SLOTS):
-                if (bits >> s) & 1:
-                    rec = pool[body + (s * cols + col) * (n + 1):body + (s * cols + col + 1) * (n + 1)]
-                    q = int(off[j]) + k0 + r
-                    assert q < off[j + 1] and not filled[q]
-                    t[q], y[q], filled[q] = rec[0], rec[1:], True
-                    r += 1
-            seg = prev
-    assert filled.all(), "every record of every trajectory must be in exactly one slot of its chain"
+    for sub in range(LOG_SUBPOOLS):
+        arenas = int(res["log_alloc"][sub * LOG_ALLOC_STRIDE]) >> 40
+        for e in range(arenas):
+            entry = int(words[(sub + 1) * region - 1 - e])
+            base0, acols, k = entry >> 8, ((entry >> 2) & 0x3F) + 1, (entry & 3) + 1
+            for p in range(k):
+                page = base0 + p * (1 + acols * (2 + LOG_SLOTS * (n + 1)))
+                cols = int(pool[page:page + 1].view(np.uint32)[0])
+                if cols == 0:
+                    continue
+                body = page + 1 + 2 * cols
+                for col in range(cols):
+                    j, k0, bits, _ = (int(v) for v in pool[page + 1 + 2 * col:page + 3 + 2 * col].view(np.uint32))
+                    r = 0
+                    for sl in range(LOG_SLOTS):
+                        if (bits >> sl) & 1:
+                            rec = pool[body + (sl * cols + col) * (n + 1):body + (sl * cols + col + 1) * (n + 1)]
+                            q = int(off[j]) + k0 + r
+                            assert q < off[j + 1] and not filled[q]
+                            t[q], y[q], filled[q] = rec[0], rec[1:], True
+                            r += 1
+    assert filled.all(), "every record of every trajectory must be in exactly one slot of one page"
     return off, t, y

@@ -80,11 +80,11 @@ def test_a_pool_that_runs_dry_keeps_counting():
     y0, p, t0, t1 = W.cr3bp_batch(16)
     opts = dict(method="DOPRI5", rtol=1e-6, atol=1e-9)
     dense = emul_batch("cr3bp", y0, p, t0, t1, max_log=2048, **opts)
-    paged = emul_batch("cr3bp", y0, p, t0, t1, paged_log=9000, **opts)
-    assert paged["log_overflow"] and paged["log_used"] > 9000
+    paged = emul_batch("cr3bp", y0, p, t0, t1, paged_log=64 * 700, **opts)       # 700 doubles per sub-pool: three pages each
+    assert paged["log_overflow"]                            # only 16 of the 64 sub-pools are used here, each far beyond its 700 doubles
     assert np.array_equal(paged["n_log"], dense["n_log"])
     assert np.array_equal(_bits(paged["y_end"]), _bits(dense["y_end"]))
-    guard = paged["log_pool"][9000:]                       # behind the pool the bodies were told about
+    guard = paged["log_pool"][64 * 700:]                   # behind the pool the bodies were told about
     assert guard.size == 256 and np.isnan(guard).all()
 
 
