@@ -1043,7 +1043,7 @@ def solve_ivp_batch_logged(f: IVP, t0, t1, y0, params=None, options: Options = N
         sl.t, sl.y, sl.capacity, sl.defer = C.c_void_p(bufs[0].data_ptr()), C.c_void_p(bufs[1].data_ptr()), max(total, 1), 0
         rc = ctx.lib.ivp_step_log_fetch_device(ctx.handle, C.byref(sl), stream)
         if rc != 0:   # the pool had run dry: integrate again -- its size now follows the counted total
-            sl.reserve = total
+            sl.reserve = 0   # automatic: what the first attempt asked of its fullest sub-pool
             res = solve_ivp_batch(f, t0d, t1d, y0d, pd, opts1, ctx, o1, _steplog=sl)
             sl.passes += 1
     res.log_offsets = offsets

@@ -747,7 +747,12 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
             const bool learnt = LS.total && LS.last_B == B;
             const uint64_t recs = log_reserve ? log_reserve : (learnt ? LS.total : (uint64_t)B * 1024u);
             uint64_t doubles = recs * (uint64_t)(n + 1) / 2 * 3 + (uint64_t)B * (2u + 2u * (uint64_t)(n + 1)) + (1u << 16);
-            if (learnt && !log_reserve) doubles = std::max<uint64_t>(doubles, LS.pool_used + LS.pool_used / 8);   // what that solve really took
+            // sub-pools: one per eight waves of the first launch, at most IVP_LOG_SUBPOOLS (they exist to spread the waves'
+            // allocation atomics; a batch of few waves would leave most regions idle)
+            uint32_t subs = 1;
+            while (subs < IVP_LOG_SUBPOOLS && (uint64_t)subs * 2u * 512u <= (uint64_t)B * (group ? 64u : 1u)) subs *= 2;
+            // what the last solve of this size really took: its fullest region, in every region
+            if (learnt && !log_reserve && LS.subs == subs) doubles = std::max<uint64_t>(doubles, (LS.region_used_max + LS.region_used_max / 8) * subs);
             if (!log_reserve && !learnt) doubles = std::max<uint64_t>(doubles, ((uint64_t)256 << 20) / 8);
             if (doubles * 8 > ctx->log_pool.cap) {   // growing: never ask for more than half of what the device can give
                 size_t free_b = 0, total_b = 0;
@@ -761,11 +766,12 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
             HIP_TRY(ctx, ctx->log_alloc.reserve(sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE));
             HIP_TRY(ctx, hipMemsetAsync(ctx->log_alloc.p, 0, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, s));
             a.log_pool = (double *)ctx->log_pool.p;
-            a.log_region = (ctx->log_pool.cap / 8) / IVP_LOG_SUBPOOLS;   // (a region stays below 2^40 doubles: the counters' low field)
+            a.log_region = (ctx->log_pool.cap / 8) / subs;   // (a region stays below 2^40 doubles: the counters' low field)
+            a.log_sub_mask = subs - 1u;
             a.log_alloc = (unsigned long long *)ctx->log_alloc.p;
             a.t_log = a.log_pool;   // "mode 2" marker of the device DefaultSolOut (so_sample); the records go to the pages
             a.y_log = a.log_pool;
-            LS.B = B; LS.n = n; LS.pool_doubles = a.log_region * IVP_LOG_SUBPOOLS; LS.region = a.log_region; LS.n_log = a.n_log;
+            LS.B = B; LS.n = n; LS.pool_doubles = a.log_region * subs; LS.region = a.log_region; LS.subs = subs; LS.n_log = a.n_log;
         } else if (count_log) {
             // counting pass = a CSR log whose offsets are all zero: so_sample runs (t_log != NULL), every record finds
             // capacity 0 and only n_log advances

@@ -71,6 +71,8 @@ struct ivp_ctx {
         uint64_t pool_doubles = 0;  // capacity of the pool during that solve
         uint64_t region = 0;        // ... per sub-pool
         uint64_t pool_used = 0;     // doubles its pages took
+        uint64_t region_used_max = 0;   // ... in the fullest sub-pool
+        uint32_t subs = 1;          // sub-pools in use
         uint32_t max_arenas = 0;    // largest directory count among the sub-pools (grid of the gather)
         uint64_t total = 0;         // records of the last logged solve (sizes the next pool)
         size_t last_B = 0;          // batch size `total` belongs to

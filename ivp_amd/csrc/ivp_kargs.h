@@ -147,12 +147,14 @@ struct IvpKArgs {
     // A column header is {j: the trajectory, k0: its record count when the page was opened, bits: which slots hold a record},
     // so a page describes itself: the gather kernel (log_gather.hip) takes one page per workgroup, reads it front to back
     // (coalesced) and writes record (j, k0 + rank of the slot) to its place in the CSR log -- no per-trajectory chains.
-    // Allocation: the pool is cut into IVP_LOG_SUBPOOLS equal regions, each with its own 64-bit counter
+    // Allocation: the pool is cut into up to IVP_LOG_SUBPOOLS equal regions, each with its own 64-bit counter
     // (pages << 40 | doubles): pages grow up from the start of a region, their directory entries (page offset << 8 | cols, one
     // per page, what the gather enumerates) grow down from its end.  A wave draws up to four pages at a time (one atomicAdd
     // on the counter blockIdx picks: 1563 waves that start a launch together do not queue on one address).
     double *log_pool;                    // NULL = the dense / two-pass CSR forms above
     unsigned long long log_region;       // doubles per sub-pool region
+    uint32_t log_sub_mask;               // sub-pools in use - 1 (a power of two <= IVP_LOG_SUBPOOLS: few waves, few sub-pools,
+                                         // so that no region is left idle while another runs dry)
     unsigned long long *log_alloc;       // [IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE] counters (one per 128-byte line)
 };
 #define IVP_LOG_SLOTS 32u

@@ -40,10 +40,12 @@ int scan_counts(ivp_ctx *ctx, unsigned long long *offsets_dev, hipStream_t s, ui
     LS.last_B = LS.B;
     // the sub-pools' counters (arenas << 40 | doubles): what the pages took, and the grid of the gather
     LS.pool_used = 0;
+    LS.region_used_max = 0;
     LS.max_arenas = 0;
-    for (uint32_t q = 0; q < IVP_LOG_SUBPOOLS; ++q) {
+    for (uint32_t q = 0; q < LS.subs; ++q) {
         const unsigned long long c = ctx->alloc_host[(size_t)q * IVP_LOG_ALLOC_STRIDE];
         LS.pool_used += (c & ((1ull << 40) - 1ull)) + (c >> 40);
+        LS.region_used_max = std::max<uint64_t>(LS.region_used_max, (c & ((1ull << 40) - 1ull)) + (c >> 40));
         LS.max_arenas = std::max<uint32_t>(LS.max_arenas, (uint32_t)std::min<unsigned long long>(c >> 40, 0x3FFFFFFFull));
     }
     return IVP_OK;
@@ -83,7 +85,7 @@ int device_destination(ivp_ctx *ctx, ivp_step_log_t *log, uint64_t total, int n,
 int gather_pool(ivp_ctx *ctx, const unsigned long long *offsets_dev, uint64_t capacity, uint64_t dst_base, double *t, double *y, hipStream_t s)
 {
     const ivp_ctx::LogState &LS = ctx->log_state;
-    HIP_TRY(ctx, ivp_log_gather((const double *)ctx->log_pool.p, LS.region, (const unsigned long long *)ctx->log_alloc.p, LS.max_arenas, offsets_dev, LS.B, LS.n,
+    HIP_TRY(ctx, ivp_log_gather((const double *)ctx->log_pool.p, LS.region, (const unsigned long long *)ctx->log_alloc.p, LS.subs, LS.max_arenas, offsets_dev, LS.B, LS.n,
                                 capacity, dst_base, t, y, s));
     return IVP_OK;
 }

@@ -97,7 +97,15 @@ __global__ __launch_bounds__(kScanThreads) void log_scan_apply(const uint32_t *n
 // One workgroup (4 wavefronts) per page: blockIdx.y = sub-pool, blockIdx.x = 4 * (arena's directory index) + page of the
 // arena.  NP1 = n + 1 as a compile-time constant where it is small (0 = run-time).  `capacity` = records the destination
 // holds: a log that does not fit is left alone (the host reports it; nothing is written out of bounds).
+//
+// A page is slot-major (the records of one attempt side by side: what makes the stepping kernels' stores coalesced), the log
+// is trajectory-major: the transposition goes through LDS.  A tile of slots is read front to back -- consecutive lanes,
+// consecutive doubles -- into LDS; then every column's records of that tile leave as TWO contiguous runs (t, y) at their place
+// in the log: whole cache lines, written once.  (Writing straight from the slot-major order scatters 8 (n + 1)-byte pieces
+// over as many destinations as the page has columns, with ~2000 pages in flight: the partly written lines fall out of L2
+// and every piece becomes a read-modify-write in HBM -- measured 1.2 ms instead of 0.4 on BASELINE C2.)
 constexpr int kGatherThreads = 256;
+constexpr int kTileDoubles = 7680;    // 60 KB of LDS per workgroup: two workgroups per CU
 template <int NP1>
 __global__ __launch_bounds__(kGatherThreads) void log_gather_kernel(const double *pool, unsigned long long region, const unsigned long long *alloc,
                                                                     const unsigned long long *offsets, uint32_t B, uint32_t n_rt,
@@ -112,8 +120,10 @@ __global__ __launch_bounds__(kGatherThreads) void log_gather_kernel(const double
     const size_t page = (size_t)(entry >> 8) + (size_t)p * (1u + acols * (2u + (size_t)IVP_LOG_SLOTS * np1));
     const uint32_t cols = *(const uint32_t *)(pool + page);
     if (cols == 0u) return;   // a page of the arena its wave never opened
+    __shared__ double tile[kTileDoubles];
     __shared__ uint32_t s_bits[IVP_WAVE];
     __shared__ unsigned long long s_q0[IVP_WAVE];
+    __shared__ unsigned char s_slot[IVP_WAVE][IVP_LOG_SLOTS];   // s_slot[col][r] = the slot of the column's r-th record
     __shared__ uint32_t s_used;
     if (threadIdx.x == 0) s_used = 0u;
     __syncthreads();
@@ -122,23 +132,36 @@ __global__ __launch_bounds__(kGatherThreads) void log_gather_kernel(const double
         const uint32_t bits = hdr[2];
         s_bits[threadIdx.x] = bits;
         s_q0[threadIdx.x] = offsets[hdr[0]] + hdr[1] + dst_base;
+        uint32_t r = 0;
+        for (uint32_t sl = 0; sl < IVP_LOG_SLOTS; ++sl)
+            if ((bits >> sl) & 1u) s_slot[threadIdx.x][r++] = (unsigned char)sl;
         if (bits) atomicOr(&s_used, bits);
     }
     __syncthreads();
     const uint32_t used = s_used;
+    if (used == 0u) return;
+    const uint32_t last = 32u - (uint32_t)__clz(used);   // slots [0, last) are in use
     const double *body = pool + page + 1u + 2u * (size_t)cols;
-    const uint32_t row = cols * np1, tx = threadIdx.x & (IVP_WAVE - 1), ty = threadIdx.x / IVP_WAVE;
-    for (uint32_t sl = ty; sl < IVP_LOG_SLOTS; sl += kGatherThreads / IVP_WAVE) {
-        if (!((used >> sl) & 1u)) continue;   // an attempt nobody accepted
-        const double *src = body + (size_t)sl * row;
-        for (uint32_t x = tx; x < row; x += IVP_WAVE) {
-            const uint32_t col = x / np1, c = x - col * np1;
+    const uint32_t row = cols * np1;
+    const uint32_t ts = min(IVP_LOG_SLOTS, (uint32_t)kTileDoubles / row);   // slots per tile (row <= 2052 doubles: ts >= 3)
+    const uint32_t tx = threadIdx.x & (IVP_WAVE - 1), ty = threadIdx.x / IVP_WAVE;
+    for (uint32_t s0 = 0; s0 < last; s0 += ts) {
+        const uint32_t s1 = min(s0 + ts, last);
+        __syncthreads();   // the previous tile has left LDS
+        for (uint32_t x = threadIdx.x; x < (s1 - s0) * row; x += kGatherThreads) tile[x] = body[(size_t)s0 * row + x];
+        __syncthreads();
+        const uint32_t tmask = (s1 >= 32u ? 0xFFFFFFFFu : ((1u << s1) - 1u)) & ~((1u << s0) - 1u);
+        for (uint32_t col = ty; col < cols; col += kGatherThreads / IVP_WAVE) {
             const uint32_t bits = s_bits[col];
-            if ((bits >> sl) & 1u) {
-                const unsigned long long q = s_q0[col] + (unsigned long long)__popc(bits & ((1u << sl) - 1u));
-                const double v = src[x];
-                if (c == 0u) t_log[q] = v;
-                else y_log[q * n + (c - 1u)] = v;
+            const uint32_t r0 = (uint32_t)__popc(bits & ((1u << s0) - 1u)), cnt = (uint32_t)__popc(bits & tmask);
+            if (cnt == 0u) continue;
+            const unsigned long long q = s_q0[col] + r0;
+            const double *src = tile + (size_t)col * np1;
+            if (tx < cnt) t_log[q + tx] = src[((uint32_t)s_slot[col][r0 + tx] - s0) * row];
+            double *dy = y_log + q * n;
+            for (uint32_t x = tx; x < cnt * n; x += IVP_WAVE) {
+                const uint32_t r = x / n, c = x - r * n;
+                dy[x] = src[((uint32_t)s_slot[col][r0 + r] - s0) * row + 1u + c];
             }
         }
     }
@@ -160,13 +183,13 @@ hipError_t ivp_log_scan(const uint32_t *n_log, size_t B, unsigned long long *off
     return hipGetLastError();
 }
 
-hipError_t ivp_log_gather(const double *pool, unsigned long long region, const unsigned long long *alloc, uint32_t max_arenas,
+hipError_t ivp_log_gather(const double *pool, unsigned long long region, const unsigned long long *alloc, uint32_t subs, uint32_t max_arenas,
                           const unsigned long long *offsets, size_t B, int n, unsigned long long capacity, unsigned long long dst_base,
                           double *t_log, double *y_log, hipStream_t s)
 {
     if (B == 0 || max_arenas == 0) return hipSuccess;
     (void)hipGetLastError();
-    const dim3 grid(4u * max_arenas, IVP_LOG_SUBPOOLS), block(kGatherThreads);
+    const dim3 grid(4u * max_arenas, subs), block(kGatherThreads);
 #define IVP_GATHER_CASE(NP1) case NP1: hipLaunchKernelGGL((log_gather_kernel<NP1>), grid, block, 0, s, pool, region, alloc, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
     switch (n + 1) {
         IVP_GATHER_CASE(2) IVP_GATHER_CASE(3) IVP_GATHER_CASE(4) IVP_GATHER_CASE(5) IVP_GATHER_CASE(6) IVP_GATHER_CASE(7) IVP_GATHER_CASE(8) IVP_GATHER_CASE(9)

@@ -831,9 +831,9 @@ IVP_HD void so_log_open(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, uint32_t s
         const uint32_t lane = __lane_id();
         const uint32_t first = (uint32_t)(__ffsll((long long)m) - 1);
         const uint32_t cols = (uint32_t)__popcll(m), col = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        const uint32_t sub = blockIdx.x & (IVP_LOG_SUBPOOLS - 1u);
+        const uint32_t sub = blockIdx.x & a.log_sub_mask;
 #else
-        const uint32_t cols = 1, col = 0, lane = 0, first = 0, sub = j & (IVP_LOG_SUBPOOLS - 1u);
+        const uint32_t cols = 1, col = 0, lane = 0, first = 0, sub = j & a.log_sub_mask;
 #endif
         const uint32_t p_local = page_no & (arena - 1u);
         unsigned long long base = 0;

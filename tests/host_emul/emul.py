@@ -41,7 +41,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("spec_cap", C.c_uint32), ("spec_min", C.c_uint32), ("ran_out", VP), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
         ("count_next", VP),
         ("window", C.c_uint32),
-        ("log_pool", VP), ("log_region", C.c_uint64), ("log_alloc", VP),
+        ("log_pool", VP), ("log_region", C.c_uint64), ("log_sub_mask", C.c_uint32), ("log_alloc", VP),
     ]
 
 
@@ -153,7 +153,7 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
             res["log_region"] = region
             res["log_pool"] = np.full(region * LOG_SUBPOOLS + 256, np.nan)   # 256 guard doubles the bodies are not told about
             res["log_alloc"] = np.zeros(LOG_SUBPOOLS * LOG_ALLOC_STRIDE, dtype=np.uint64)
-            a.log_pool, a.log_region, a.log_alloc = p(res["log_pool"]), region, p(res["log_alloc"])
+            a.log_pool, a.log_region, a.log_sub_mask, a.log_alloc = p(res["log_pool"]), region, LOG_SUBPOOLS - 1, p(res["log_alloc"])
             a.t_log = a.y_log = p(res["log_pool"])   # the "mode 2" marker, like the library sets it
         elif max_log > 0:
             res["t_log"] = np.full((max_log, B), np.nan)
