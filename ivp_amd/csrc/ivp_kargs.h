@@ -138,15 +138,21 @@ struct IvpKArgs {
     // counting solve before the filling solve costs a whole second integration.  With log_pool != NULL the stepping kernels
     // record as they go.  A page belongs to ONE WAVE and covers IVP_LOG_SLOTS record slots of every trajectory the wave is
     // stepping (32 attempts of a log-only kernel, 16 of a full one, whose attempts may record twice):
-    //     [cols x header (2 doubles)] [slot 0: cols records] [slot 1: cols records] ...      record = [t, y_0 .. y_{n-1}]
+    //     [page header][cols x column header (2 doubles)][group 0: slots x W records][group 1: slots x W records] ...
     // cols = trajectories the wave is stepping when it opens the page, column = a trajectory's rank among them, slot = attempt
-    // index within the page (wave-uniform), so the records of one attempt are ONE contiguous run of cols x (n + 1) doubles:
-    // the wave's stores fill whole cache lines back to back (lanes that rejected leave holes).  (Per-trajectory pages touch one
-    // partly written line per trajectory and attempt; 1M trajectories x 2 lines fit no cache and every 8-byte store became a
-    // partial HBM write -- measured on BASELINE C3: 28.9 ms against 12.7 for the end state.)
+    // index within the page (wave-uniform), record = [t, y_0 .. y_{n-1}].  The columns are cut into GROUPS of W = 8 (n <= 8;
+    // W = 1 for the wave-per-trajectory kernels of larger systems): within a group the records of one attempt lie side by
+    // side, W x (n + 1) doubles, and a group's slots follow each other.  A wave's stores of one attempt therefore fill 8 runs
+    // of 8 x 8 (n + 1) bytes -- a few whole cache lines each, completed by the very next stores (lanes that rejected leave
+    // holes) -- and a group is a small dense block (32 x 8 x (n + 1) doubles: 6 KB at n = 2, 14 KB at n = 6) that the gather
+    // kernel transposes through LDS in one piece.  (Per-trajectory pages touch one partly written line per trajectory and
+    // attempt; 1M trajectories x 2 lines fit no cache and every 8-byte store became a partial HBM write -- measured on
+    // BASELINE C3: 28.9 ms against 12.7 for the end state.  Whole-wave rows -- W = 64 -- made the stores perfect and the
+    // gather slow: 64 destinations per row.)
     // A column header is {j: the trajectory, k0: its record count when the page was opened, bits: which slots hold a record},
-    // so a page describes itself: the gather kernel (log_gather.hip) takes one page per workgroup, reads it front to back
-    // (coalesced) and writes record (j, k0 + rank of the slot) to its place in the CSR log -- no per-trajectory chains.
+    // so a page describes itself: the gather kernel (log_gather.hip) takes one column group per wavefront, reads it front to
+    // back (coalesced) into LDS and writes every column's records -- record (j, k0 + rank of the slot) -- to their place in the
+    // CSR log as one contiguous run: no per-trajectory chains, whole cache lines on both sides.
     // Allocation: the pool is cut into up to IVP_LOG_SUBPOOLS equal regions, each with its own 64-bit counter
     // (pages << 40 | doubles): pages grow up from the start of a region, their directory entries (page offset << 8 | cols, one
     // per page, what the gather enumerates) grow down from its end.  A wave draws up to four pages at a time (one atomicAdd
@@ -158,6 +164,7 @@ struct IvpKArgs {
     unsigned long long *log_alloc;       // [IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE] counters (one per 128-byte line)
 };
 #define IVP_LOG_SLOTS 32u
+#define IVP_LOG_GROUP(np1) ((np1) <= 9 ? 8u : 1u)   /* columns per group of a page, by record length n + 1 */
 #define IVP_LOG_SUBPOOLS 64u
 #define IVP_LOG_ALLOC_STRIDE 16u
 #define IVP_NO_SEG 0xFFFFFFFFFFFFFFFFull

@@ -3,17 +3,19 @@
 // The stepping kernels leave the records in self-describing wave pages (layout in ivp_kargs.h, writers so_log_open /
 // so_push_log in rk_core.h) and every trajectory's record count in n_log.  Here:
 //   ivp_log_scan    offsets[b] = sum of n_log[0 .. b), offsets[B] = total          (three small launches)
-//   ivp_log_gather  one workgroup per page: the column headers (trajectory j, first record index k0, slot bits) go to LDS,
-//                   then the page is read front to back -- consecutive lanes read consecutive doubles -- and the record in
-//                   slot s of column c goes to t_log[q], y_log[q * n + ..] with q = offsets[j] + k0 + (rank of s among the
-//                   column's set bits): time-major like the reference's Solution.t / Solution.y (src/solve/solout.rs:387-428,
-//                   src/solve/solve_ivp.rs:288-312).  A column's records land on consecutive addresses slot after slot, so
-//                   the scattered 8 (n + 1)-byte writes complete their cache lines while those are still in L2.
+//   ivp_log_gather  one wavefront per COLUMN GROUP of a page (8 trajectories x 32 slots x (n + 1) doubles, one dense block):
+//                   the block is read front to back -- consecutive lanes, consecutive doubles -- into LDS, then every
+//                   column's records leave as two contiguous runs (t, y) at their place in the log: record (j, k0 + rank of
+//                   its slot among the column's set bits) -> t_log[offsets[j] + ..], y_log[(offsets[j] + ..) * n + c],
+//                   time-major like the reference's Solution.t / Solution.y (src/solve/solout.rs:387-428,
+//                   src/solve/solve_ivp.rs:288-312).  Whole cache lines on both sides, each touched once.
 // Both are pure data movement: HBM-bound, ~2 x 8 (n + 1) bytes per record (+ the holes rejected attempts leave in a page).
 #include <hip/hip_runtime.h>
 
 #include "ivp_kargs.h"
 #include "log_gather.h"
+
+#include <algorithm>
 
 namespace {
 
@@ -94,74 +96,76 @@ __global__ __launch_bounds__(kScanThreads) void log_scan_apply(const uint32_t *n
     }
 }
 
-// One workgroup (4 wavefronts) per page: blockIdx.y = sub-pool, blockIdx.x = 4 * (arena's directory index) + page of the
-// arena.  NP1 = n + 1 as a compile-time constant where it is small (0 = run-time).  `capacity` = records the destination
+// One wavefront per column group: blockIdx.y = sub-pool, blockIdx.x = ((arena's directory index) * 4 + page of the arena) * 8
+// + group.  NP1 = n + 1 as a compile-time constant where it is small (0 = run-time).  `capacity` = records the destination
 // holds: a log that does not fit is left alone (the host reports it; nothing is written out of bounds).
-//
-// A page is slot-major (the records of one attempt side by side: what makes the stepping kernels' stores coalesced), the log
-// is trajectory-major: the transposition goes through LDS.  A tile of slots is read front to back -- consecutive lanes,
-// consecutive doubles -- into LDS; then every column's records of that tile leave as TWO contiguous runs (t, y) at their place
-// in the log: whole cache lines, written once.  (Writing straight from the slot-major order scatters 8 (n + 1)-byte pieces
-// over as many destinations as the page has columns, with ~2000 pages in flight: the partly written lines fall out of L2
-// and every piece becomes a read-modify-write in HBM -- measured 1.2 ms instead of 0.4 on BASELINE C2.)
-constexpr int kGatherThreads = 256;
-constexpr int kTileDoubles = 7680;    // 60 KB of LDS per workgroup: two workgroups per CU
+// LDS (dynamic): the whole group where it is small (n <= 8: at most 32 x 8 x 9 doubles), a tile of its slots otherwise.
+constexpr int kLoadUnroll = 8;        // loads a lane has in flight
 template <int NP1>
-__global__ __launch_bounds__(kGatherThreads) void log_gather_kernel(const double *pool, unsigned long long region, const unsigned long long *alloc,
-                                                                    const unsigned long long *offsets, uint32_t B, uint32_t n_rt,
-                                                                    unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log)
+__global__ __launch_bounds__(IVP_WAVE) void log_gather_kernel(const double *pool, unsigned long long region, const unsigned long long *alloc,
+                                                              const unsigned long long *offsets, uint32_t B, uint32_t n_rt,
+                                                              unsigned long long capacity, unsigned long long dst_base, double *t_log, double *y_log,
+                                                              uint32_t tile_doubles)
 {
-    const uint32_t np1 = NP1 ? (uint32_t)NP1 : n_rt + 1u, n = np1 - 1u;
-    const uint32_t sub = blockIdx.y, e = blockIdx.x >> 2, p = blockIdx.x & 3u;
+    const uint32_t np1 = NP1 ? (uint32_t)NP1 : n_rt + 1u, n = np1 - 1u, W = IVP_LOG_GROUP(np1);
+    const uint32_t sub = blockIdx.y, g = blockIdx.x & 7u, p = (blockIdx.x >> 3) & 3u, e = blockIdx.x >> 5;
     if ((unsigned long long)e >= (alloc[(size_t)sub * IVP_LOG_ALLOC_STRIDE] >> 40) || offsets[B] > capacity) return;
     const unsigned long long entry = ((const unsigned long long *)pool)[(size_t)(sub + 1u) * region - 1u - e];
     if (p > (uint32_t)(entry & 3u)) return;
     const size_t acols = (size_t)((entry >> 2) & 0x3Fu) + 1u;
-    const size_t page = (size_t)(entry >> 8) + (size_t)p * (1u + acols * (2u + (size_t)IVP_LOG_SLOTS * np1));
-    const uint32_t cols = *(const uint32_t *)(pool + page);
-    if (cols == 0u) return;   // a page of the arena its wave never opened
-    __shared__ double tile[kTileDoubles];
-    __shared__ uint32_t s_bits[IVP_WAVE];
-    __shared__ unsigned long long s_q0[IVP_WAVE];
-    __shared__ unsigned char s_slot[IVP_WAVE][IVP_LOG_SLOTS];   // s_slot[col][r] = the slot of the column's r-th record
-    __shared__ uint32_t s_used;
-    if (threadIdx.x == 0) s_used = 0u;
-    __syncthreads();
-    if (threadIdx.x < cols) {
-        const uint32_t *hdr = (const uint32_t *)(pool + page + 1u + 2u * (size_t)threadIdx.x);
-        const uint32_t bits = hdr[2];
-        s_bits[threadIdx.x] = bits;
-        s_q0[threadIdx.x] = offsets[hdr[0]] + hdr[1] + dst_base;
-        uint32_t r = 0;
-        for (uint32_t sl = 0; sl < IVP_LOG_SLOTS; ++sl)
-            if ((bits >> sl) & 1u) s_slot[threadIdx.x][r++] = (unsigned char)sl;
-        if (bits) atomicOr(&s_used, bits);
+    // (arenas of more than one page are made of IVP_LOG_SLOTS-slot pages: so_log_attempt in rk_core.h)
+    const size_t page = (size_t)(entry >> 8) + (size_t)p * (1u + 2u * acols + ((acols + W - 1u) / W) * (size_t)IVP_LOG_SLOTS * W * np1);
+    const uint32_t cols = ((const uint32_t *)(pool + page))[0], slots = ((const uint32_t *)(pool + page))[1];
+    if (cols == 0u || g * W >= cols) return;   // a page of the arena its wave never opened / a group the page does not have
+    const uint32_t c0 = g * W, gc = min(W, cols - c0), lane = threadIdx.x;
+    extern __shared__ double tile[];
+    __shared__ unsigned char s_slot[8][IVP_LOG_SLOTS];   // s_slot[c][r] = the slot of column c's r-th record
+    uint32_t my_bits = 0;
+    unsigned long long my_q0 = 0;
+    if (lane < gc) {
+        const uint32_t *hdr = (const uint32_t *)(pool + page + 1u + 2u * (size_t)(c0 + lane));
+        my_bits = hdr[2];
+        if (my_bits) my_q0 = offsets[hdr[0]] + hdr[1] + dst_base;
     }
-    __syncthreads();
-    const uint32_t used = s_used;
+    uint32_t used = 0;
+    for (uint32_t c = 0; c < gc; ++c) {
+        const uint32_t b = (uint32_t)__shfl((int)my_bits, (int)c);
+        used |= b;
+        if (lane < IVP_LOG_SLOTS && ((b >> lane) & 1u)) s_slot[c][__popc(b & ((1u << lane) - 1u))] = (unsigned char)lane;
+    }
     if (used == 0u) return;
     const uint32_t last = 32u - (uint32_t)__clz(used);   // slots [0, last) are in use
-    const double *body = pool + page + 1u + 2u * (size_t)cols;
-    const uint32_t row = cols * np1;
-    const uint32_t ts = min(IVP_LOG_SLOTS, (uint32_t)kTileDoubles / row);   // slots per tile (row <= 2052 doubles: ts >= 3)
-    const uint32_t tx = threadIdx.x & (IVP_WAVE - 1), ty = threadIdx.x / IVP_WAVE;
+    const uint32_t row = W * np1;
+    const double *src = pool + page + 1u + 2u * (size_t)cols + (size_t)g * slots * row;
+    const uint32_t ts = max(1u, min(slots, tile_doubles / row));
     for (uint32_t s0 = 0; s0 < last; s0 += ts) {
         const uint32_t s1 = min(s0 + ts, last);
-        __syncthreads();   // the previous tile has left LDS
-        for (uint32_t x = threadIdx.x; x < (s1 - s0) * row; x += kGatherThreads) tile[x] = body[(size_t)s0 * row + x];
+        __syncthreads();   // the previous tile has left LDS (and s_slot is complete)
+        {
+            const uint32_t count = (s1 - s0) * row;
+            const double *in = src + (size_t)s0 * row;
+            for (uint32_t x0 = lane; x0 < count; x0 += IVP_WAVE * kLoadUnroll) {
+                double v[kLoadUnroll];
+#pragma unroll
+                for (int u = 0; u < kLoadUnroll; ++u) { const uint32_t x = x0 + (uint32_t)u * IVP_WAVE; v[u] = x < count ? in[x] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < kLoadUnroll; ++u) { const uint32_t x = x0 + (uint32_t)u * IVP_WAVE; if (x < count) tile[x] = v[u]; }
+            }
+        }
         __syncthreads();
         const uint32_t tmask = (s1 >= 32u ? 0xFFFFFFFFu : ((1u << s1) - 1u)) & ~((1u << s0) - 1u);
-        for (uint32_t col = ty; col < cols; col += kGatherThreads / IVP_WAVE) {
-            const uint32_t bits = s_bits[col];
+        for (uint32_t c = 0; c < gc; ++c) {
+            const uint32_t bits = (uint32_t)__shfl((int)my_bits, (int)c);
+            const unsigned long long q00 = ((unsigned long long)(uint32_t)__shfl((int)(my_q0 >> 32), (int)c) << 32) | (uint32_t)__shfl((int)(uint32_t)my_q0, (int)c);
             const uint32_t r0 = (uint32_t)__popc(bits & ((1u << s0) - 1u)), cnt = (uint32_t)__popc(bits & tmask);
             if (cnt == 0u) continue;
-            const unsigned long long q = s_q0[col] + r0;
-            const double *src = tile + (size_t)col * np1;
-            if (tx < cnt) t_log[q + tx] = src[((uint32_t)s_slot[col][r0 + tx] - s0) * row];
+            const unsigned long long q = q00 + r0;
+            const double *col = tile + (size_t)c * np1;
+            if (lane < cnt) t_log[q + lane] = col[((uint32_t)s_slot[c][r0 + lane] - s0) * row];
             double *dy = y_log + q * n;
-            for (uint32_t x = tx; x < cnt * n; x += IVP_WAVE) {
-                const uint32_t r = x / n, c = x - r * n;
-                dy[x] = src[((uint32_t)s_slot[col][r0 + r] - s0) * row + 1u + c];
+            for (uint32_t x = lane; x < cnt * n; x += IVP_WAVE) {
+                const uint32_t r = x / n, cc = x - r * n;
+                dy[x] = col[((uint32_t)s_slot[c][r0 + r] - s0) * row + 1u + cc];
             }
         }
     }
@@ -189,11 +193,15 @@ hipError_t ivp_log_gather(const double *pool, unsigned long long region, const u
 {
     if (B == 0 || max_arenas == 0) return hipSuccess;
     (void)hipGetLastError();
-    const dim3 grid(4u * max_arenas, subs), block(kGatherThreads);
-#define IVP_GATHER_CASE(NP1) case NP1: hipLaunchKernelGGL((log_gather_kernel<NP1>), grid, block, 0, s, pool, region, alloc, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
+    const dim3 grid(32u * max_arenas, subs), block(IVP_WAVE);
+    // LDS: a whole column group (32 slots x W columns x (n + 1) doubles) for n <= 8, a tile of at most 32 KB of its slots beyond
+    const uint32_t np1 = (uint32_t)n + 1u, row = IVP_LOG_GROUP(np1) * np1;
+    const uint32_t tile_doubles = np1 <= 9u ? IVP_LOG_SLOTS * row : std::max<uint32_t>(row, std::min<uint32_t>(IVP_LOG_SLOTS * row, 4096u));
+    const size_t lds = (size_t)tile_doubles * sizeof(double);
+#define IVP_GATHER_CASE(NP1) case NP1: hipLaunchKernelGGL((log_gather_kernel<NP1>), grid, block, lds, s, pool, region, alloc, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log, tile_doubles); break;
     switch (n + 1) {
         IVP_GATHER_CASE(2) IVP_GATHER_CASE(3) IVP_GATHER_CASE(4) IVP_GATHER_CASE(5) IVP_GATHER_CASE(6) IVP_GATHER_CASE(7) IVP_GATHER_CASE(8) IVP_GATHER_CASE(9)
-    default: hipLaunchKernelGGL((log_gather_kernel<0>), grid, block, 0, s, pool, region, alloc, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log); break;
+    default: hipLaunchKernelGGL((log_gather_kernel<0>), grid, block, lds, s, pool, region, alloc, offsets, (uint32_t)B, (uint32_t)n, capacity, dst_base, t_log, y_log, tile_doubles); break;
     }
 #undef IVP_GATHER_CASE
     return hipGetLastError();

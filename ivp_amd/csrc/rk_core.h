@@ -798,11 +798,18 @@ IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t t
     L.n_filled += 1;
 }
 // ---- one-pass step log: wave pages (layout and rationale: ivp_kargs.h) ----
-// a lane's "segment": page offset (doubles) << 18 | (arena cols - 1) << 12 | (cols - 1) << 6 | column
-#define IVP_SEG_BASE(seg) ((size_t)((seg) >> 18))
+// a lane's "segment": page offset (doubles) << 23 | (slots - 1) << 18 | (arena cols - 1) << 12 | (cols - 1) << 6 | column
+#define IVP_SEG_BASE(seg) ((size_t)((seg) >> 23))
+#define IVP_SEG_SLOTS(seg) ((size_t)(((seg) >> 18) & 0x1Fu) + 1u)
 #define IVP_SEG_ACOLS(seg) ((size_t)(((seg) >> 12) & 0x3Fu) + 1u)
 #define IVP_SEG_COLS(seg) ((size_t)(((seg) >> 6) & 0x3Fu) + 1u)
 #define IVP_SEG_COL(seg) ((size_t)((seg) & 0x3Fu))
+// doubles of a page of `cols` columns and `slots` slots: header, column headers, ceil(cols / W) column groups
+IVP_HD unsigned long long ivp_log_page_doubles(unsigned long long cols, unsigned long long slots, unsigned long long np1)
+{
+    const unsigned long long w = IVP_LOG_GROUP(np1);
+    return 1u + 2u * cols + ((cols + w - 1u) / w) * slots * w * np1;
+}
 // so_log_flush: the slots of the current page column that hold a record go to its header (a column nobody recorded into
 // keeps the 0 it was opened with).
 template <class MAP, int N, int P>
@@ -825,7 +832,7 @@ IVP_HD void so_log_open(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, uint32_t s
     so_log_flush<MAP>(a, L);
     uint64_t seg = IVP_NO_SEG;
     if (MAP::leader()) {
-        const unsigned long long per_col = 2u + (unsigned long long)slots * (MAP::NT + 1);
+        constexpr unsigned long long np1 = MAP::NT + 1;
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned long long m = __ballot(true);
         const uint32_t lane = __lane_id();
@@ -840,7 +847,7 @@ IVP_HD void so_log_open(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, uint32_t s
         uint32_t acols = cols;
         bool ok;
         if (p_local == 0u) {   // a new arena: `arena` pages of the width the wave has now
-            const unsigned long long stride = 1u + (unsigned long long)cols * per_col, need = (unsigned long long)arena * stride;
+            const unsigned long long stride = ivp_log_page_doubles(cols, slots, np1), need = (unsigned long long)arena * stride;
             unsigned long long old = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
             if (lane == first) old = atomicAdd(a.log_alloc + (size_t)sub * IVP_LOG_ALLOC_STRIDE, (1ull << 40) | need);
@@ -860,13 +867,17 @@ IVP_HD void so_log_open(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, uint32_t s
         } else {               // the next page of the arena this lane's current page belongs to
             ok = L.log_seg != IVP_NO_SEG;
             acols = (uint32_t)IVP_SEG_ACOLS(L.log_seg);
-            base = IVP_SEG_BASE(L.log_seg) + 1u + (unsigned long long)acols * per_col;
+            base = IVP_SEG_BASE(L.log_seg) + ivp_log_page_doubles(acols, slots, np1);
         }
         if (!ok) {
             ivp_flag_error(a, IVP_ERRFLAG_LOG_OVERFLOW);
         } else {
-            seg = ((uint64_t)base << 18) | ((uint64_t)(acols - 1u) << 12) | ((uint64_t)(cols - 1u) << 6) | (uint64_t)col;
-            if (lane == first) *(uint32_t *)(a.log_pool + (size_t)base) = cols;   // page header: opened, this many columns
+            seg = ((uint64_t)base << 23) | ((uint64_t)(slots - 1u) << 18) | ((uint64_t)(acols - 1u) << 12) | ((uint64_t)(cols - 1u) << 6) | (uint64_t)col;
+            if (lane == first) {   // page header: opened -- this many columns, this many slots
+                uint32_t *ph = (uint32_t *)(a.log_pool + (size_t)base);
+                ph[0] = cols;
+                ph[1] = slots;
+            }
             uint32_t *hdr = (uint32_t *)(a.log_pool + (size_t)base + 1u + 2u * (size_t)col);
             hdr[0] = j;            // the trajectory,
             hdr[1] = L.n_log;      // its record count so far: where this column's records go in its log,
@@ -904,8 +915,11 @@ IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, 
         // one-pass log: the record goes to this attempt's slot of the trajectory's column in the wave's current page
         // (ivp_kargs.h) -- next to the records the other trajectories of the wave write in this attempt
         if (L.log_seg != IVP_NO_SEG) {
-            const size_t cols = IVP_SEG_COLS(L.log_seg), col = IVP_SEG_COL(L.log_seg);
-            double *rec = a.log_pool + IVP_SEG_BASE(L.log_seg) + 1u + 2u * cols + ((size_t)L.log_slot * cols + col) * (MAP::NT + 1);
+            // column groups of W trajectories (ivp_kargs.h): record (slot, col) of group g = col / W sits at
+            // body + ((g * slots + slot) * W + col % W) * (n + 1): the W records of a group and slot are one contiguous run
+            constexpr size_t np1 = MAP::NT + 1, W = IVP_LOG_GROUP(np1);
+            const size_t cols = IVP_SEG_COLS(L.log_seg), col = IVP_SEG_COL(L.log_seg), slots = IVP_SEG_SLOTS(L.log_seg);
+            double *rec = a.log_pool + IVP_SEG_BASE(L.log_seg) + 1u + 2u * cols + (((col / W) * slots + (size_t)L.log_slot) * W + (col % W)) * np1;
             if (MAP::leader()) rec[0] = t;
 #pragma unroll
             for (int c = 0; c < N; ++c) if (MAP::own(c)) rec[1 + MAP::gi(c)] = yv[c];

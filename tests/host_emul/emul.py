@@ -210,6 +210,9 @@ def gather_pages(res, n):
     off[1:] = np.cumsum(cnt)
     pool, region = res["log_pool"], res["log_region"]
     words = pool.view(np.uint64)
+    np1 = n + 1
+    W = 8 if np1 <= 9 else 1
+    page_doubles = lambda cols, slots: 1 + 2 * cols + ((cols + W - 1) // W) * slots * W * np1
     t = np.full(int(off[-1]), np.nan)
     y = np.full((int(off[-1]), n), np.nan)
     filled = np.zeros(int(off[-1]), dtype=bool)
@@ -219,8 +222,8 @@ def gather_pages(res, n):
             entry = int(words[(sub + 1) * region - 1 - e])
             base0, acols, k = entry >> 8, ((entry >> 2) & 0x3F) + 1, (entry & 3) + 1
             for p in range(k):
-                page = base0 + p * (1 + acols * (2 + LOG_SLOTS * (n + 1)))
-                cols = int(pool[page:page + 1].view(np.uint32)[0])
+                page = base0 + p * page_doubles(acols, LOG_SLOTS)
+                cols, slots = (int(v) for v in pool[page:page + 1].view(np.uint32))
                 if cols == 0:
                     continue
                 body = page + 1 + 2 * cols
@@ -229,9 +232,10 @@ def gather_pages(res, n):
                     r = 0
                     for sl in range(LOG_SLOTS):
                         if (bits >> sl) & 1:
-                            rec = pool[body + (sl * cols + col) * (n + 1):body + (sl * cols + col + 1) * (n + 1)]
+                            at = body + (((col // W) * slots + sl) * W + col % W) * np1
+                            rec = pool[at:at + np1]
                             q = int(off[j]) + k0 + r
-                            assert q < off[j + 1] and not filled[q]
+                            assert sl < slots and q < off[j + 1] and not filled[q]
                             t[q], y[q], filled[q] = rec[0], rec[1:], True
                             r += 1
     assert filled.all(), "every record of every trajectory must be in exactly one slot of one page"

@@ -45,8 +45,8 @@ def test_paged_log_equals_dense_log_and_oracle(name, rhs, make, opts, chunk):
         assert np.array_equal(_bits(lean[k]), _bits(dense[k])), k
     for k in ("n_log", "nfev", "naccpt", "nrejct", "status"):
         assert np.array_equal(lean[k], dense[k]), k
-    paged = emul_batch(rhs, y0, p, t0, t1, paged_log=1 << 22, chunk=chunk, **opts)
-    assert not paged["log_overflow"] and 0 < paged["log_used"] <= 1 << 22
+    paged = emul_batch(rhs, y0, p, t0, t1, paged_log=1 << 25, chunk=chunk, **opts)
+    assert not paged["log_overflow"] and 0 < paged["log_used"] <= 1 << 25
     assert np.array_equal(paged["n_log"], dense["n_log"])
     for k in ("y_end", "t_end", "h_next"):
         assert np.array_equal(_bits(paged[k]), _bits(dense[k])), k
@@ -67,8 +67,8 @@ def test_terminal_event_record_goes_to_the_pages():
     y0 = np.array([[1.0, 0.3], [0.0, 1.0]])
     kw = dict(method="DOPRI5", rtol=1e-8, atol=1e-10, event_direction=[0], event_terminal=[2])
     dense = emul_batch("sho_ev", y0, None, 0.0, 20.0, max_log=512, **kw)
-    paged = emul_batch("sho_ev", y0, None, 0.0, 20.0, paged_log=1 << 18, **kw)
-    assert (dense["status"] == 1).all() and np.array_equal(paged["n_log"], dense["n_log"])
+    paged = emul_batch("sho_ev", y0, None, 0.0, 20.0, paged_log=1 << 22, **kw)
+    assert (dense["status"] == 1).all() and np.array_equal(paged["n_log"], dense["n_log"]) and not paged["log_overflow"]
     _, t, y = E.gather_pages(paged, 2)
     td, yd = _dense_as_csr(dense)
     assert np.array_equal(_bits(t), _bits(td)) and np.array_equal(_bits(y), _bits(yd))
@@ -80,7 +80,7 @@ def test_a_pool_that_runs_dry_keeps_counting():
     y0, p, t0, t1 = W.cr3bp_batch(16)
     opts = dict(method="DOPRI5", rtol=1e-6, atol=1e-9)
     dense = emul_batch("cr3bp", y0, p, t0, t1, max_log=2048, **opts)
-    paged = emul_batch("cr3bp", y0, p, t0, t1, paged_log=64 * 700, **opts)       # 700 doubles per sub-pool: three pages each
+    paged = emul_batch("cr3bp", y0, p, t0, t1, paged_log=64 * 700, **opts)       # 700 doubles per sub-pool: not even one page of a launch
     assert paged["log_overflow"]                            # only 16 of the 64 sub-pools are used here, each far beyond its 700 doubles
     assert np.array_equal(paged["n_log"], dense["n_log"])
     assert np.array_equal(_bits(paged["y_end"]), _bits(dense["y_end"]))
@@ -93,7 +93,8 @@ def test_zero_length_interval_and_nan_interval_lanes():
     y0 = np.array([[1.0, 2.0, 3.0], [0.0, 0.0, 0.0]])
     t0 = np.array([0.0, 1.0, 0.0])
     t1 = np.array([0.0, 2.0, np.nan])
-    paged = emul_batch("sho", y0, None, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, paged_log=1 << 16)
+    paged = emul_batch("sho", y0, None, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, paged_log=1 << 22)
+    assert not paged["log_overflow"]
     dense = emul_batch("sho", y0, None, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, max_log=64)
     assert np.array_equal(paged["n_log"], dense["n_log"]) and paged["n_log"][0] == 1 and paged["n_log"][2] == 0
     off, t, y = E.gather_pages(paged, 2)

@@ -25,8 +25,9 @@ def main():
     ap.add_argument("workload", nargs="?", default="c2", choices=["c2", "c3"])
     ap.add_argument("--fp", default="strict", choices=["strict", "fma"])
     ap.add_argument("--solves", type=int, default=10)
-    ap.add_argument("--only", default="all", choices=["all", "one", "two", "end"])
+    ap.add_argument("--only", default="all", choices=["all", "one", "two", "end", "none"])
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--fetch-reps", type=int, default=0, help="time scan + gather alone this many times (the pool of one logged solve)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if a.workload == "c2":
@@ -63,6 +64,28 @@ def main():
         med, mn, out = timed(lambda prev: ivp_amd.solve_ivp_batch_logged(f, t0, t1d, y0d, pd, opts, ctx, out=prev), a.solves)
         res["one_pass_ms"] = {"median": med, "min": mn, "log_info": out.log_info}
         del out
+    if a.fetch_reps:
+        # the second half alone (scan + gather kernel): the records of the solve above are fetched again and again from the pool
+        import ctypes as C
+        from ivp_amd import _lib
+        r = ivp_amd.solve_ivp_batch_logged(f, t0, t1d, y0d, pd, opts, ctx)
+        total = int(r.log_offsets[-1])
+        tb, yb = torch.empty(total, dtype=torch.float64, device=dev), torch.empty((total, y0.shape[0]), dtype=torch.float64, device=dev)
+        sl = _lib.StepLogT()
+        sl.t, sl.y, sl.capacity = tb.data_ptr(), yb.data_ptr(), total
+        ts = []
+        for _ in range(a.fetch_reps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            rc = ctx.lib.ivp_step_log_fetch_device(ctx.handle, C.byref(sl), None)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+            assert rc == 0, ctx.last_error()
+        assert torch.equal(tb, r.t_log) and torch.equal(yb, r.y_log)
+        byts = total * (y0.shape[0] + 1) * 8
+        res["fetch_ms"] = {"median": float(np.median(ts)), "min": float(np.min(ts)), "records": total, "payload_GB": byts / 1e9,
+                           "pool_used_GB": r.log_info["pool_used_bytes"] / 1e9,
+                           "GBs_read_plus_written": (byts + r.log_info["pool_used_bytes"]) / (float(np.min(ts)) * 1e-3) / 1e9}
     if a.only in ("all", "two"):
         med, mn, out = timed(lambda prev: ivp_amd.solve_ivp_batch_logged(f, t0, t1d, y0d, pd, opts, ctx, two_pass=True), max(3, a.solves // 2))
         res["two_pass_ms"] = {"median": med, "min": mn}
