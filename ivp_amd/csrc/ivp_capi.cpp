@@ -348,6 +348,9 @@ int enqueue_round(ivp_ctx *ctx)
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((P.c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (!P.err_checked || P.paged) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // one-pass step log: the sub-pools' counters travel with every round's active count, so that the round that finishes the
+    // solve also tells the host how many pages there are to gather (ivp_log.cpp) -- no extra round trip
+    if (P.paged) HIP_TRY(ctx, hipMemcpyAsync(ctx->alloc_host, ctx->log_alloc.p, sizeof(unsigned long long) * ctx->log_state.subs * IVP_LOG_ALLOC_STRIDE, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(P.round_done, s));
     return IVP_OK;
 }
@@ -764,6 +767,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
             doubles = std::min<uint64_t>(std::max<uint64_t>(doubles, (uint64_t)1 << 16), (uint64_t)1 << 45);
             HIP_TRY(ctx, ctx->log_pool.reserve((size_t)doubles * 8));
             HIP_TRY(ctx, ctx->log_alloc.reserve(sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE));
+            if (!ctx->alloc_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->alloc_host, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, hipHostMallocDefault));
             HIP_TRY(ctx, hipMemsetAsync(ctx->log_alloc.p, 0, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, s));
             a.log_pool = (double *)ctx->log_pool.p;
             a.log_region = (ctx->log_pool.cap / 8) / subs;   // (a region stays below 2^40 doubles: the counters' low field)

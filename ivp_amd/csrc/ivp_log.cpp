@@ -23,31 +23,50 @@ using namespace ivp_host;
 
 namespace {
 
-// offsets (device, [B + 1]) from the counts of the context's last logged solve; total -> host.  Synchronises `s`.
-int scan_counts(ivp_ctx *ctx, unsigned long long *offsets_dev, hipStream_t s, uint64_t *total)
+// the sub-pools' counters (arenas << 40 | doubles) of the context's last logged solve -- they arrived with the round that
+// finished it (enqueue_round in ivp_capi.cpp): what the pages took, and the grid of the gather
+void pool_stats(ivp_ctx *ctx)
 {
     ivp_ctx::LogState &LS = ctx->log_state;
-    HIP_TRY(ctx, ctx->log_bsum.reserve(ivp_log_scan_scratch_bytes(LS.B)));
-    HIP_TRY(ctx, ivp_log_scan(LS.n_log, LS.B, offsets_dev, ctx->log_bsum.p, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 8, offsets_dev + LS.B, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    if (!ctx->alloc_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->alloc_host, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, hipHostMallocDefault));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->alloc_host, ctx->log_alloc.p, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    unsigned long long t;
-    std::memcpy(&t, ctx->pinned + 8, sizeof t);
-    *total = t;
-    LS.total = t;
-    LS.last_B = LS.B;
-    // the sub-pools' counters (arenas << 40 | doubles): what the pages took, and the grid of the gather
     LS.pool_used = 0;
     LS.region_used_max = 0;
     LS.max_arenas = 0;
     for (uint32_t q = 0; q < LS.subs; ++q) {
         const unsigned long long c = ctx->alloc_host[(size_t)q * IVP_LOG_ALLOC_STRIDE];
-        LS.pool_used += (c & ((1ull << 40) - 1ull)) + (c >> 40);
-        LS.region_used_max = std::max<uint64_t>(LS.region_used_max, (c & ((1ull << 40) - 1ull)) + (c >> 40));
-        LS.max_arenas = std::max<uint32_t>(LS.max_arenas, (uint32_t)std::min<unsigned long long>(c >> 40, 0x3FFFFFFFull));
+        const unsigned long long used = (c & ((1ull << 40) - 1ull)) + (c >> 40);
+        LS.pool_used += used;
+        LS.region_used_max = std::max<uint64_t>(LS.region_used_max, used);
+        LS.max_arenas = std::max<uint32_t>(LS.max_arenas, (uint32_t)std::min<unsigned long long>(c >> 40, 0x3FFFFFFull));
     }
+}
+
+// offsets (device, [B + 1]) from the counts of the context's last logged solve, the total on its way to the host: enqueued
+// on `s`, not waited for
+int enqueue_scan(ivp_ctx *ctx, unsigned long long *offsets_dev, hipStream_t s)
+{
+    ivp_ctx::LogState &LS = ctx->log_state;
+    HIP_TRY(ctx, ctx->log_bsum.reserve(ivp_log_scan_scratch_bytes(LS.B)));
+    HIP_TRY(ctx, ivp_log_scan(LS.n_log, LS.B, offsets_dev, ctx->log_bsum.p, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 8, offsets_dev + LS.B, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    return IVP_OK;
+}
+uint64_t scanned_total(ivp_ctx *ctx)   // after the stream has been synchronised
+{
+    ivp_ctx::LogState &LS = ctx->log_state;
+    unsigned long long t;
+    std::memcpy(&t, ctx->pinned + 8, sizeof t);
+    LS.total = t;
+    LS.last_B = LS.B;
+    return t;
+}
+// both, and the wait
+int scan_counts(ivp_ctx *ctx, unsigned long long *offsets_dev, hipStream_t s, uint64_t *total)
+{
+    pool_stats(ctx);
+    const int rc = enqueue_scan(ctx, offsets_dev, s);
+    if (rc != IVP_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *total = scanned_total(ctx);
     return IVP_OK;
 }
 
@@ -113,13 +132,23 @@ int ivp_batch_solve_logged_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, siz
     ctx->log_plan = ivp_ctx::LogPlan{};
     if (rc != IVP_OK) return rc;
     log->passes = 1;
-    uint64_t total = 0;
-    rc = scan_counts(ctx, (unsigned long long *)log->offsets, s, &total);
+    // offsets, and -- when the caller brought buffers -- the gather right behind the scan, without a round trip to the host in
+    // between: the kernel itself leaves a log alone that does not fit (offsets[B] > capacity)
+    pool_stats(ctx);
+    rc = enqueue_scan(ctx, (unsigned long long *)log->offsets, s);
     if (rc != IVP_OK) return rc;
+    const bool early = !log->defer && log->t && log->y && !ctx->log_state.overflow;
+    if (early) {
+        rc = gather_pool(ctx, (const unsigned long long *)log->offsets, log->capacity, 0, log->t, log->y, s);
+        if (rc != IVP_OK) return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    const uint64_t total = scanned_total(ctx);
     fill_log_info(ctx, log);
     if (log->defer) return IVP_OK;   // the caller fetches the records (ivp_step_log_fetch_device); after an overflow that fetch fails
     rc = device_destination(ctx, log, total, ctx->log_state.n, ctx->device);
     if (rc != IVP_OK) return rc;
+    if (early) return IVP_OK;        // the records are there (device_destination has checked that they fitted)
     if (!ctx->log_state.overflow) {
         rc = gather_pool(ctx, (const unsigned long long *)log->offsets, log->capacity, 0, log->t, log->y, s);
         if (rc != IVP_OK) return rc;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kScanThreads) void log_scan_apply(const uint32_t *n
 // + group.  NP1 = n + 1 as a compile-time constant where it is small (0 = run-time).  `capacity` = records the destination
 // holds: a log that does not fit is left alone (the host reports it; nothing is written out of bounds).
 // LDS (dynamic): the whole group where it is small (n <= 8: at most 32 x 8 x 9 doubles), a tile of its slots otherwise.
-constexpr int kLoadUnroll = 8;        // loads a lane has in flight
+constexpr int kLoadUnroll = 8;        // loads a lane has in flight per round of the tiled path
 template <int NP1>
 __global__ __launch_bounds__(IVP_WAVE) void log_gather_kernel(const double *pool, unsigned long long region, const unsigned long long *alloc,
                                                               const unsigned long long *offsets, uint32_t B, uint32_t n_rt,
@@ -118,8 +118,21 @@ __global__ __launch_bounds__(IVP_WAVE) void log_gather_kernel(const double *pool
     const uint32_t cols = ((const uint32_t *)(pool + page))[0], slots = ((const uint32_t *)(pool + page))[1];
     if (cols == 0u || g * W >= cols) return;   // a page of the arena its wave never opened / a group the page does not have
     const uint32_t c0 = g * W, gc = min(W, cols - c0), lane = threadIdx.x;
+    const uint32_t row = W * np1;
+    const double *src = pool + page + 1u + 2u * (size_t)cols + (size_t)g * slots * row;
     extern __shared__ double tile[];
     __shared__ unsigned char s_slot[8][IVP_LOG_SLOTS];   // s_slot[c][r] = the slot of column c's r-th record
+    // The group in one piece (n <= 8): its loads are issued FIRST -- they depend on the page header only -- and travel while
+    // the column headers and the trajectories' offsets are fetched (a wavefront is a chain of dependent round trips to HBM;
+    // what overlaps them is the only thing that keeps the memory system busy).
+    constexpr bool whole = NP1 != 0 && NP1 <= 9;
+    constexpr int kGroupLoads = whole ? (int)(IVP_LOG_SLOTS * 8u * (unsigned)NP1 / IVP_WAVE) : 1;   // loads per lane: the whole group
+    double v[kGroupLoads];
+    if (whole) {
+        const uint32_t count = slots * row;
+#pragma unroll
+        for (int u = 0; u < kGroupLoads; ++u) { const uint32_t x = lane + (uint32_t)u * IVP_WAVE; v[u] = x < count ? src[x] : 0.0; }
+    }
     uint32_t my_bits = 0;
     unsigned long long my_q0 = 0;
     if (lane < gc) {
@@ -135,21 +148,23 @@ __global__ __launch_bounds__(IVP_WAVE) void log_gather_kernel(const double *pool
     }
     if (used == 0u) return;
     const uint32_t last = 32u - (uint32_t)__clz(used);   // slots [0, last) are in use
-    const uint32_t row = W * np1;
-    const double *src = pool + page + 1u + 2u * (size_t)cols + (size_t)g * slots * row;
-    const uint32_t ts = max(1u, min(slots, tile_doubles / row));
+    const uint32_t ts = whole ? slots : max(1u, min(slots, tile_doubles / row));
     for (uint32_t s0 = 0; s0 < last; s0 += ts) {
         const uint32_t s1 = min(s0 + ts, last);
         __syncthreads();   // the previous tile has left LDS (and s_slot is complete)
-        {
+        if (whole) {
+            const uint32_t count = slots * row;
+#pragma unroll
+            for (int u = 0; u < kGroupLoads; ++u) { const uint32_t x = lane + (uint32_t)u * IVP_WAVE; if (x < count) tile[x] = v[u]; }
+        } else {
             const uint32_t count = (s1 - s0) * row;
             const double *in = src + (size_t)s0 * row;
             for (uint32_t x0 = lane; x0 < count; x0 += IVP_WAVE * kLoadUnroll) {
-                double v[kLoadUnroll];
+                double w[kLoadUnroll];
 #pragma unroll
-                for (int u = 0; u < kLoadUnroll; ++u) { const uint32_t x = x0 + (uint32_t)u * IVP_WAVE; v[u] = x < count ? in[x] : 0.0; }
+                for (int u = 0; u < kLoadUnroll; ++u) { const uint32_t x = x0 + (uint32_t)u * IVP_WAVE; w[u] = x < count ? in[x] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < kLoadUnroll; ++u) { const uint32_t x = x0 + (uint32_t)u * IVP_WAVE; if (x < count) tile[x] = v[u]; }
+                for (int u = 0; u < kLoadUnroll; ++u) { const uint32_t x = x0 + (uint32_t)u * IVP_WAVE; if (x < count) tile[x] = w[u]; }
             }
         }
         __syncthreads();
