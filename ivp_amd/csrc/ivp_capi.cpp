@@ -150,6 +150,7 @@ struct Tune {
     int launches_per_poll = 3;       // bulk launches between two host polls
     int launches_per_poll_set = 0;   // IVP_TUNE_LAUNCHES_PER_POLL given: taken literally (no extra hand-over pair)
     int lds_lu = 1;                  // large-n BDF: 0 = never keep the factors in LDS
+    int defer_eval = 1;              // DOP853 t_eval sampling in a second, sample-parallel kernel (flavour 3): 0 = sample in the stepping kernel
     int bdf_lpw = 0;                 // trajectories per wave of the BDF chunk launches: 0 = auto (spread the active set over the SIMDs)
     Tune()
     {
@@ -158,6 +159,7 @@ struct Tune {
         if (const char *e = getenv("IVP_TUNE_BDF_OCC2")) bdf_occ2 = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_WINDOW")) window = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_LDS_LU")) lds_lu = (int)strtol(e, nullptr, 10);
+        if (const char *e = getenv("IVP_TUNE_DEFER_EVAL")) defer_eval = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BDF_LPW")) bdf_lpw = (int)std::min(64l, std::max(0l, strtol(e, nullptr, 10)));
         if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) { launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10))); launches_per_poll_set = 1; }
     }
@@ -388,6 +390,15 @@ int finish_round(ivp_ctx *ctx, int *done)
     }
     P.lanes = ctx->pinned[0];
     if (P.lanes != 0) return enqueue_round(ctx);
+    if (P.full == 3 && !P.sampled) {
+        // deferred t_eval sampling: every trajectory has finished stepping; its noted steps are evaluated now, one lane each
+        // (the solve is complete when THIS kernel is: one more turn of the round-done event)
+        P.sampled = true;
+        const bool fast = P.fp_mode == IVP_FP_FAST;
+        LAUNCH_TRY(ctx, (fast ? ivp_launch_fast : ivp_launch_strict)(IVP_LAUNCH_SAMPLE, P.method, P.prob.rhs_id, 3, P.a, (uint32_t)P.B, P.stream));
+        HIP_TRY(ctx, hipEventRecord(P.round_done, P.stream));
+        return IVP_OK;
+    }
     set_active(ctx, false);
     *done = 1;
     if (P.paged) {   // one-pass step log: the pool holds every record unless it ran dry on the way (ivp_log.cpp decides what follows)
@@ -495,7 +506,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
                       &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1, &c->st_logoff,
-                      &c->log_pool, &c->log_alloc, &c->log_off, &c->log_bsum, &c->st_log_t, &c->st_log_y};
+                      &c->log_pool, &c->log_alloc, &c->def_rec, &c->log_off, &c->log_bsum, &c->st_log_t, &c->st_log_y};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -695,6 +706,12 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     a.flags = (uint32_t *)ctx->flags.p;
 
     a.n_eval = -1;
+    // Deferred t_eval sampling (kernel flavour 3): DOP853 with Options.t_eval and nothing else asked of the device DefaultSolOut,
+    // built-in thread-per-trajectory problems.  The stepping kernels note the sampled steps, a second kernel with one lane per
+    // noted step evaluates the dense stages and the samples (rk_core.h so_defer_samples / dop853_sample_body): in lock-step a
+    // wave pays DOP853's three dense stages whenever ANY of its trajectories has a sample in the step.
+    const bool defer_eval = want_eval && opt->method == IVP_DOP853 && !want_dense && n_events == 0 && !group && prob->rhs_id != IVP_RHS_JIT &&
+                            opt->n_eval > 0 && tune().defer_eval != 0;
     if (n_events > 0) {   // event state: prev_event, hit counters; outputs where given
         for (int i = 0; i < 4; ++i) { a.ev_direction[i] = opt->ev_direction[i]; a.ev_terminal[i] = opt->ev_terminal[i]; }
         if (opt->ev_direction_vec && opt->ev_terminal_vec && opt->n_event_cfg == n_events) {   // any number of event functions
@@ -731,6 +748,17 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
                 a.teval_off = (const unsigned long long *)ctx->teval_off.p;
                 a.teval_extra = n_events > 0 ? 1u : 0u;
             }
+        }
+        if (defer_eval) {   // noted steps: at most one per t_eval point of a trajectory (every noted step holds a sample)
+            uint64_t cap = (uint64_t)opt->n_eval;
+            if (opt->t_eval_offsets) {
+                cap = 0;
+                for (size_t b = 0; b < B; ++b) cap = std::max<uint64_t>(cap, opt->t_eval_offsets[b + 1] - opt->t_eval_offsets[b]);
+            }
+            cap = std::max<uint64_t>(cap, 1);
+            HIP_TRY(ctx, ctx->def_rec.reserve(sizeof(double) * (size_t)cap * (size_t)(2 * n + 5) * B));
+            a.def_rec = (double *)ctx->def_rec.p;
+            a.def_cap = (uint32_t)cap;
         }
         BIND(n_filled, out->n_filled, sc_n_filled, sizeof(int32_t) * B);
         BIND(n_log, out->n_log, sc_n_log, sizeof(uint32_t) * B);
@@ -822,7 +850,8 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     // enforcement, no dense-output segments, no event functions) -- then no interpolant is ever evaluated, the kernels skip
     // the dense-output coefficients and keep the registers (occupancy) of the end-state kernels
     const bool log_only = want_log && !want_eval && !want_dense && n_events == 0 && !opt->has_first_step;
-    P.full = log_only ? 2 : (full ? 1 : 0);
+    P.full = log_only ? 2 : (defer_eval ? 3 : (full ? 1 : 0));
+    P.sampled = false;
     P.group = group;
     P.jit = prob->rhs_id == IVP_RHS_JIT;
     P.has_settings = opt->has_settings != 0;

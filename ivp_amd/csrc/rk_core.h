@@ -1182,6 +1182,69 @@ IVP_HD void so_log_accepted(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, 
     if (L.n_log == 0 || fabs(L.t_last - x) > 1e-12) so_push_log<0, R::N, R::P, MAP>(a, j, L, x, y);
 }
 
+// FULL == 3, the DEFERRED-SAMPLING flavour (DOP853 with Options.t_eval and nothing else asked of DefaultSolOut: no event
+// functions, no dense-output collection).  DOP853's interpolant costs three more right-hand-side evaluations per step that is
+// sampled (dop853.rs:474-560); in lock-step a WAVE pays them whenever ANY of its 64 trajectories has a sample in the step --
+// with 128 samples per ~450 steps that is nearly every step (BASELINE C3: 12.8 -> 23.8 ms).  Here the stepping kernel only
+// NOTES a sampled step -- (x, h, y, k1), the t_eval indices it consumes and where its samples go (so_defer_samples) -- and
+// a second kernel with one lane per noted step (dop853_sample_body) redoes that step from (x, h, y, k1) with the very same
+// expressions, evaluates the dense stages and the polynomial and writes the samples: the same arithmetic per sampled step
+// as the reference, no union over a wave, every lane busy.  Record layout: def_rec[(k * F + f) * B + j], F = 2 n + 5 fields
+// x, h, first / end t_eval index, first output position, y[n], k1[n]; L.n_seg counts a trajectory's noted steps.
+template <int N, class MAP>
+IVP_HD void so_emit_eval_at(const IvpKArgs &a, uint32_t j, size_t k, int32_t ti, const double *yv)
+{
+    const size_t B = a.B;
+    if (a.teval_off != nullptr) {   // per-trajectory grids: time-major CSR records like Solution.y (Vec<Vec<f64>>)
+        const size_t q = (size_t)a.teval_off[j] + (size_t)j * a.teval_extra + k;
+#pragma unroll
+        for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_eval[q * MAP::NT + MAP::gi(c)] = yv[c];
+        if (a.eval_idx) a.eval_idx[q] = ti;
+    } else {
+#pragma unroll
+        for (int c = 0; c < N; ++c) if (MAP::own(c)) a.y_eval[(k * MAP::NT + MAP::gi(c)) * B + j] = yv[c];
+        if (a.eval_idx) a.eval_idx[k * B + j] = ti;
+    }
+}
+template <class R>
+IVP_HD void so_defer_samples(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
+                             const double *yold, const double *k1old, const double *ynew, double h)
+{
+    constexpr int N = R::N;
+    using MAP = typename OutMap<R>::type;
+    const double tol = 1e-12;
+    const EvalGrid grid = so_grid(a, j);
+    const int32_t ne = grid.n;
+    int32_t i = L.next_idx;
+    if (fabs(xold - x) <= tol) {   // solout.rs:349-356: no interpolant involved
+        while (i < ne && fabs(grid.t[i] - x) <= tol) { so_emit_eval<M_DOP853, N, R::P, MAP>(a, j, L, i, ynew); ++i; }
+        L.next_idx = i;
+        return;
+    }
+    const int32_t i0 = i;
+    int32_t cnt = 0;
+    if (x > xold) {                // the tests of so_sample (solout.rs:357-385), without the interpolation
+        while (i < ne && grid.t[i] <= x + tol) { if (grid.t[i] >= xold - tol) ++cnt; ++i; }
+    } else {
+        while (i < ne && grid.t[i] >= x - tol) { if (grid.t[i] <= xold + tol) ++cnt; ++i; }
+    }
+    if (cnt > 0) {
+        if (L.n_seg < a.def_cap) {
+            const size_t B = a.B;
+            double *rec = a.def_rec + (size_t)L.n_seg * (size_t)(2 * MAP::NT + 5) * B + j;
+            if (MAP::leader()) {
+                rec[0] = xold; rec[B] = h; rec[2 * B] = (double)i0; rec[3 * B] = (double)i; rec[4 * B] = (double)L.n_filled;
+            }
+#pragma unroll
+            for (int c = 0; c < N; ++c)
+                if (MAP::own(c)) { rec[(size_t)(5 + MAP::gi(c)) * B] = yold[c]; rec[(size_t)(5 + MAP::NT + MAP::gi(c)) * B] = k1old[c]; }
+        }
+        L.n_seg += 1;
+        L.n_filled += cnt;
+    }
+    L.next_idx = i;
+}
+
 // does the accepted step [xold, xph] need dense coefficients? (lazy DOP853 dense stages)
 template <int N, int P>
 IVP_HD bool so_needs_dense(const IvpKArgs &a, uint32_t j, const Lane<N, P> &L, double xold, double xph)
@@ -1345,6 +1408,7 @@ IVP_HD int32_t init_body(const IvpKArgs &a, uint32_t j)
     }
     if (FULL == 1) (void)solout_full<M, R>(a, j, L, L.x, L.x, L.y, (const double *)L.y, (const double *)nullptr, 0.0, L.x);
     else if (FULL == 2) so_log_accepted<R>(a, j, L, L.x, L.y);
+    else if (FULL == 3) so_sample<M, N, P, MAP>(a, j, L, L.x, L.x, L.y, (const double *)nullptr, 0.0, L.x);   // xold == x: no interpolant
 
 #pragma unroll
     for (int c = 0; c < N; ++c) { map_st<MAP>(a.y, c, B, j, L.y[c]); map_st<MAP>(a.k1, c, B, j, L.k1[c]); }
@@ -1545,6 +1609,217 @@ IVP_HD bool dopri5_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
     return true;
 }
 
+// Hairer's DOP853 coefficients (dop853.rs:674-848): shared by the stepping attempt and by the sample-parallel t_eval kernel
+// (dop853_sample_body), which redoes a recorded step with the very same expressions
+namespace dop853_tab {
+constexpr double C2 = 0.526001519587677318785587544488e-01, C3 = 0.789002279381515978178381316732e-01,
+                 C4 = 0.118350341907227396726757197510e+00, C5 = 0.281649658092772603273242802490e+00,
+                 C6 = 0.333333333333333333333333333333e+00, C7 = 0.25e+00, C8 = 0.307692307692307692307692307692e+00,
+                 C9 = 0.651282051282051282051282051282e+00, C10 = 0.6e+00, C11 = 0.857142857142857142857142857142e+00,
+                 C14 = 0.1e+00, C15 = 0.2e+00, C16 = 7.777777777777778e-1;
+constexpr double A21 = 5.26001519587677318785587544488e-2;
+constexpr double A31 = 1.97250569845378994544595329183e-2, A32 = 5.91751709536136983633785987549e-2;
+constexpr double A41 = 2.95875854768068491816892993775e-2, A43 = 8.87627564304205475450678981324e-2;
+constexpr double A51 = 2.41365134159266685502369798665e-1, A53 = -8.84549479328286085344864962717e-1, A54 = 9.24834003261792003115737966543e-1;
+constexpr double A61 = 3.7037037037037037037037037037e-2, A64 = 1.70828608729473871279604482173e-1, A65 = 1.25467687566822425016691814123e-1;
+constexpr double A71 = 3.7109375e-2, A74 = 1.70252211019544039314978060272e-1, A75 = 6.02165389804559606850219397283e-2, A76 = -1.7578125e-2;
+constexpr double A81 = 3.70920001185047927108779319836e-2, A84 = 1.70383925712239993810214054705e-1, A85 = 1.07262030446373284651809199168e-1,
+                 A86 = -1.53194377486244017527936158236e-2, A87 = 8.27378916381402288758473766002e-3;
+constexpr double A91 = 6.24110958716075717114429577812e-1, A94 = -3.36089262944694129406857109825e0, A95 = -8.68219346841726006818189891453e-1,
+                 A96 = 2.75920996994467083049415600797e1, A97 = 2.01540675504778934086186788979e1, A98 = -4.34898841810699588477366255144e1;
+constexpr double A101 = 4.77662536438264365890433908527e-1, A104 = -2.48811461997166764192642586468e0, A105 = -5.90290826836842996371446475743e-1,
+                 A106 = 2.12300514481811942347288949897e1, A107 = 1.52792336328824235832596922938e1, A108 = -3.32882109689848629194453265587e1,
+                 A109 = -2.03312017085086261358222928593e-2;
+constexpr double A111 = -9.3714243008598732571704021658e-1, A114 = 5.18637242884406370830023853209e0, A115 = 1.09143734899672957818500254654e0,
+                 A116 = -8.14978701074692612513997267357e0, A117 = -1.85200656599969598641566180701e1, A118 = 2.27394870993505042818970056734e1,
+                 A119 = 2.49360555267965238987089396762e0, A1110 = -3.0467644718982195003823669022e0;
+constexpr double A121 = 2.27331014751653820792359768449e0, A124 = -1.05344954667372501984066689879e1, A125 = -2.00087205822486249909675718444e0,
+                 A126 = -1.79589318631187989172765950534e1, A127 = 2.79488845294199600508499808837e1, A128 = -2.85899827713502369474065508674e0,
+                 A129 = -8.87285693353062954433549289258e0, A1210 = 1.23605671757943030647266201528e1, A1211 = 6.43392746015763530355970484046e-1;
+constexpr double B1 = 5.42937341165687622380535766363e-2, B6 = 4.45031289275240888144113950566e0, B7 = 1.89151789931450038304281599044e0,
+                 B8 = -5.8012039600105847814672114227e0, B9 = 3.1116436695781989440891606237e-1, B10 = -1.52160949662516078556178806805e-1,
+                 B11 = 2.01365400804030348374776537501e-1, B12 = 4.47106157277725905176885569043e-2;
+constexpr double BH1 = 0.244094488188976377952755905512e+00, BH2 = 0.733846688281611857341361741547e+00, BH3 = 0.220588235294117647058823529412e-01;
+constexpr double ER1 = 0.1312004499419488073250102996e-01, ER6 = -0.1225156446376204440720569753e+01, ER7 = -0.4957589496572501915214079952e+00,
+                 ER8 = 0.1664377182454986536961530415e+01, ER9 = -0.3503288487499736816886487290e+00, ER10 = 0.3341791187130174790297318841e+00,
+                 ER11 = 0.8192320648511571246570742613e-01, ER12 = -0.2235530786388629525884427845e-01;
+constexpr double A141 = 5.61675022830479523392909219681e-2, A147 = 2.53500210216624811088794765333e-1, A148 = -2.46239037470802489917441475441e-1,
+                 A149 = -1.24191423263816360469010140626e-1, A1410 = 1.5329179827876569731206322685e-1, A1411 = 8.20105229563468988491666602057e-3,
+                 A1412 = 7.56789766054569976138603589584e-3, A1413 = -8.298e-3;
+constexpr double A151 = 3.18346481635021405060768473261e-2, A156 = 2.83009096723667755288322961402e-2, A157 = 5.35419883074385676223797384372e-2,
+                 A158 = -5.49237485713909884646569340306e-2, A1511 = -1.08347328697249322858509316994e-4, A1512 = 3.82571090835658412954920192323e-4,
+                 A1513 = -3.40465008687404560802977114492e-4, A1514 = 1.41312443674632500278074618366e-1;
+constexpr double A161 = -4.28896301583791923408573538692e-1, A166 = -4.69762141536116384314449447206e0, A167 = 7.68342119606259904184240953878e0,
+                 A168 = 4.06898981839711007970213554331e0, A169 = 3.56727187455281109270669543021e-1, A1613 = -1.39902416515901462129418009734e-3,
+                 A1614 = 2.9475147891527723389556272149e0, A1615 = -9.15095847217987001081870187138e0;
+constexpr double D41 = -0.84289382761090128651353491142e+01, D46 = 0.56671495351937776962531783590e+00, D47 = -0.30689499459498916912797304727e+01,
+                 D48 = 0.23846676565120698287728149680e+01, D49 = 0.21170345824450282767155149946e+01, D410 = -0.87139158377797299206789907490e+00,
+                 D411 = 0.22404374302607882758541771650e+01, D412 = 0.63157877876946881815570249290e+00, D413 = -0.88990336451333310820698117400e-01,
+                 D414 = 0.18148505520854727256656404962e+02, D415 = -0.91946323924783554000451984436e+01, D416 = -0.44360363875948939664310572000e+01;
+constexpr double D51 = 0.10427508642579134603413151009e+02, D56 = 0.24228349177525818288430175319e+03, D57 = 0.16520045171727028198505394887e+03,
+                 D58 = -0.37454675472269020279518312152e+03, D59 = -0.22113666853125306036270938578e+02, D510 = 0.77334326684722638389603898808e+01,
+                 D511 = -0.30674084731089398182061213626e+02, D512 = -0.93321305264302278729567221706e+01, D513 = 0.15697238121770843886131091075e+02,
+                 D514 = -0.31139403219565177677282850411e+02, D515 = -0.93529243588444783865713862664e+01, D516 = 0.35816841486394083752465898540e+02;
+constexpr double D61 = 0.19985053242002433820987653617e+02, D66 = -0.38703730874935176555105901742e+03, D67 = -0.18917813819516756882830838328e+03,
+                 D68 = 0.52780815920542364900561016686e+03, D69 = -0.11573902539959630126141871134e+02, D610 = 0.68812326946963000169666922661e+01,
+                 D611 = -0.10006050966910838403183860980e+01, D612 = 0.77771377980534432092869265740e+00, D613 = -0.27782057523535084065932004339e+01,
+                 D614 = -0.60196695231264120758267380846e+02, D615 = 0.84320405506677161018159903784e+02, D616 = 0.11992291136182789328035130030e+02;
+constexpr double D71 = -0.25693933462703749003312586129e+02, D76 = -0.15418974869023643374053993627e+03, D77 = -0.23152937917604549567536039109e+03,
+                 D78 = 0.35763911791061412378285349910e+03, D79 = 0.93405324183624310003907691704e+02, D710 = -0.37458323136451633156875139351e+02,
+                 D711 = 0.10409964950896230045147246184e+03, D712 = 0.29840293426660503123344363579e+02, D713 = -0.43533456590011143754432175058e+02,
+                 D714 = 0.96324553959188282948394950600e+02, D715 = -0.39177261675615439165231486172e+02, D716 = -0.14972683625798562581422125276e+03;
+}  // namespace dop853_tab
+
+// ------------------------------------------------------------------------------------------------
+// One noted step of the deferred-sampling flavour (FULL == 3), redone by ONE lane: the stages, the eighth-order
+// solution and the new derivative exactly as dop853_attempt computes them (same expressions, same order: identical bits),
+// then the dense-output coefficients with their three extra stages (dop853.rs:474-592) and the samples the step holds
+// (solout.rs:357-385), written to the positions the stepping kernel reserved for them.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+IVP_HD void dop853_sample_body(const IvpKArgs &a, uint32_t j, uint32_t kd)
+{
+    KC_SCOPE
+    constexpr int N = R::N, P = R::P;
+    using namespace dop853_tab;
+    const size_t B = a.B;
+    const double *rec = a.def_rec + (size_t)kd * (size_t)(2 * N + 5) * B + j;
+    const double x = rec[0], h = rec[B];
+    const int32_t i0 = (int32_t)rec[2 * B], i1 = (int32_t)rec[3 * B];
+    size_t pos = (size_t)rec[4 * B];
+    double y[N], k1[N], p[P > 0 ? P : 1];
+#pragma unroll
+    for (int c = 0; c < N; ++c) { y[c] = rec[(size_t)(5 + c) * B]; k1[c] = rec[(size_t)(5 + N + c) * B]; }
+#pragma unroll
+    for (int c = 0; c < P; ++c) p[c] = a.params[c * B + j];
+    double k2[N], k3[N], k4[N], k5[N], k6[N], k7[N], k8[N], k9[N], k10[N], y1[N];
+{ const double cA21 = KC(A21);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h * cA21, k1[i]);
+}
+    R::ode(x + KC(C2) * h, y1, k2, p);
+{ const double cA31 = KC(A31), cA32 = KC(A32);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA31, k1[i], cA32, k2[i]));
+}
+    R::ode(x + KC(C3) * h, y1, k3, p);
+{ const double cA41 = KC(A41), cA43 = KC(A43);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA41, k1[i], cA43, k3[i]));
+}
+    R::ode(x + KC(C4) * h, y1, k4, p);
+{ const double cA51 = KC(A51), cA53 = KC(A53), cA54 = KC(A54);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA51, k1[i], cA53, k3[i], cA54, k4[i]));
+}
+    R::ode(x + KC(C5) * h, y1, k5, p);
+{ const double cA61 = KC(A61), cA64 = KC(A64), cA65 = KC(A65);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA61, k1[i], cA64, k4[i], cA65, k5[i]));
+}
+    R::ode(x + KC(C6) * h, y1, k6, p);
+{ const double cA71 = KC(A71), cA74 = KC(A74), cA75 = KC(A75), cA76 = KC(A76);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA71, k1[i], cA74, k4[i], cA75, k5[i], cA76, k6[i]));
+}
+    R::ode(x + KC(C7) * h, y1, k7, p);
+{ const double cA81 = KC(A81), cA84 = KC(A84), cA85 = KC(A85), cA86 = KC(A86), cA87 = KC(A87);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = IVP_MA(y[i], h, IVP_LC(cA81, k1[i], cA84, k4[i], cA85, k5[i], cA86, k6[i], cA87, k7[i]));
+}
+    R::ode(x + KC(C8) * h, y1, k8, p);
+{ const double cA91 = KC(A91), cA94 = KC(A94), cA95 = KC(A95), cA96 = KC(A96), cA97 = KC(A97), cA98 = KC(A98);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA91, k1[i], cA94, k4[i], cA95, k5[i], cA96, k6[i], cA97, k7[i], cA98, k8[i]));
+}
+    R::ode(x + KC(C9) * h, y1, k9, p);
+{ const double cA101 = KC(A101), cA104 = KC(A104), cA105 = KC(A105), cA106 = KC(A106), cA107 = KC(A107), cA108 = KC(A108), cA109 = KC(A109);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA101, k1[i], cA104, k4[i], cA105, k5[i], cA106, k6[i], cA107, k7[i], cA108, k8[i], cA109, k9[i]));
+}
+    R::ode(x + KC(C10) * h, y1, k10, p);
+{ const double cA111 = KC(A111), cA114 = KC(A114), cA115 = KC(A115), cA116 = KC(A116), cA117 = KC(A117), cA118 = KC(A118), cA119 = KC(A119), cA1110 = KC(A1110);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA111, k1[i], cA114, k4[i], cA115, k5[i], cA116, k6[i], cA117, k7[i], cA118, k8[i], cA119, k9[i], cA1110, k10[i]));
+}
+    R::ode(x + KC(C11) * h, y1, k2, p);
+    const double xph = x + h;
+{ const double cA121 = KC(A121), cA124 = KC(A124), cA125 = KC(A125), cA126 = KC(A126), cA127 = KC(A127), cA128 = KC(A128), cA129 = KC(A129), cA1210 = KC(A1210), cA1211 = KC(A1211);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA121, k1[i], cA124, k4[i], cA125, k5[i], cA126, k6[i], cA127, k7[i], cA128, k8[i], cA129, k9[i],
+                                       cA1210, k10[i], cA1211, k2[i]));
+}
+    R::ode(xph, y1, k3, p);
+
+{ const double cB1 = KC(B1), cB6 = KC(B6), cB7 = KC(B7), cB8 = KC(B8), cB9 = KC(B9), cB10 = KC(B10), cB11 = KC(B11), cB12 = KC(B12);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        k4[i] = IVP_LC(cB1, k1[i], cB6, k6[i], cB7, k7[i], cB8, k8[i], cB9, k9[i], cB10, k10[i], cB11, k2[i], cB12, k3[i]);
+        k5[i] = IVP_MA(y[i], h, k4[i]);
+    }
+}
+    R::ode(xph, k5, k4, p);   // the new derivative (dop853.rs:443)
+    ContRegs<8 * N> cont;
+{ const double cD41 = KC(D41), cD46 = KC(D46), cD47 = KC(D47), cD48 = KC(D48), cD49 = KC(D49), cD410 = KC(D410), cD411 = KC(D411), cD412 = KC(D412), cD51 = KC(D51), cD56 = KC(D56), cD57 = KC(D57), cD58 = KC(D58), cD59 = KC(D59), cD510 = KC(D510), cD511 = KC(D511), cD512 = KC(D512), cD61 = KC(D61), cD66 = KC(D66), cD67 = KC(D67), cD68 = KC(D68), cD69 = KC(D69), cD610 = KC(D610), cD611 = KC(D611), cD612 = KC(D612), cD71 = KC(D71), cD76 = KC(D76), cD77 = KC(D77), cD78 = KC(D78), cD79 = KC(D79), cD710 = KC(D710), cD711 = KC(D711), cD712 = KC(D712);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cont.set(i, y[i]);
+        const double ydiff = k5[i] - y[i];
+        cont.set(N + i, ydiff);
+        const double bspl = IVP_MB(h, k1[i], ydiff);
+        cont.set(2 * N + i, bspl);
+        cont.set(3 * N + i, IVP_MS(ydiff, h, k4[i]) - bspl);
+        cont.set(4 * N + i, IVP_LC(cD41, k1[i], cD46, k6[i], cD47, k7[i], cD48, k8[i], cD49, k9[i], cD410, k10[i], cD411, k2[i], cD412, k3[i]));
+        cont.set(5 * N + i, IVP_LC(cD51, k1[i], cD56, k6[i], cD57, k7[i], cD58, k8[i], cD59, k9[i], cD510, k10[i], cD511, k2[i], cD512, k3[i]));
+        cont.set(6 * N + i, IVP_LC(cD61, k1[i], cD66, k6[i], cD67, k7[i], cD68, k8[i], cD69, k9[i], cD610, k10[i], cD611, k2[i], cD612, k3[i]));
+        cont.set(7 * N + i, IVP_LC(cD71, k1[i], cD76, k6[i], cD77, k7[i], cD78, k8[i], cD79, k9[i], cD710, k10[i], cD711, k2[i], cD712, k3[i]));
+    }
+}
+{ const double cA141 = KC(A141), cA147 = KC(A147), cA148 = KC(A148), cA149 = KC(A149), cA1410 = KC(A1410), cA1411 = KC(A1411), cA1412 = KC(A1412), cA1413 = KC(A1413);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA141, k1[i], cA147, k7[i], cA148, k8[i], cA149, k9[i], cA1410, k10[i], cA1411, k2[i], cA1412, k3[i], cA1413, k4[i]));
+}
+    R::ode(x + KC(C14) * h, y1, k10, p);
+{ const double cA151 = KC(A151), cA156 = KC(A156), cA157 = KC(A157), cA158 = KC(A158), cA1511 = KC(A1511), cA1512 = KC(A1512), cA1513 = KC(A1513), cA1514 = KC(A1514);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA151, k1[i], cA156, k6[i], cA157, k7[i], cA158, k8[i], cA1511, k2[i], cA1512, k3[i], cA1513, k4[i], cA1514, k10[i]));
+}
+    R::ode(x + KC(C15) * h, y1, k2, p);
+{ const double cA161 = KC(A161), cA166 = KC(A166), cA167 = KC(A167), cA168 = KC(A168), cA169 = KC(A169), cA1613 = KC(A1613), cA1614 = KC(A1614), cA1615 = KC(A1615);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y1[i] = IVP_MA(y[i], h, IVP_LC(cA161, k1[i], cA166, k6[i], cA167, k7[i], cA168, k8[i], cA169, k9[i], cA1613, k4[i], cA1614, k10[i], cA1615, k2[i]));
+}
+    R::ode(x + KC(C16) * h, y1, k3, p);
+{ const double cD413 = KC(D413), cD414 = KC(D414), cD415 = KC(D415), cD416 = KC(D416), cD513 = KC(D513), cD514 = KC(D514), cD515 = KC(D515), cD516 = KC(D516), cD613 = KC(D613), cD614 = KC(D614), cD615 = KC(D615), cD616 = KC(D616), cD713 = KC(D713), cD714 = KC(D714), cD715 = KC(D715), cD716 = KC(D716);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cont.set(4 * N + i, h * IVP_NS::ivp_lc(cont[4 * N + i], cD413, k4[i], cD414, k10[i], cD415, k2[i], cD416, k3[i]));
+        cont.set(5 * N + i, h * IVP_NS::ivp_lc(cont[5 * N + i], cD513, k4[i], cD514, k10[i], cD515, k2[i], cD516, k3[i]));
+        cont.set(6 * N + i, h * IVP_NS::ivp_lc(cont[6 * N + i], cD613, k4[i], cD614, k10[i], cD615, k2[i], cD616, k3[i]));
+        cont.set(7 * N + i, h * IVP_NS::ivp_lc(cont[7 * N + i], cD713, k4[i], cD714, k10[i], cD715, k2[i], cD716, k3[i]));
+    }
+}
+    // the samples of this step, in t_eval order (the tests of so_sample; the stepping kernel counted with the same ones)
+    const double tol = 1e-12;
+    const EvalGrid grid = so_grid(a, j);
+    double yi[N];
+    for (int32_t i = i0; i < i1; ++i) {
+        const double te = grid.t[i];
+        if (xph > x ? (te >= x - tol) : (te <= x + tol)) {
+            interpolate<M_DOP853, N>(te, yi, cont, x, h);
+            so_emit_eval_at<N, IdMap<N>>(a, j, pos, i, yi);
+            ++pos;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // DOP853 attempt (dop853.rs:272-653)
 // ------------------------------------------------------------------------------------------------
@@ -1553,63 +1828,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
 {
     KC_SCOPE_KZ(L.kz)
     constexpr int N = R::N, P = R::P;
-    // Hairer's DOP853 coefficients, dop853.rs:674-848
-    constexpr double C2 = 0.526001519587677318785587544488e-01, C3 = 0.789002279381515978178381316732e-01,
-                     C4 = 0.118350341907227396726757197510e+00, C5 = 0.281649658092772603273242802490e+00,
-                     C6 = 0.333333333333333333333333333333e+00, C7 = 0.25e+00, C8 = 0.307692307692307692307692307692e+00,
-                     C9 = 0.651282051282051282051282051282e+00, C10 = 0.6e+00, C11 = 0.857142857142857142857142857142e+00,
-                     C14 = 0.1e+00, C15 = 0.2e+00, C16 = 7.777777777777778e-1;
-    constexpr double A21 = 5.26001519587677318785587544488e-2;
-    constexpr double A31 = 1.97250569845378994544595329183e-2, A32 = 5.91751709536136983633785987549e-2;
-    constexpr double A41 = 2.95875854768068491816892993775e-2, A43 = 8.87627564304205475450678981324e-2;
-    constexpr double A51 = 2.41365134159266685502369798665e-1, A53 = -8.84549479328286085344864962717e-1, A54 = 9.24834003261792003115737966543e-1;
-    constexpr double A61 = 3.7037037037037037037037037037e-2, A64 = 1.70828608729473871279604482173e-1, A65 = 1.25467687566822425016691814123e-1;
-    constexpr double A71 = 3.7109375e-2, A74 = 1.70252211019544039314978060272e-1, A75 = 6.02165389804559606850219397283e-2, A76 = -1.7578125e-2;
-    constexpr double A81 = 3.70920001185047927108779319836e-2, A84 = 1.70383925712239993810214054705e-1, A85 = 1.07262030446373284651809199168e-1,
-                     A86 = -1.53194377486244017527936158236e-2, A87 = 8.27378916381402288758473766002e-3;
-    constexpr double A91 = 6.24110958716075717114429577812e-1, A94 = -3.36089262944694129406857109825e0, A95 = -8.68219346841726006818189891453e-1,
-                     A96 = 2.75920996994467083049415600797e1, A97 = 2.01540675504778934086186788979e1, A98 = -4.34898841810699588477366255144e1;
-    constexpr double A101 = 4.77662536438264365890433908527e-1, A104 = -2.48811461997166764192642586468e0, A105 = -5.90290826836842996371446475743e-1,
-                     A106 = 2.12300514481811942347288949897e1, A107 = 1.52792336328824235832596922938e1, A108 = -3.32882109689848629194453265587e1,
-                     A109 = -2.03312017085086261358222928593e-2;
-    constexpr double A111 = -9.3714243008598732571704021658e-1, A114 = 5.18637242884406370830023853209e0, A115 = 1.09143734899672957818500254654e0,
-                     A116 = -8.14978701074692612513997267357e0, A117 = -1.85200656599969598641566180701e1, A118 = 2.27394870993505042818970056734e1,
-                     A119 = 2.49360555267965238987089396762e0, A1110 = -3.0467644718982195003823669022e0;
-    constexpr double A121 = 2.27331014751653820792359768449e0, A124 = -1.05344954667372501984066689879e1, A125 = -2.00087205822486249909675718444e0,
-                     A126 = -1.79589318631187989172765950534e1, A127 = 2.79488845294199600508499808837e1, A128 = -2.85899827713502369474065508674e0,
-                     A129 = -8.87285693353062954433549289258e0, A1210 = 1.23605671757943030647266201528e1, A1211 = 6.43392746015763530355970484046e-1;
-    constexpr double B1 = 5.42937341165687622380535766363e-2, B6 = 4.45031289275240888144113950566e0, B7 = 1.89151789931450038304281599044e0,
-                     B8 = -5.8012039600105847814672114227e0, B9 = 3.1116436695781989440891606237e-1, B10 = -1.52160949662516078556178806805e-1,
-                     B11 = 2.01365400804030348374776537501e-1, B12 = 4.47106157277725905176885569043e-2;
-    constexpr double BH1 = 0.244094488188976377952755905512e+00, BH2 = 0.733846688281611857341361741547e+00, BH3 = 0.220588235294117647058823529412e-01;
-    constexpr double ER1 = 0.1312004499419488073250102996e-01, ER6 = -0.1225156446376204440720569753e+01, ER7 = -0.4957589496572501915214079952e+00,
-                     ER8 = 0.1664377182454986536961530415e+01, ER9 = -0.3503288487499736816886487290e+00, ER10 = 0.3341791187130174790297318841e+00,
-                     ER11 = 0.8192320648511571246570742613e-01, ER12 = -0.2235530786388629525884427845e-01;
-    constexpr double A141 = 5.61675022830479523392909219681e-2, A147 = 2.53500210216624811088794765333e-1, A148 = -2.46239037470802489917441475441e-1,
-                     A149 = -1.24191423263816360469010140626e-1, A1410 = 1.5329179827876569731206322685e-1, A1411 = 8.20105229563468988491666602057e-3,
-                     A1412 = 7.56789766054569976138603589584e-3, A1413 = -8.298e-3;
-    constexpr double A151 = 3.18346481635021405060768473261e-2, A156 = 2.83009096723667755288322961402e-2, A157 = 5.35419883074385676223797384372e-2,
-                     A158 = -5.49237485713909884646569340306e-2, A1511 = -1.08347328697249322858509316994e-4, A1512 = 3.82571090835658412954920192323e-4,
-                     A1513 = -3.40465008687404560802977114492e-4, A1514 = 1.41312443674632500278074618366e-1;
-    constexpr double A161 = -4.28896301583791923408573538692e-1, A166 = -4.69762141536116384314449447206e0, A167 = 7.68342119606259904184240953878e0,
-                     A168 = 4.06898981839711007970213554331e0, A169 = 3.56727187455281109270669543021e-1, A1613 = -1.39902416515901462129418009734e-3,
-                     A1614 = 2.9475147891527723389556272149e0, A1615 = -9.15095847217987001081870187138e0;
-    constexpr double D41 = -0.84289382761090128651353491142e+01, D46 = 0.56671495351937776962531783590e+00, D47 = -0.30689499459498916912797304727e+01,
-                     D48 = 0.23846676565120698287728149680e+01, D49 = 0.21170345824450282767155149946e+01, D410 = -0.87139158377797299206789907490e+00,
-                     D411 = 0.22404374302607882758541771650e+01, D412 = 0.63157877876946881815570249290e+00, D413 = -0.88990336451333310820698117400e-01,
-                     D414 = 0.18148505520854727256656404962e+02, D415 = -0.91946323924783554000451984436e+01, D416 = -0.44360363875948939664310572000e+01;
-    constexpr double D51 = 0.10427508642579134603413151009e+02, D56 = 0.24228349177525818288430175319e+03, D57 = 0.16520045171727028198505394887e+03,
-                     D58 = -0.37454675472269020279518312152e+03, D59 = -0.22113666853125306036270938578e+02, D510 = 0.77334326684722638389603898808e+01,
-                     D511 = -0.30674084731089398182061213626e+02, D512 = -0.93321305264302278729567221706e+01, D513 = 0.15697238121770843886131091075e+02,
-                     D514 = -0.31139403219565177677282850411e+02, D515 = -0.93529243588444783865713862664e+01, D516 = 0.35816841486394083752465898540e+02;
-    constexpr double D61 = 0.19985053242002433820987653617e+02, D66 = -0.38703730874935176555105901742e+03, D67 = -0.18917813819516756882830838328e+03,
-                     D68 = 0.52780815920542364900561016686e+03, D69 = -0.11573902539959630126141871134e+02, D610 = 0.68812326946963000169666922661e+01,
-                     D611 = -0.10006050966910838403183860980e+01, D612 = 0.77771377980534432092869265740e+00, D613 = -0.27782057523535084065932004339e+01,
-                     D614 = -0.60196695231264120758267380846e+02, D615 = 0.84320405506677161018159903784e+02, D616 = 0.11992291136182789328035130030e+02;
-    constexpr double D71 = -0.25693933462703749003312586129e+02, D76 = -0.15418974869023643374053993627e+03, D77 = -0.23152937917604549567536039109e+03,
-                     D78 = 0.35763911791061412378285349910e+03, D79 = 0.93405324183624310003907691704e+02, D710 = -0.37458323136451633156875139351e+02,
-                     D711 = 0.10409964950896230045147246184e+03, D712 = 0.29840293426660503123344363579e+02, D713 = -0.43533456590011143754432175058e+02,
-                     D714 = 0.96324553959188282948394950600e+02, D715 = -0.39177261675615439165231486172e+02, D716 = -0.14972683625798562581422125276e+03;
+    using namespace dop853_tab;
     // struct defaults (dop853.rs:34-63)
     constexpr double d_uround = 2.3e-16, d_safety = 0.9, d_beta = 0.0;   // dop853.rs:34-63
     constexpr double d_facc1 = 1.0 / 0.333, d_facc2 = 1.0 / 6.0;
@@ -1792,6 +2011,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
             }
 }
         }
+        if (FULL == 3) so_defer_samples<R>(a, j, L, x, xph, y, k1, k5, h);   // before y / k1 (= L.y / L.k1) move on
 #pragma unroll
         for (int i = 0; i < N; ++i) { L.k1[i] = k4[i]; L.y[i] = k5[i]; }
         L.x = xph;

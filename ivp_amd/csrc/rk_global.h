@@ -38,6 +38,17 @@ __global__ __launch_bounds__(IVP_WAVE) void init_kernel_t(const IvpKArgs a)
     if (a.perm_out) compact_append(a, i, valid && st == IVP_RUNNING);
 }
 
+// Deferred t_eval sampling (flavour 3): one lane per noted step.  blockIdx.x tiles the trajectories (consecutive lanes,
+// consecutive trajectories: the record fields are read coalesced), blockIdx.y strides over a trajectory's noted steps.
+template <class R>
+__global__ __launch_bounds__(IVP_WAVE) void sample_kernel_t(const IvpKArgs a)
+{
+    const uint32_t j = blockIdx.x * IVP_WAVE + threadIdx.x;
+    if (j >= a.B) return;
+    const uint32_t nd = min(a.n_seg[j], a.def_cap);
+    for (uint32_t k = blockIdx.y; k < nd; k += gridDim.y) dop853_sample_body<R>(a, j, k);
+}
+
 template <int M, class R, int FULL, bool CTL = false>
 __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 {

@@ -77,6 +77,9 @@ hipError_t launch_coop_flavour(int full, const IvpKArgs &a, uint32_t n, hipStrea
         return launch_coop_one<M, R, 1>(a, n, s);
     } else {
         if (full == 2) return launch_coop_one<M, R, 2>(a, n, s);   // log-only flavour (rk_core.h so_log_accepted)
+        if constexpr (M == IVP_NS::M_DOP853) {
+            if (full == 3) return launch_coop_one<M, R, 3>(a, n, s);   // deferred t_eval sampling (rk_core.h so_defer_samples)
+        }
         return full ? launch_coop_one<M, R, 1>(a, n, s) : launch_coop_one<M, R, 0>(a, n, s);
     }
 }

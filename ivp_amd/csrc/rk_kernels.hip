@@ -73,6 +73,20 @@ hipError_t launch_flavour(int what, int full, const IvpKArgs &a, uint32_t lanes,
     if constexpr (R::NE == 0 && M != M_RK4) {
         if (full == 2) return launch_one<M, R, 2>(what, a, lanes, s);
     }
+    if constexpr (R::NE == 0 && M == M_DOP853) {
+        if (full == 3) {
+#if !IVP_HOIST
+            if (what == IVP_LAUNCH_SAMPLE) {   // one lane per noted step: grid.y strides over a trajectory's noted steps
+                const dim3 grid((lanes + IVP_WAVE - 1) / IVP_WAVE, 8), block(IVP_WAVE);
+                (void)hipGetLastError();
+                hipLaunchKernelGGL((sample_kernel_t<R>), grid, block, 0, s, a);
+                return hipGetLastError();
+            }
+#endif
+            return launch_one<M, R, 3>(what, a, lanes, s);
+        }
+    }
+    if (what == IVP_LAUNCH_SAMPLE) return hipErrorInvalidValue;
     return full ? launch_one<M, R, 1>(what, a, lanes, s) : launch_one<M, R, 0>(what, a, lanes, s);
 }
 

@@ -7,11 +7,14 @@
 // trajectories into a wavefront, everything larger (and every built-in) uses the whole wavefront
 static inline int ivp_group_width(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
 
-enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1, IVP_LAUNCH_COOP = 2 /* hiprtc modules only */ };
+enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1, IVP_LAUNCH_COOP = 2 /* hiprtc modules only */,
+       IVP_LAUNCH_SAMPLE = 3 /* flavour 3's second kernel: one lane per noted step (rk_global.h sample_kernel_t; lean builds, DOP853) */ };
 
 // `lanes` = upper bound of trajectories the launch has to cover (grid = ceil(lanes / 64) one-wave blocks).
 // `full` = flavour of the kernel: 0 end state only, 1 the whole device DefaultSolOut, 2 log-only (every accepted step recorded,
-// nothing else: no interpolant -- rk_core.h so_log_accepted); tables that do not carry flavour 2 run it as flavour 1.
+// nothing else: no interpolant -- rk_core.h so_log_accepted), 3 deferred t_eval sampling (DOP853, built-in problems without
+// event functions: the stepping kernel notes the sampled steps, IVP_LAUNCH_SAMPLE evaluates them -- rk_core.h
+// so_defer_samples); tables that do not carry flavour 2 / 3 run them as flavour 1 (the host never asks them for 3).
 hipError_t ivp_launch_strict(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 hipError_t ivp_launch_strict_hoist(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);
 hipError_t ivp_launch_fast_hoist(int what, int method, int rhs_id, int full, const IvpKArgs &a, uint32_t lanes, hipStream_t s);

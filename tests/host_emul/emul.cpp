@@ -43,6 +43,14 @@ static void run_flavour(int full, const IvpKArgs &a, uint64_t *chunks)
     if constexpr (R::NE == 0 && (M == M_RK23 || M == M_DOPRI5 || M == M_DOP853)) {
         if (full == 2) { run_all<M, R, 2>(a, chunks); return; }
     }
+    if constexpr (R::NE == 0 && M == M_DOP853) {
+        if (full == 3) {   // deferred t_eval sampling: the stepping bodies note the sampled steps, then one "lane" per noted step
+            run_all<M, R, 3>(a, chunks);
+            for (uint32_t j = 0; j < a.B; ++j)
+                for (uint32_t k = 0; k < a.n_seg[j] && k < a.def_cap; ++k) dop853_sample_body<R>(a, j, k);
+            return;
+        }
+    }
     full ? run_all<M, R, 1>(a, chunks) : run_all<M, R, 0>(a, chunks);
 }
 

@@ -41,6 +41,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("spec_cap", C.c_uint32), ("spec_min", C.c_uint32), ("ran_out", VP), ("lds_lu", C.c_uint32), ("lpw", C.c_uint32),
         ("count_next", VP),
         ("window", C.c_uint32),
+        ("def_rec", VP), ("def_cap", C.c_uint32),
         ("log_pool", VP), ("log_region", C.c_uint64), ("log_sub_mask", C.c_uint32), ("log_alloc", VP),
     ]
 
@@ -79,7 +80,7 @@ def lib(fast=False):
 
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
                 first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False,
-                event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None, flavour_log_only=True):
+                event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None, flavour_log_only=True, defer_eval=True):
     """``paged_log=pool_doubles``: the one-pass step log -- records go to wave pages in a pool of that many doubles, chained
     per trajectory (ivp_kargs.h; on the host a "wave" is one lane, so every page has one column); ``res['log_pool']``,
     ``res['log_cur']``, ``res['log_used']`` (doubles) and ``res['log_overflow']`` come back next to ``n_log``
@@ -183,6 +184,12 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     # asked of the device DefaultSolOut
     log_only = full and t_eval is None and not dense_output and ne_ev == 0 and first_step is None and (max_log > 0 or paged_log is not None)
     flavour = 2 if (log_only and flavour_log_only) else int(full)
+    # ... deferred t_eval sampling (flavour 3): DOP853 with t_eval and nothing else asked of the device DefaultSolOut
+    if m == 2 and t_eval is not None and len(np.atleast_1d(t_eval)) > 0 and not dense_output and ne_ev == 0 and defer_eval:
+        flavour = 3
+        cap = max(len(np.atleast_1d(t_eval)), 1)
+        res["def_rec"] = np.full((cap, 2 * n + 5, B), np.nan)
+        a.def_rec, a.def_cap = p(res["def_rec"]), cap
     rc = L.emul_solve(m, rid, flavour, C.byref(a), C.byref(chunks))
     if rc == -5:
         raise ValueError("IVP_ERR_INVALID_STEP_SIZE")

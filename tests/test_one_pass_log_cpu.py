@@ -101,3 +101,29 @@ def test_zero_length_interval_and_nan_interval_lanes():
     td, yd = _dense_as_csr(dense)
     assert np.array_equal(_bits(t), _bits(td)) and np.array_equal(_bits(y), _bits(yd))
     assert paged["n_log"][2] == 0
+
+
+@pytest.mark.parametrize("rhs,make,rtol", [("vdp", lambda: W.vdp_batch(30), 1e-8), ("cr3bp", lambda: W.cr3bp_batch(10), 1e-9)])
+@pytest.mark.parametrize("chunk", [1, 64])
+def test_deferred_t_eval_sampling_equals_sampling_in_the_stepping_bodies(rhs, make, rtol, chunk):
+    """Kernel flavour 3 (DOP853 + t_eval): the stepping bodies only note the sampled steps, dop853_sample_body redoes each
+    noted step from (x, h, y, k1) and evaluates dense stages + samples.  Same expressions, same order: the samples are the
+    bits the in-line sampling (flavour 1) and the oracle produce -- unsorted grids, repeated points, points outside the span
+    and backward integration included."""
+    y0, p, t0, t1 = make()
+    t1s = float(np.max(t1))
+    te = np.concatenate([np.linspace(0.0, t1s, 41), [0.3 * t1s, 0.3 * t1s, -1.0, 2.0 * t1s, 0.05 * t1s]])
+    kw = dict(method="DOP853", rtol=rtol, atol=1e-11, t_eval=te, chunk=chunk)
+    inline = emul_batch(rhs, y0, p, t0, t1, defer_eval=False, **kw)
+    deferred = emul_batch(rhs, y0, p, t0, t1, **kw)
+    assert "def_rec" in deferred and "def_rec" not in inline
+    for k in ("n_filled", "eval_idx", "status", "nfev", "naccpt"):
+        assert np.array_equal(deferred[k], inline[k]), k
+    for k in ("y_eval", "y_end", "t_end", "h_next"):
+        assert np.array_equal(_bits(deferred[k]), _bits(inline[k])), k
+    assert int(deferred["n_filled"].min()) > 10
+    # backward in time, a grid running backward
+    back = dict(method="DOP853", rtol=rtol, atol=1e-11, t_eval=np.linspace(t1s, 0.0, 23)[1:], chunk=chunk)
+    a = emul_batch(rhs, y0, p, t1s, 0.0, defer_eval=False, **back)
+    b = emul_batch(rhs, y0, p, t1s, 0.0, **back)
+    assert np.array_equal(a["n_filled"], b["n_filled"]) and np.array_equal(_bits(a["y_eval"]), _bits(b["y_eval"])) and int(b["n_filled"].max()) == 22
