@@ -32,10 +32,16 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+# the CPU baseline's OpenMP runtime reads these when the oracle library is first loaded: one thread per core, spread over the sockets
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+from kernel_sha import kernel_sources_sha256  # noqa: E402
 
+PROFILE_ROUND = "r04"        # the counter profiles under profiles/ this file reads (each carries the hash of the kernels it was taken on)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (FMA = 2 flop), SURVEY.md section 8d
 # Algorithmic work of ONE DOPRI5 step attempt on the 6-state CR3BP system:
@@ -109,8 +115,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...` (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -119,6 +125,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     import ivp_amd
     from ivp_amd import workloads as W
@@ -229,17 +236,23 @@ def main():
         bytes_per_launch = lanes_per_launch * bytes_per_lane_launch(n_state, prob.n_params, args.workload)
         gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         tflops = (attempts_per_launch * flop_per_attempt / (avg_launch_ms * 1e-3) / 1e12) if (avg_launch_ms > 0 and flop_per_attempt) else None
+        # PMC-derived figures come from committed profiles of this command (separate rocprofv3 --pmc passes: counters cannot be
+        # collected inside a timed run).  Each profile is stamped with the hash of the kernel sources it was taken on; a
+        # profile of OTHER kernels than the ones just timed is reported as stale and nothing is derived from it.
+        sha_now = kernel_sources_sha256()
         traffic = traffic_src = None
-        pmc_name = f"r03_pmc_hbm_bytes_per_launch_{args.fp}.json"
-        if not os.path.exists(os.path.join(ROOT, "profiles", pmc_name)) and args.fp == "strict":
-            pmc_name = "pmc_hbm_bytes_per_launch.json"          # round 2's pass (the strict kernels' traffic has not changed)
+        traffic_stale = None
+        pmc_name = f"{PROFILE_ROUND}_pmc_hbm_bytes_per_launch_{args.fp}.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc) and args.workload == "c2" and world == 1 and B == 100_000:
             try:
                 j = json.load(open(pmc))
-                traffic = j.get("hbm_bytes_per_launch")
+                traffic_stale = j.get("kernel_sources_sha256") != sha_now
+                if not traffic_stale:
+                    traffic = j.get("hbm_bytes_per_launch")
                 traffic_src = f"profiles/{pmc_name} (" + str(j.get("run", "rocprofv3 --pmc passes of tools/profile_c2.sh")) + \
-                              "): PMC counters of a separate profiled run of this command, not of this process"
+                              "): PMC counters of a separate profiled run of this command, not of this process" + \
+                              ("; STALE: taken on other kernel sources than this run's (hash mismatch), not used" if traffic_stale else "")
             except Exception:
                 traffic = None
         # VALU issue view of the dominant kernel: the thread-per-trajectory stepping kernel is bound by vector-instruction
@@ -248,15 +261,15 @@ def main():
         # come from the committed SQ-counter profile of this command (profiles/r03_sq_counters_<workload>_<fp>.json,
         # SQ_INSTS_VALU, tools/profile_sq.sh), the launch duration is this run's.
         issue = None
-        sq_name = f"r03_sq_counters_{args.workload}_{args.fp}.json"
-        if not os.path.exists(os.path.join(ROOT, "profiles", sq_name)) and args.fp == "strict":
-            sq_name = f"r02_sq_counters_{args.workload}.json"
+        sq_name = f"{PROFILE_ROUND}_sq_counters_{args.workload}_{args.fp}.json"
         sqf = os.path.join(ROOT, "profiles", sq_name)
         chunk_launches = launches - coop_launches
         chunk_ms = (kern_ms - coop_ms) / max(chunk_launches, 1)
         if os.path.exists(sqf) and world == 1 and B == wl["B"] and chunk_ms > 0:
             try:
                 sq = json.load(open(sqf))
+                if sq.get("kernel_sources_sha256") != sha_now:
+                    raise LookupError("stale")
                 ent = next(v for k, v in sq.items() if "chunk_kernel_t" in k and "coop" not in k)
                 valu = float(ent["mean_per_dispatch"]["SQ_INSTS_VALU"])
                 if "per_solve" in ent:   # instructions of a whole solve / this run's launches per solve: robust against a
@@ -267,8 +280,12 @@ def main():
                          "avg_launch_ms": chunk_ms,
                          "source": f"profiles/{sq_name} (SQ_INSTS_VALU per launch, separate rocprofv3 --pmc "
                                    "run of this command) / this run's launch duration"}
+            except LookupError:
+                issue = {"bound": "valu_issue", "kernel": "chunk_kernel_t", "stale": True,
+                         "source": f"profiles/{sq_name}: taken on other kernel sources than this run's (hash mismatch), nothing derived"}
             except Exception:
                 issue = None
+        fp64_frac = (tflops / FP64_PEAK_TFLOPS) if tflops is not None else None
         res = {
             "metric": wl["metric"],
             "value": value,
@@ -304,7 +321,15 @@ def main():
             "attempts_per_s": attempts / el * 1.0, "rejection_ratio": nrej_rank / max(nstep_rank, 1.0),
             "roofline": {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                # the resource that actually bounds this path: FP64 vector arithmetic, counted flops of the
+                # whole solve over its wall time -- the HBM figures above are what north_star asks to be reported, and small
+                "binding": {"bound": "valu_fp64", "achieved": (attempts * flop_per_attempt / elapsed / 1e12) if flop_per_attempt else None,
+                            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": (attempts * flop_per_attempt / elapsed / 1e12 / FP64_PEAK_TFLOPS) if flop_per_attempt else None,
+                            "kernel_time_frac": fp64_frac,
+                            "note": "algorithmic flops of every step attempt of one solve / wall time of the solve; kernel_time_frac: the same "
+                                    "flops / time inside the stepping kernels"},
                 "kernel": wl["kernel"], "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": launches / args.steps,
                 # per kernel name, for a one-to-one check against the rocprofv3 --kernel-trace --stats rows
@@ -330,18 +355,23 @@ def main():
                 "attempts_per_launch": attempts_per_launch,
             },
             "roofline_issue": issue,
+            "kernel_sources_sha256": sha_now,
         }
+        if world > 1:
+            res["rccl_ranks"] = dist.get_world_size()
         if weak is not None:
             res["weak"] = weak
         if world > 1:
             # the builder's own single-GPU prediction of this curve, on the record next to the measured number
             # (every rank's shard timed alone on one MI355X; max over ranks = what the job takes, gather excluded)
             try:
-                pred = json.load(open(os.path.join(ROOT, "profiles", "r02_strong_scaling_prediction.json")))
-                res["strong_scaling_prediction"] = {"source": "profiles/r02_strong_scaling_prediction.json (tools/strong_scaling_prediction.py, strict mode, "
-                                                              "one MI355X, gather excluded)", "prediction": pred,
-                                                    "baseline_target": ">= 6x at 8 GPUs (BASELINE.json); predicted ~1.8x for ONE 100k batch: the slowest "
-                                                                       "trajectory's 702 sequential attempts do not shrink with the shard"}
+                pred = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_strong_scaling_prediction.json")))
+                res["strong_scaling_prediction"] = {"source": f"profiles/{PROFILE_ROUND}_strong_scaling_prediction.json (tools/strong_scaling_prediction.py, strict mode, "
+                                                              "one MI355X: every rank's shard timed alone, gather excluded)", "prediction": pred,
+                                                    "stale": pred.get("kernel_sources_sha256") != sha_now,
+                                                    "baseline_target": ">= 6x at 8 GPUs (BASELINE.json): out of reach for ONE 100k batch (the slowest "
+                                                                       "trajectory's 702 sequential attempts do not shrink with the shard); the prediction "
+                                                                       "file names the batch size that reaches it"}
             except Exception:   # noqa: BLE001
                 pass
             res["latency_floor_note"] = ("strong scaling of one C2 batch is bounded by its slowest trajectory: 702 sequential "
@@ -530,16 +560,6 @@ def pipelined_numbers(ivp_amd, prob, t0, t1, y0d, pd, fp_mode, args, streams=4):
                     "ivp_batch_submit_device / ivp_batch_poll; every solve is complete and unshared"}
 
 
-def _time_oracle(O, y0, p, t0, t1, threads):
-    walls, r = [], None
-    for rep in range(6):   # one warm-up + five timed runs, median (the protocol of benches/benchmark.py:56-78)
-        t = time.perf_counter()
-        r = O.solve_batch("cr3bp", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=threads)
-        if rep:
-            walls.append(time.perf_counter() - t)
-    return float(np.median(walls)), r
-
-
 def reference_crate_timing():
     """if the GPU node has a Rust toolchain, time the genuine `ivp` 0.5.1 crate.  The crate is
     not vendored here (and /root/reference does not exist on the GPU box), so this needs cargo AND a local checkout
@@ -562,11 +582,28 @@ def reference_crate_timing():
         return {"available": False, "why": f"cargo run failed: {e}"}
 
 
+def _cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(y0, p, t0, t1):
-    """The CPU oracle (C restatement of the reference algorithm, libm pow, -ffp-contract=off) on this host's
-    cores: B back-to-back solve_ivp calls, OpenMP over trajectories.  Bounded to ~10-30 s of CPU work.
-    Headline: every core of this process's affinity mask (SURVEY.md section 8d "all host cores"; count stated);
-    the 16-thread figure (the GPU box's CPU share for one GPU) and the single-thread figure are reported beside it."""
+    """The CPU oracle (C restatement of the reference algorithm, libm pow, -ffp-contract=off) on this host's cores: B
+    back-to-back solve_ivp calls, OpenMP over trajectories (dynamic schedule), threads bound one per core
+    (OMP_PROC_BIND=spread, OMP_PLACES=cores, set before the library loads).  SURVEY.md section 8d asks for "all host cores";
+    what a container may USE is its cgroup quota, not its affinity mask, so the leg sweeps 16 / 32 / 64 / 128 / all threads
+    (median of three runs each after a warm-up, the whole sweep ~5 s), reports the best with its thread count and states
+    the quota beside it.  The single-thread figure is measured on the first 4096 trajectories."""
     from oracle import oracle as O
     O.build()
     try:
@@ -580,9 +617,20 @@ def cpu_baseline(y0, p, t0, t1):
     dt1 = time.perf_counter() - t
     single = r1["total_accepted"] / dt1
     nall = y0.shape[1]
-    dt, r = _time_oracle(O, y0, p, t0, t1, cores)
-    t16 = min(16, cores)
-    dt16 = dt if t16 == cores else _time_oracle(O, y0, p, t0, t1, t16)[0]
+    sweep, r = {}, None
+    t_leg = time.perf_counter()
+    for th in sorted({min(c, cores) for c in (16, 32, 64, 128, cores)}):
+        walls = []
+        for rep in range(4):   # one warm-up + three timed runs
+            t = time.perf_counter()
+            r = O.solve_batch("cr3bp", y0, p, t0, t1, method="DOPRI5", rtol=1e-6, atol=1e-9, threads=th)
+            if rep:
+                walls.append(time.perf_counter() - t)
+        sweep[th] = float(np.median(walls))
+        if time.perf_counter() - t_leg > 20.0:   # a slow host: the leg stays bounded
+            break
+    best_threads = min(sweep, key=sweep.get)
+    best_dt = sweep[best_threads]
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -592,16 +640,19 @@ def cpu_baseline(y0, p, t0, t1):
     except OSError:
         pass
     rej = float(r["nrejct"].sum()) / max(float(r["nstep"].sum()), 1.0)
-    # headline = the faster of the two thread counts (a container's affinity mask may list far more logical CPUs than its
-    # CPU quota lets run at once: 256 threads on a 16-core share is slower than 16); both are reported
-    best_dt, best_threads = (dt, cores) if dt <= dt16 else (dt16, t16)
+    acc = r["total_accepted"]
+    quota = _cgroup_cpu_quota()
     return {
-        "value": r["total_accepted"] / best_dt, "unit": "steps/s", "cores": best_threads, "kind": "port",
-        "sample": f"the same {nall} CR3BP trajectories, one solve_ivp call each, OpenMP over trajectories, median of 5 runs after "
-                  f"a warm-up: {cores} threads (every CPU of the affinity mask) {r['total_accepted'] / dt:.3e} steps/s ({dt:.2f} s wall); "
-                  f"{t16} threads {r['total_accepted'] / dt16:.3e} steps/s ({dt16:.2f} s wall); single thread on the first {n1}: {single:.3e} steps/s",
-        "all_affinity_cpus": cores, "all_affinity_cpus_value": r["total_accepted"] / dt,
-        "threads16_value": r["total_accepted"] / dt16, "threads16": t16,
+        "value": acc / best_dt, "unit": "steps/s", "cores": best_threads, "kind": "port",
+        "sample": f"the same {nall} CR3BP trajectories, one solve_ivp call each, OpenMP over trajectories, OMP_PROC_BIND="
+                  f"{os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}; median of 3 runs after a warm-up per thread count: "
+                  + "; ".join(f"{th} threads {acc / dt:.3e} steps/s" for th, dt in sorted(sweep.items()))
+                  + f"; single thread on the first {n1}: {single:.3e} steps/s",
+        "thread_sweep_steps_per_s": {str(th): acc / dt for th, dt in sorted(sweep.items())},
+        "affinity_cpus": cores, "cgroup_cpu_quota_cores": quota,
+        "all_host_cores_note": ("the affinity mask lists %d logical CPUs" % cores)
+                               + (", the cgroup lets this process run %.1f of them at a time" % quota if quota else ", no cgroup CPU quota is set")
+                               + ": the best thread count of the sweep is the headline",
         "single_core_value": single, "cpu_model": model, "wall_s": best_dt,
         "attempts_per_s": float(r["nstep"].sum()) / best_dt, "rejection_ratio": rej,
         "what": "oracle/ivp_oracle.c: C restatement of the reference (Rust) algorithm; the crate cannot be built here",

@@ -576,10 +576,25 @@ struct Lane {
     // the next record of this attempt goes to
     uint64_t log_seg;
     uint32_t log_bits, log_slot;
+    // deferred t_eval sampling (flavour 3): the next t_eval point of the trajectory (NaN: none left), so that an attempt whose
+    // step holds no sample decides that from registers -- a load from the grid in every attempt sat on every wave's path
+    double t_next;
 };
 
+// The t_eval grid of trajectory j: the batch's shared grid, or -- every reference solve_ivp() call has its own
+// Options.t_eval (options.rs:75-123) -- its own slice of a CSR grid.
+struct EvalGrid { const double *t; int32_t n; };
+IVP_HD EvalGrid so_grid(const IvpKArgs &a, uint32_t j)
+{
+    if (a.teval_off != nullptr) {
+        const unsigned long long lo = a.teval_off[j];
+        return EvalGrid{a.t_eval + lo, (int32_t)(a.teval_off[j + 1] - lo)};
+    }
+    return EvalGrid{a.t_eval, a.n_eval};
+}
+
 template <class R>
-IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool rk23, bool full)
+IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool rk23, int full)
 {
     constexpr int N = R::N, P = R::P;
     using MAP = typename OutMap<R>::type;
@@ -620,10 +635,15 @@ IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool r
         L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
     }
     L.log_seg = IVP_NO_SEG; L.log_bits = 0; L.log_slot = 0;
+    L.t_next = 0.0;
+    if (full == 3) {
+        const EvalGrid grid = so_grid(a, j);
+        L.t_next = L.next_idx < grid.n ? grid.t[L.next_idx] : u2d(0x7FF8000000000000ull);
+    }
 }
 
 template <class R>
-IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L, bool full)
+IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L, int full)
 {
     constexpr int N = R::N;
     using MAP = typename OutMap<R>::type;
@@ -769,17 +789,6 @@ IVP_HD void interpolate(double xi, double *yi, const CP &cont, double xold, doub
 // collection, t_eval sampling, accepted-step recording with first_step enforcement.
 // `cont == nullptr` is the initial callback (interpolant None).
 // ------------------------------------------------------------------------------------------------
-// The t_eval grid of trajectory j: the batch's shared grid, or -- every reference solve_ivp() call has its own
-// Options.t_eval (options.rs:75-123) -- its own slice of a CSR grid.
-struct EvalGrid { const double *t; int32_t n; };
-IVP_HD EvalGrid so_grid(const IvpKArgs &a, uint32_t j)
-{
-    if (a.teval_off != nullptr) {
-        const unsigned long long lo = a.teval_off[j];
-        return EvalGrid{a.t_eval + lo, (int32_t)(a.teval_off[j + 1] - lo)};
-    }
-    return EvalGrid{a.t_eval, a.n_eval};
-}
 template <int M, int N, int P, class MAP = IdMap<N>>
 IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t ti, const double *yv)
 {
@@ -1221,6 +1230,8 @@ IVP_HD void so_defer_samples(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L,
         L.next_idx = i;
         return;
     }
+    // no sample in this step (the usual case): decided from the cached next point (a NaN -- grid exhausted -- fails both tests)
+    if (x > xold ? !(L.t_next <= x + tol) : !(L.t_next >= x - tol)) return;
     const int32_t i0 = i;
     int32_t cnt = 0;
     if (x > xold) {                // the tests of so_sample (solout.rs:357-385), without the interpolation
@@ -1243,6 +1254,7 @@ IVP_HD void so_defer_samples(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L,
         L.n_filled += cnt;
     }
     L.next_idx = i;
+    L.t_next = i < ne ? grid.t[i] : u2d(0x7FF8000000000000ull);
 }
 
 // does the accepted step [xold, xph] need dense coefficients? (lazy DOP853 dense stages)

@@ -6,7 +6,10 @@ Each csv is a rocprofv3 `*_counter_collection.csv` (one row per dispatch and cou
 FETCH_SIZE / WRITE_SIZE are in KiB-units per the guide (hbm_bytes = counter * 1024); the calibration kernel
 (tools/hbm_calib.hip, the integrator's 8-B-per-lane SoA pattern, known byte count) gives the correction factors.
 """
-import csv, json, sys
+import csv, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_sha import kernel_sources_sha256   # noqa: E402
 
 def per_kernel(path, counter):
     d = {}
@@ -40,5 +43,6 @@ if ck:
     res["hbm_bytes_per_launch"] = sum(kern[k]["hbm_bytes_per_launch"] * kern[k]["launches"] for k in ck) / n
     res["kernel"] = " + ".join(ck)
     res["stepping_launches"] = n
+res["kernel_sources_sha256"] = kernel_sources_sha256()   # the kernels these counters belong to (bench.py checks it)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -4,8 +4,11 @@
 Usage: pmc_sq.py <sq_counter_collection.csv> <out.json>
 Per kernel: dispatches and the per-dispatch mean of every counter, plus a few quotients (VALU instructions per wave,
 share of wave time that is issue-stall / parked; SQ_WAVE_CYCLES, SQ_WAIT_* and SQ_ACTIVE_INST_* count quad-cycles)."""
-import csv, json, sys
+import csv, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_sha import kernel_sources_sha256   # noqa: E402
 
 src, out = sys.argv[1:3]
 solves = int(sys.argv[3]) if len(sys.argv) > 3 else None   # complete solves the profiled command ran (bench.py: 3 passes x (steps + warmup))
@@ -28,5 +31,6 @@ for k, cs in acc.items():
         wc = m["SQ_WAVE_CYCLES"]
         e["share_of_wave_cycles"] = {c: m[c] / wc for c in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if c in m}
     res[k] = e
+res["kernel_sources_sha256"] = kernel_sources_sha256()   # the kernels these counters belong to (bench.py checks it)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
