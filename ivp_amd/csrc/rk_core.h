@@ -625,15 +625,12 @@ IVP_HD void lane_load(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, bool r
         L.budget = left > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)left;
     }
     L.acc_small = nacc0 > 2 ? 2u : (uint32_t)nacc0;
-    if (full) {
-        L.next_idx = a.next_idx[j];
-        L.n_filled = a.n_filled[j];
-        L.n_log = a.n_log[j];
-        L.n_seg = a.n_seg[j];
-        L.t_last = a.t_last[j];
-    } else {
-        L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
-    }
+    // DefaultSolOut registers: only what the kernel flavour reads (a field that is neither loaded nor stored costs no
+    // register across the attempt loop; the flavours that record are register-bound: BASELINE C3 runs 5 waves per SIMD at
+    // 95 VGPRs and 4 at 97)
+    L.next_idx = 0; L.n_filled = 0; L.n_log = 0; L.n_seg = 0; L.t_last = 0.0;
+    if (full == 1 || full == 3) { L.next_idx = a.next_idx[j]; L.n_filled = a.n_filled[j]; L.n_seg = a.n_seg[j]; }
+    if (full == 1 || full == 2) { L.n_log = a.n_log[j]; L.t_last = a.t_last[j]; }
     L.log_seg = IVP_NO_SEG; L.log_bits = 0; L.log_slot = 0;
     L.t_next = 0.0;
     if (full == 3) {
@@ -660,13 +657,8 @@ IVP_HD void lane_store(const IvpKArgs &a, uint32_t j, const Lane<R::N, R::P> &L,
     a.nstep[j] += L.d_nstep;
     a.naccpt[j] += L.d_naccpt;
     a.nrejct[j] += L.d_nrejct;
-    if (full) {
-        a.next_idx[j] = L.next_idx;
-        a.n_filled[j] = L.n_filled;
-        a.n_log[j] = L.n_log;
-        a.n_seg[j] = L.n_seg;
-        a.t_last[j] = L.t_last;
-    }
+    if (full == 1 || full == 3) { a.next_idx[j] = L.next_idx; a.n_filled[j] = L.n_filled; a.n_seg[j] = L.n_seg; }
+    if (full == 1 || full == 2) { a.n_log[j] = L.n_log; a.t_last[j] = L.t_last; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2217,14 +2209,14 @@ IVP_HD uint32_t chunk_body(const IvpKArgs &a, uint32_t j, int32_t &status_out)
     uint32_t it = 0;
     bool run = true;
     while (run && it < a.chunk) {
-        if (FULL && a.log_pool != nullptr) so_log_attempt<typename OutMap<R>::type, FULL>(a, j, L, it);
+        if ((FULL == 1 || FULL == 2) && a.log_pool != nullptr) so_log_attempt<typename OutMap<R>::type, FULL>(a, j, L, it);
         if constexpr (M == M_DOPRI5) run = dopri5_attempt<R, FULL, CTL>(a, j, L);
         else if constexpr (M == M_DOP853) run = dop853_attempt<R, FULL, CTL>(a, j, L);
         else if constexpr (M == M_RK4) run = rk4_attempt<R, FULL>(a, j, L);
         else run = rk23_attempt<R, FULL, CTL>(a, j, L);
         ++it;
     }
-    if (FULL && a.log_pool != nullptr) so_log_flush<typename OutMap<R>::type>(a, L);
+    if ((FULL == 1 || FULL == 2) && a.log_pool != nullptr) so_log_flush<typename OutMap<R>::type>(a, L);
     // Re-derive the store addresses from an opaque copy of j: otherwise the ~2 VGPRs per state array
     // that the loads' address arithmetic produced stay live across the whole attempt loop.
     uint32_t js = j;

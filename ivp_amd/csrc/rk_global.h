@@ -93,6 +93,8 @@ __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 // CTL = true: controller fields from IvpKArgs.ctl_* (a direct method call with non-default struct fields);
 // CTL = false keeps them compile-time constants, which is the path solve_ivp() takes.
 template <int M, class R, int FULL, bool CTL = false>
+// (tried for the recording flavours 2 / 3 of BASELINE C3's system: forcing the end-state kernel's 5 waves per SIMD -- 96 VGPRs
+// -- spills 20 registers to scratch and is slower than 4 waves at 118: t_eval 20.1 -> 22.0 ms, step log 21.7 -> 22.6)
 __global__ __launch_bounds__(IVP_WAVE, (M == M_BDF) ? IVP_BDF_MIN_WAVES : ((M == M_DOP853 && FULL == 1 && R::N >= 5) ? 1 : IVP_MIN_WAVES)) void chunk_kernel_t(const IvpKArgs a)
 {
     chunk_kernel_body<M, R, FULL, CTL>(a);
