@@ -34,6 +34,17 @@
 
 namespace IVP_NS {
 
+// -DIVP_PHASE_CLOCKS: shader-clock cycles per phase of the attempt, summed per launch and printed by lane 0 of workgroup 0
+// (a measuring build for tools/phase_clocks_large_n.sh; never part of libivp_hip.so)
+#ifdef IVP_PHASE_CLOCKS
+__device__ unsigned long long ivp_phase_clk[16];
+#define IVP_CLK_T0() unsigned long long ivp_clk_t = clock64()
+#define IVP_CLK(ph) do { const unsigned long long ivp_clk_n = clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) ivp_phase_clk[ph] += ivp_clk_n - ivp_clk_t; ivp_clk_t = ivp_clk_n; } while (0)
+#else
+#define IVP_CLK_T0() do { } while (0)
+#define IVP_CLK(ph) do { } while (0)
+#endif
+
 template <class R, int G>
 struct BdfG {
     using GR = GroupRhs<R, G>;
@@ -56,29 +67,73 @@ struct BdfG {
         return sqrt(NormOps<GR>::sum(term) / (double)NT);
     }
 
-    // default IVP::jac (src/ivp.rs:67-107): forward differences; jac is column-major [col * NT + row]
-    static __device__ __forceinline__ void fd_jac(double x, const double (&y)[C], const double *p, double *jac)
+    // default IVP::jac (src/ivp.rs:67-107): forward differences; jac is column-major [col * NT + row].
+    // One column needs f at the state with ONE component perturbed.  The component-form right-hand side reads its state from
+    // LDS, so KJ perturbed copies of the state are kept there and KJ columns are evaluated per sweep: three barriers per KJ
+    // columns instead of two per column, KJ x C independent evaluations between them (a lone wavefront's sweep is a chain of
+    // LDS round trips and barriers: 1.5 us per column at n = 100, where the n + 1 evaluations of this function were 2/3 of a
+    // BDF step).  Every entry is still (f_row(y + pert e_col) - f_row(y)) / pert with the reference's operations.
+    // `work` (LDSWORK): the kernels that keep the factors of (I - cJ) in LDS have no room for KJ more vectors (two 80 KB
+    // matrices fill a CU at n = 100) -- but the factors are dead whenever BDF evaluates a Jacobian (it refactorises afterwards,
+    // bdf.rs:448-459, 596-606), so their LDS is the work space there.
+    enum { KJ = 8 };
+    template <bool LDSWORK>
+    static __device__ __forceinline__ void fd_jac(double x, const double (&y)[C], const double *p, double *jac, double *work)
     {
-        double fo[C], fp[C], yp[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) yp[c] = y[c];
+        static_assert(!LDSWORK || NT >= KJ, "the factor matrix (n x n) must hold KJ state copies");
+        double *st = work;
+        if constexpr (!LDSWORK) {
+            __shared__ double ivp_fd_states[NGROUP * KJ * NT];
+            st = ivp_fd_states + (size_t)((int)threadIdx.x / G) * KJ * NT;
+        }
+        double fo[C];
         GR::ode(x, y, fo, p);
         const double eps = 1.4901161193847656e-08;   // f64::EPSILON.sqrt() = 2^-26
+        __syncthreads();
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) {
+        for (int k = 0; k < KJ; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) if (own(c)) st[k * NT + gi(c)] = y[c];
 #pragma unroll 1
-            for (int ll = 0; ll < G; ++ll) {
-                const int col = ll + G * cc;
-                if (col >= NT) break;
-                const double yo = __shfl(y[cc], wl0() + ll);
-                const double pert = eps * fmax(fabs(yo), 1.0);
-                if (gl() == ll) yp[cc] = yo + pert;
-                GR::ode(x, yp, fp, p);
-                if (gl() == ll) yp[cc] = yo;
+        for (int col0 = 0; col0 < NT; col0 += KJ) {
+            double pert[KJ];
+            // the owner of component col0 + k perturbs it in copy k; everybody needs the perturbation for the quotient
 #pragma unroll
-                for (int c = 0; c < C; ++c) if (own(c)) jac[(size_t)col * NT + gi(c)] = (fp[c] - fo[c]) / pert;
+            for (int k = 0; k < KJ; ++k) {
+                const int col = col0 + k;
+                const int ll = col % G, cc = col / G;
+                double ysel = y[0];
+#pragma unroll
+                for (int q = 1; q < C; ++q) ysel = cc == q ? y[q] : ysel;
+                const double yo = __shfl(ysel, wl0() + ll);
+                pert[k] = eps * fmax(fabs(yo), 1.0);
+                if (col < NT && gl() == ll) st[k * NT + col] = yo + pert[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KJ; ++k) {
+                const int col = col0 + k;
+                if (col < NT) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const int i = gi(c);
+                        if (i < NT) jac[(size_t)col * NT + i] = (R::ode_comp(i, x, st + k * NT, p) - fo[c]) / pert[k];
+                    }
+                }
+            }
+            __syncthreads();
+            // the copies return to y for the next KJ columns
+#pragma unroll
+            for (int k = 0; k < KJ; ++k) {
+                const int col = col0 + k;
+                const int ll = col % G, cc = col / G;
+                double ysel = y[0];
+#pragma unroll
+                for (int q = 1; q < C; ++q) ysel = cc == q ? y[q] : ysel;
+                if (col < NT && gl() == ll) st[k * NT + col] = ysel;
             }
         }
+        __syncthreads();
     }
 
     // f.jac(x, y, &mut j): the problem's own Jacobian when the functor has one -- the `impl IVP { fn jac }` override of
@@ -90,7 +145,8 @@ struct BdfG {
     struct HasJacCol { enum { v = 0 }; };
     template <class RR>
     struct HasJacCol<RR, decltype((void)&RR::jac_col)> { enum { v = 1 }; };
-    static __device__ __forceinline__ void eval_jac(double x, const double (&y)[C], const double *p, double *jac)
+    template <bool LDSWORK = false>
+    static __device__ __forceinline__ void eval_jac(double x, const double (&y)[C], const double *p, double *jac, double *work = nullptr)
     {
         if constexpr (HasJacCol<R>::v) {
             double *st = GR::scratch();
@@ -101,31 +157,38 @@ struct BdfG {
             for (int col = gl(); col < NT; col += G) R::jac_col(col, x, st, jac + (size_t)col * NT, p);
             __syncthreads();
         } else {
-            fd_jac(x, y, p, jac);
+            fd_jac<LDSWORK>(x, y, p, jac, work);
         }
     }
 
-    // (value, row) of the first row >= k attaining max |a[row][k]| (NaNs never win; none found -> row = NT)
-    static __device__ __forceinline__ int pivot_row(const double *a, int k)
+    // max over the group's lanes of v (v >= -1.0, no NaNs), in every lane.  One group per wavefront: the DPP row-shift /
+    // row-broadcast reduction (6 dependent v_max with DPP operand moves), then a v_readlane of lane 63 -- no LDS round trips
+    // (the shuffle butterfly's 6 dependent ds_bpermute stages were 45 % of a pivot step of lu_decomp on a lone wavefront).
+    static __device__ __forceinline__ double group_max(double v)
     {
-        double lv = -1.0;
-        int li = NT;
+        if constexpr (G == IVP_WAVE) {
+            constexpr int kIdLo = 0, kIdHi = (int)0xBFF00000;   // -1.0: below every candidate
+            auto stage = [&](auto ctrl, auto row_mask) {
+                const unsigned long long u = d2u(v);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(kIdLo, (int)(uint32_t)u, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(kIdHi, (int)(uint32_t)(u >> 32), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+                const double o = u2d(((unsigned long long)hi << 32) | lo);
+                v = o > v ? o : v;
+            };
+            stage(IntC<0x111>{}, IntC<0xf>{});   // row_shr:1
+            stage(IntC<0x112>{}, IntC<0xf>{});   // row_shr:2
+            stage(IntC<0x114>{}, IntC<0xf>{});   // row_shr:4
+            stage(IntC<0x118>{}, IntC<0xf>{});   // row_shr:8   (lane 15 of every row: the row's maximum)
+            stage(IntC<0x142>{}, IntC<0xa>{});   // row_bcast:15 into rows 1 and 3
+            stage(IntC<0x143>{}, IntC<0xc>{});   // row_bcast:31 into rows 2 and 3   (lane 63: the maximum)
+            return lane_bcast(v, IVP_WAVE - 1);
+        } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int i = gi(c);
-            if (i >= k && i < NT) {
-                const double v = fabs(a[(size_t)k * NT + i]);
-                if (v > lv) { lv = v; li = i; }
-            }
+            for (int o = G / 2; o > 0; o >>= 1) { const double ov = __shfl_xor(v, o); v = ov > v ? ov : v; }
+            return v;
         }
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(lv, o);
-            const int oi = __shfl_xor(li, o);
-            if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
-        }
-        return li;
     }
+    template <int V> struct IntC { static constexpr int value = V; };
 
     // lu_decomp (src/matrix/lu.rs:37-125) in place on the column-major matrix a; pivots to piv[0..NT-2].
     static __device__ __forceinline__ bool lu_decomp(double *a, uint32_t *piv)
@@ -134,49 +197,48 @@ struct BdfG {
         __syncthreads();
 #pragma unroll 1
         for (int k = 0; k < NT - 1; ++k) {
-            // One memory round trip brings everything the pivot step needs from column k: the diagonal entry (the same
-            // address in every lane) and this lane's rows.  The pivot search carries the signed entry along with
-            // (|entry|, row), and the multipliers are formed from the values already in registers -- the three further
-            // dependent loads of the plain formulation (pivot value, swapped column) were a third of a pivot's latency.
-            const double *colk_p = a + (size_t)k * NT;
-            const double akk = colk_p[k];
+            // One memory round trip brings everything the pivot step needs from column k: this lane's rows (whole column,
+            // no masks: rows >= n read a clamped address and never become candidates).  The diagonal entry and the pivot
+            // come out of the registers by v_readlane, the pivot row by a maximum over the wavefront plus a ballot; the
+            // multipliers are formed from the values already in registers and every lane stores its own rows of column k
+            // (row k receives the pivot: that IS the row exchange within this column), so the step needs no barrier
+            // before the trailing columns are touched.
+            IVP_CLK_T0();
             double colk[C];
 #pragma unroll
+            for (int c = 0; c < C; ++c) colk[c] = a[(size_t)k * NT + (own(c) ? gi(c) : NT - 1)];
+            const double akk = row_bcast(colk, k, 0);
+            IVP_CLK(8);
+            // first row >= k attaining max |a[row][k]| (NaNs never win)
+            double av[C], lv = -1.0;
+#pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = gi(c);
-                colk[c] = (i >= k && i < NT) ? colk_p[i] : 0.0;
+                const double v = fabs(colk[c]);
+                av[c] = (i >= k && i < NT && v == v) ? v : -1.0;
+                lv = av[c] > lv ? av[c] : lv;
             }
-            double lv = -1.0, sv = 0.0;   // first row >= k attaining max |a[row][k]| (NaNs never win)
+            const double vmax = group_max(lv);
             int li = NT;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int i = gi(c);
-                if (i >= k && i < NT) {
-                    const double v = fabs(colk[c]);
-                    if (v > lv) { lv = v; li = i; sv = colk[c]; }
-                }
-            }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-                const double ov = __shfl_xor(lv, o), os = __shfl_xor(sv, o);
-                const int oi = __shfl_xor(li, o);
-                if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; sv = os; }
+            for (int c = C - 1; c >= 0; --c) {
+                unsigned long long hit = __ballot(av[c] == vmax);
+                if (G < IVP_WAVE) hit = (hit >> wl0()) & ((1ull << (G & 63)) - 1ull);
+                if (hit != 0ull) li = G * c + __ffsll((long long)hit) - 1;
             }
             int m = k;
             double pivot = akk;
-            if (akk == akk && li < NT) { m = li; pivot = sv; }   // |a[k][k]| NaN: every `>` of the reference's scan is false
+            if (akk == akk && vmax >= 0.0) { m = li; pivot = row_bcast(colk, li, 0); }   // |a[k][k]| NaN: every `>` of the reference's scan is false
             if (gl() == 0) piv[k] = (uint32_t)m;
             if (pivot == 0.0) return false;
-            __syncthreads();   // everyone has read column k before the swap
-            if (gl() == 0 && m != k) { a[(size_t)k * NT + m] = akk; a[(size_t)k * NT + k] = pivot; }
-            __syncthreads();
+            IVP_CLK(9);
             const double t = 1.0 / pivot;
             double mult[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = gi(c);
-                mult[c] = 0.0;
-                if (i > k && i < NT) { mult[c] = -((i == m) ? akk : colk[c]) * t; a[(size_t)k * NT + i] = mult[c]; }   // row m holds row k's entry after the swap
+                mult[c] = (i > k && i < NT) ? -((i == m) ? akk : colk[c]) * t : 0.0;    // row m holds row k's entry after the swap
+                if (i >= k && i < NT) a[(size_t)k * NT + i] = i == k ? pivot : mult[c];
             }
             // Trailing update.  A column j > k changes only if its pivot-row entry t_j = a[m][j] is non-zero (the reference
             // guards the update with `t != 0`, lu.rs:88-104) or if the row exchange moves two different values; for a
@@ -186,6 +248,7 @@ struct BdfG {
             // are all issued before the first dependent instruction: a lone wavefront working out of L2 pays a full
             // memory round trip for whatever it waits on).  Skipped columns are exactly those the reference leaves
             // bit-for-bit unchanged; a dense matrix flags every column and costs two extra loads per 64 columns.
+            IVP_CLK(10);
             constexpr int JB = 4;
             struct Blk { double tj[JB], akj[JB], cur[JB][C]; };
             // Branch-free per element: a G-row chunk that lies entirely above the pivot row is skipped by a SCALAR test
@@ -242,6 +305,7 @@ struct BdfG {
                 tjs[sg] = 0.0; aks[sg] = 0.0;
                 if (jj < NT) { tjs[sg] = a[(size_t)jj * NT + m]; aks[sg] = a[(size_t)jj * NT + k]; }
             }
+            IVP_CLK(11);
 #pragma unroll 1
             for (int sg = 0; sg < SEG; ++sg) {
                 const int j0 = k + 1 + sg * G;
@@ -269,82 +333,157 @@ struct BdfG {
                 }
             }
             __syncthreads();   // column k+1 is complete before the next pivot search reads it
+            IVP_CLK(12);
         }
         return a[(size_t)(NT - 1) * NT + (NT - 1)] != 0.0;
     }
 
-    // lin_solve (src/matrix/linear.rs:55-96): b (this lane's components) <- A^-1 b
+    // Lane `l` (of this group) broadcasts a value to the whole group.  l is uniform within the group; with one group per
+    // wavefront it is wave-uniform and the broadcast is a v_readlane (no LDS round trip, the result lands in SGPRs).
+    static __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int l)
+    {
+        if constexpr (G == IVP_WAVE) return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l));
+        else return (uint32_t)__shfl((int)v, wl0() + l);
+    }
+    static __device__ __forceinline__ double lane_bcast(double v, int l)
+    {
+        if constexpr (G == IVP_WAVE) {
+            const int lane = __builtin_amdgcn_readfirstlane(l);
+            const unsigned long long u = d2u(v);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+            return u2d(((unsigned long long)hi << 32) | lo);
+        } else {
+            return __shfl(v, wl0() + l);
+        }
+    }
+    // row r (uniform within the group, r >= G * c0; c0 a constant after unrolling) of a vector whose row i lives in lane
+    // i % G, component i / G
+    static __device__ __forceinline__ double row_bcast(const double (&v)[C], int r, int c0)
+    {
+        const int q = r / G;
+        double sel = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (c == c0) sel = v[c];
+            else if (c > c0) sel = q == c ? v[c] : sel;
+        }
+        return lane_bcast(sel, r % G);
+    }
+
+    // lin_solve (src/matrix/linear.rs:55-96): b (this lane's components) <- A^-1 b.
+    // The right-hand side never leaves the registers: each of the 2n sequential pivot steps broadcasts ONE entry of b and
+    // every lane updates the rows it owns -- the reference's operations on every entry, in its order.  A lone wavefront
+    // retires one instruction every ~5 cycles, so what a pivot step costs is its instruction count (round 3 kept b in LDS:
+    // two LDS round trips, two barriers and ~100 instructions per step = 525 cycles, 60 % of a BDF step at n = 100;
+    // tools/phase_clocks_large_n.sh).  Hence:
+    //   * the steps are walked in blocks of G (block KB: rows KB*G ...): components below the block are not touched at all,
+    //     the block's own component is the only one that needs the row mask, which component holds b[k] is static;
+    //   * whole columns of the factors are fetched, PF steps ahead, without masks: entries the step must not use are
+    //     dropped by the row mask of the update (rows >= n read a clamped address; their results are never looked at);
+    //   * the pivot indices sit in registers (one coalesced load) and are read with v_readlane.
+    enum { PF = C <= 2 ? 8 : (C <= 4 ? 4 : 2) };
     static __device__ __forceinline__ void lin_solve(const double *a, const uint32_t *piv, double (&bl)[C])
     {
-        double *b = GR::scratch();
-        __syncthreads();
+        if (NT == 1) { bl[0] = own(0) ? bl[0] / a[0] : 0.0; return; }
+        int row[C];
+        uint32_t pv[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) if (own(c)) b[gi(c)] = bl[c];
-        __syncthreads();
-        if (NT == 1) { if (gl() == 0) b[0] /= a[0]; __syncthreads(); bl[0] = b[0]; return; }
-        // each of the 2n pivot steps needs one column of the factors from memory: the next step's column (and pivot index)
-        // is fetched while the current step runs, so that the steps do not each start with a memory round trip
-        double cnext[C];
-        int mnext = (int)piv[0];
+        for (int c = 0; c < C; ++c) {
+            row[c] = own(c) ? gi(c) : NT - 1;
+            pv[c] = gi(c) < NT - 1 ? piv[gi(c)] : 0u;
+        }
+        // forward: b <- L^-1 P b (row exchange m <-> k, then b[i] += l[i][k] * b[k] for i > k; the multipliers are stored negated)
 #pragma unroll
-        for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = (i > 0 && i < NT) ? a[i] : 0.0; }
-#pragma unroll 1
-        for (int k = 0; k < NT - 1; ++k) {
-            const int m = mnext;
-            double ccur[C];
+        for (int kb = 0; kb < C; ++kb) {
+            const int kend = (kb + 1) * G < NT - 1 ? (kb + 1) * G : NT - 1;
+            if (kb * G >= NT - 1) break;
+            double cq[PF][C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) ccur[c] = cnext[c];
-            if (k + 1 < NT - 1) {
-                mnext = (int)piv[k + 1];
-                const double *ncol = a + (size_t)(k + 1) * NT;
+            for (int u = 0; u < PF; ++u) {
+                const int k = kb * G + u < NT ? kb * G + u : NT - 1;
 #pragma unroll
-                for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = (i > k + 1 && i < NT) ? ncol[i] : 0.0; }
+                for (int c = kb; c < C; ++c) cq[u][c] = a[(size_t)k * NT + row[c]];
             }
-            const double t = b[m], bk_old = b[k];
-            __syncthreads();
-            if (gl() == 0) { b[m] = bk_old; b[k] = t; }
+#pragma unroll 1
+            for (int k0 = kb * G; k0 < kend; k0 += PF) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int i = gi(c);
-                if (i > k && i < NT) {
-                    const double bi = (i == m) ? bk_old : b[i];
-                    b[i] = IVP_MA(bi, ccur[c], t);
+                for (int u = 0; u < PF; ++u) {
+                    const int k = k0 + u;
+                    if (k < kend) {
+                        double ccur[C];
+#pragma unroll
+                        for (int c = kb; c < C; ++c) ccur[c] = cq[u][c];
+                        const int kn = k + PF;
+                        if (kn < kend) {
+#pragma unroll
+                            for (int c = kb; c < C; ++c) cq[u][c] = a[(size_t)kn * NT + row[c]];
+                        }
+                        const int m = (int)lane_bcast(pv[kb], k - kb * G);
+                        const double bk_old = lane_bcast(bl[kb], k - kb * G);
+                        const double t = row_bcast(bl, m, kb);
+                        {
+                            const int i = gi(kb);
+                            double bi = bl[kb];
+                            bi = i == m ? bk_old : bi;
+                            bi = i == k ? t : bi;
+                            bl[kb] = i > k ? IVP_MA(bi, ccur[kb], t) : bi;
+                        }
+#pragma unroll
+                        for (int c = kb + 1; c < C; ++c) {
+                            const double bi = gi(c) == m ? bk_old : bl[c];
+                            bl[c] = IVP_MA(bi, ccur[c], t);
+                        }
+                    }
                 }
             }
-            __syncthreads();
         }
-        double dnext = a[(size_t)(NT - 1) * NT + (NT - 1)];
+        // backward: b <- U^-1 b (b[k] /= u[k][k], then b[i] -= u[i][k] * b[k] for i < k)
 #pragma unroll
-        for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = i < NT - 1 ? a[(size_t)(NT - 1) * NT + i] : 0.0; }
+        for (int kb = C - 1; kb >= 0; --kb) {
+            const int ktop = (kb + 1) * G - 1 < NT - 1 ? (kb + 1) * G - 1 : NT - 1;   // first (highest) row of the block
+            const int kbot = kb == 0 ? 1 : kb * G;                                      // last row the loop handles (row 0: below)
+            if (kb * G > NT - 1) continue;
+            double cq[PF][C], dq[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int k = ktop - u >= 0 ? ktop - u : 0;
+                dq[u] = a[(size_t)k * NT + k];
+#pragma unroll
+                for (int c = 0; c <= kb; ++c) cq[u][c] = a[(size_t)k * NT + row[c]];
+            }
 #pragma unroll 1
-        for (int kb = 1; kb < NT; ++kb) {
-            const int k = NT - kb;
-            double ccur[C];
-            const double dcur = dnext;
+            for (int k0 = ktop; k0 >= kbot; k0 -= PF) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) ccur[c] = cnext[c];
-            if (k - 1 >= 1) {
-                const double *ncol = a + (size_t)(k - 1) * NT;
-                dnext = ncol[k - 1];
+                for (int u = 0; u < PF; ++u) {
+                    const int k = k0 - u;
+                    if (k >= kbot) {
+                        double ccur[C];
+                        const double dcur = dq[u];
 #pragma unroll
-                for (int c = 0; c < C; ++c) { const int i = gi(c); cnext[c] = i < k - 1 ? ncol[i] : 0.0; }
+                        for (int c = 0; c <= kb; ++c) ccur[c] = cq[u][c];
+                        const int kn = k - PF;
+                        if (kn >= kbot) {
+                            dq[u] = a[(size_t)kn * NT + kn];
+#pragma unroll
+                            for (int c = 0; c <= kb; ++c) cq[u][c] = a[(size_t)kn * NT + row[c]];
+                        }
+                        const double bk = lane_bcast(bl[kb], k - kb * G) / dcur;
+                        {
+                            const int i = gi(kb);
+                            const double bi = i == k ? bk : bl[kb];
+                            bl[kb] = i < k ? IVP_MA(bi, ccur[kb], -bk) : bi;
+                        }
+#pragma unroll
+                        for (int c = 0; c < kb; ++c) bl[c] = IVP_MA(bl[c], ccur[c], -bk);
+                    }
+                }
             }
-            const double bk = b[k] / dcur;
-            __syncthreads();
-            if (gl() == 0) b[k] = bk;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int i = gi(c);
-                if (i < k) b[i] = IVP_MA(b[i], ccur[c], -bk);
-            }
-            __syncthreads();
         }
-        const double b0 = b[0] / a[0];
-        __syncthreads();
-        if (gl() == 0) b[0] = b0;
-        __syncthreads();
+        const double b0 = lane_bcast(bl[0], 0) / a[0];
+        if (gi(0) == 0) bl[0] = b0;
 #pragma unroll
-        for (int c = 0; c < C; ++c) bl[c] = own(c) ? b[gi(c)] : 0.0;
+        for (int c = 0; c < C; ++c) bl[c] = own(c) ? bl[c] : 0.0;
     }
 };
 
@@ -478,7 +617,7 @@ struct BdfGLane {
 };
 
 // One pass of the main loop (bdf.rs:276-607). Returns false when the trajectory retired.
-template <class R, int FULL, int G>
+template <class R, int FULL, int G, bool LDSWORK = false>
 __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j, BdfGLane<BdfG<R, G>::C> &S, Lane<BdfG<R, G>::C, R::P> &L,
                                                   double *jac, double *lu, uint32_t *piv)
 {
@@ -497,6 +636,7 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
                   (lu_current ? IVP_BDF_LU_CURRENT : 0u);
     };
 
+    IVP_CLK_T0();
     if (S.over || S.d_nstep >= S.budget) { S.status = 2; return false; }                 // steps.total >= nmax
     if (S.current_h < MIN_POSITIVE) { S.status = 3; return false; }
     double h_try = S.current_h;
@@ -563,24 +703,33 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
     }
     const double c = h_signed / alpha_o;
     bool lu_failed = false;
+    IVP_CLK(0);
     if (!lu_current || fabs(c - S.current_c) / fmax(fabs(c), 1.0) > 0.1) {
         __syncthreads();
+        // (I - cJ), element by element over the n x n column-major block: coalesced, FB loads in flight per lane (a loop
+        // over columns waited for one memory round trip per column: 64 000 cycles per refactorisation at n = 100)
+        {
+            constexpr int NE = BG::NT * BG::NT, FB = 8;
 #pragma unroll 1
-        for (int col = 0; col < BG::NT; ++col) {
+            for (int e0 = 0; e0 < NE; e0 += FB * G) {
+                double jv[FB];
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const int r = BG::gi(cc);
-                if (r < BG::NT) {
-                    const double jv = jac[(size_t)col * BG::NT + r];
-                    const double v = r == col ? IVP_MA(1.0, -c, jv) : -c * jv;   // (I - cJ): the diagonal is -c j + 1
-                    lu[(size_t)col * BG::NT + r] = v;
+                for (int u = 0; u < FB; ++u) { const int e = e0 + u * G + BG::gl(); jv[u] = e < NE ? jac[e] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    const int e = e0 + u * G + BG::gl();
+                    const int col = e / BG::NT, r = e - col * BG::NT;
+                    const double v = r == col ? IVP_MA(1.0, -c, jv[u]) : -c * jv[u];   // (I - cJ): the diagonal is -c j + 1
+                    if (e < NE) lu[e] = v;
                 }
             }
         }
         S.d_nlu += 1;
+        IVP_CLK(1);
         if (BG::lu_decomp(lu, piv)) { lu_current = true; S.current_c = c; }
         else lu_failed = true;
         __syncthreads();
+        IVP_CLK(2);
     }
     if (lu_failed) {   // bdf.rs:373-381
         S.pending_factor = 0.5; S.flags |= IVP_BDF_PENDING;
@@ -599,12 +748,16 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
     if (newton_tol <= 0.0) newton_tol = 1e-9;
 #pragma unroll 1
     while (iters < newton_maxiter) {
+        IVP_CLK(7);
         GR::ode(x_new, y_new, rhs, L.p);
         S.d_nfev += 1;
 #pragma unroll
         for (int i = 0; i < C; ++i) rhs[i] = IVP_MB(c, rhs[i], psi[i]) - delta[i];
+        IVP_CLK(3);
         BG::lin_solve(lu, piv, rhs);
+        IVP_CLK(4);
         const double dy_norm = BG::wrms(rhs, scale);
+        IVP_CLK(5);
         bool rate_condition = false;
         if (has_prev && dy_norm_prev > 0.0) {
             const double rate = dy_norm / dy_norm_prev;
@@ -634,8 +787,10 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
         dy_norm_prev = dy_norm; has_prev = true;
         iters += 1;
     }
+    IVP_CLK(7);
     if (!converged) {   // bdf.rs:448-459: refresh the Jacobian at the predictor, halve the step
-        BG::eval_jac(x_new, y_predict, L.p, jac);
+        BG::template eval_jac<LDSWORK>(x_new, y_predict, L.p, jac, lu);   // (lu_current goes false right below: the factors are dead)
+        IVP_CLK(6);
         S.d_njev += 1;
         lu_current = false;
         S.pending_factor = 0.5; S.flags |= IVP_BDF_PENDING;
@@ -746,8 +901,11 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
         order = new_order;
         n_equal = 0;
         lu_current = false;
-        if (new_order != old_order) { BG::eval_jac(S.x, S.y, L.p, jac); S.d_njev += 1; }
+        IVP_CLK(7);
+        if (new_order != old_order) { BG::template eval_jac<LDSWORK>(S.x, S.y, L.p, jac, lu); S.d_njev += 1; }
+        IVP_CLK(6);
     }
+    IVP_CLK(7);
     pack();
     return true;
 }
@@ -820,11 +978,20 @@ __device__ __forceinline__ uint32_t bdf_group_chunk_body(const IvpKArgs &a, uint
     bool run = true;
     while (run && it < a.chunk) {
         if (FULL && a.log_pool != nullptr) so_log_attempt<MAP, 1>(a, j, L, it);
-        run = bdf_group_attempt<R, FULL, G>(a, j, S, L, jac, lu, piv);
+        run = bdf_group_attempt<R, FULL, G, kLds>(a, j, S, L, jac, lu, piv);
         ++it;
     }
     if (FULL && a.log_pool != nullptr) so_log_flush<MAP>(a, L);
     __syncthreads();
+#ifdef IVP_PHASE_CLOCKS
+    if (threadIdx.x == 0 && j == 0) {
+        printf("phase clocks (launch of %u attempts): pre %llu  form %llu  lu %llu  ode %llu  solve %llu  wrms %llu  jac %llu  rest %llu\n", it,
+               ivp_phase_clk[0], ivp_phase_clk[1], ivp_phase_clk[2], ivp_phase_clk[3], ivp_phase_clk[4], ivp_phase_clk[5], ivp_phase_clk[6], ivp_phase_clk[7]);
+        printf("  inside lu: column load %llu  pivot search %llu  swap + multipliers %llu  pivot-row loads %llu  trailing update + barrier %llu\n",
+               ivp_phase_clk[8], ivp_phase_clk[9], ivp_phase_clk[10], ivp_phase_clk[11], ivp_phase_clk[12]);
+        for (int q = 0; q < 16; ++q) ivp_phase_clk[q] = 0;
+    }
+#endif
     if constexpr (kLds) {
         if (S.flags & IVP_BDF_LU_CURRENT) {   // the next launch continues with these factors (same nlu as the global-memory path)
             for (int e = (int)threadIdx.x; e < NT * NT; e += IVP_WAVE) lu_mem[e] = lu[e];

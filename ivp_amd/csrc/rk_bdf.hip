@@ -9,7 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #define IVP_HD __host__ __device__ __forceinline__
+#ifndef IVP_HOIST
 #define IVP_HOIST 2
+#endif
 // Second build (-DIVP_BDF_MIN_WAVES=2 -> *_occ2): the same source under __launch_bounds__(64, 2).  It spills a few
 // registers to scratch (84 B per lane at n = 2) and is ~10 % slower per attempt for a lone wave, but two resident waves
 // per SIMD hide each other's latencies once a batch over-subscribes the chip (262 144 stiff Van der Pol trajectories:

@@ -676,7 +676,11 @@ struct ContStage {
     double *b;
     __device__ __forceinline__ ContStage()
     {
+        // one row of IVP_WAVE doubles per coefficient, addressed by threadIdx.x alone: the kernels that instantiate this are
+        // launched with one-wavefront workgroups (rk_kernels.hip / rk_coop.h: block(IVP_WAVE); a wider block would alias lanes).
+        // LDS cost: NC x 512 B per wave = 32 KB at N = 8 -- 5 waves per CU of the 160 KB, below the VGPR limit of these kernels.
         __shared__ double ivp_cont_lds[NC * IVP_WAVE];
+        __builtin_assume(blockDim.x == IVP_WAVE);
         b = ivp_cont_lds + threadIdx.x;
     }
     __device__ __forceinline__ double operator[](int c) const { return b[c * IVP_WAVE]; }
