@@ -272,66 +272,6 @@ IVP_HD void bdf_change_d(double (&d)[8][N], int order, double factor)
         }
 }
 
-// change_d once more, for REGISTERS instead of latency (the IVP_BDF_DIET build: batches that over-subscribe the chip, where
-// waves per SIMD pay and a wave's own dependent chains do not).  The structured form above keeps all of R (25 doubles), all of
-// RU (25) and the six new rows alive at once so that consecutive instructions belong to different accumulators; here the
-// row index k of R runs OUTERMOST: R's row k is made from row k - 1 in place (5 doubles), each RU[k][row] is formed and spent
-// at once on the accumulators acc[row][.] += RU[k][row] d[k][.].  Every accumulator still receives the reference's terms in
-// the reference's order -- the same operations on the same operands as bdf_change_d, only issued in another order -- so the
-// results are bit-identical (tests/test_kernel_bodies_cpu.py compares the three forms).  Live: 10 + 6 n doubles.
-template <int N>
-IVP_HD void bdf_change_d_lean(double (&d)[8][N], int order, double factor, uint64_t kz = 0)
-{
-    KC_SCOPE_KZ(kz)   // U's 25 entries are wave-uniform literals: made where they are used (KC), not parked in registers
-    if (factor == 1.0) return;
-    if (order > BDF_MAXO) order = BDF_MAXO;
-    bool plain = fabs(factor) < 1e50;
-#pragma unroll
-    for (int k = 1; k < 6; ++k)
-#pragma unroll
-        for (int c = 0; c < N; ++c) plain = plain && fabs(d[k][c]) < u2d(0x7FF0000000000000ull);
-    if (!plain) { bdf_change_d_generic<N>(d, order, factor); return; }
-    constexpr BdfU U{};
-    double fm[6], rk[6], acc[6][N];
-#pragma unroll
-    for (int m = 1; m < 6; ++m) { fm[m] = factor * (double)m; rk[m] = 1.0; }
-#pragma unroll
-    for (int c = 0; c < N; ++c) acc[0][c] = 0.0 + 1.0 * d[0][c];
-#pragma unroll
-    for (int row = 1; row < 6; ++row)
-#pragma unroll
-        for (int c = 0; c < N; ++c) acc[row][c] = 0.0;
-#pragma unroll
-    for (int k = 1; k < 6; ++k) {
-#pragma unroll
-        for (int m = 1; m < 6; ++m) {
-            const double num = (double)k - 1.0 - fm[m];
-            const double quot = k == 3 ? ivp_div_small_const<3>(num) : (k == 5 ? ivp_div_small_const<5>(num) : num / (double)k);
-            rk[m] = rk[m] * quot;   // R[k][m] = R[k - 1][m] * quot
-        }
-        const double keep = k <= order ? 1.0 : 0.0;
-#pragma unroll
-        for (int row = 1; row < 6; ++row) {
-            double ru = rk[1] * KC(U.v[1][row]);
-#pragma unroll
-            for (int m = 2; m < 6; ++m)
-                if (m <= row) ru = IVP_MA(ru, rk[m], KC(U.v[m][row]));
-            ru = ru * keep;
-#pragma unroll
-            for (int c = 0; c < N; ++c) acc[row][c] = IVP_MA(acc[row][c], ru, d[k][c]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (i <= order) {
-#pragma unroll
-            for (int c = 0; c < N; ++c) d[i][c] = acc[i][c];
-        }
-}
-#ifndef IVP_BDF_DIET
-#define IVP_BDF_DIET 0
-#endif
-
 // lu_decomp (src/matrix/lu.rs:37-125), row-major a[r][c]; pivots packed 4 bits each. Returns false if singular.
 template <int N>
 IVP_HD bool bdf_lu_decomp(double (&a)[N][N], uint32_t &piv)
@@ -613,13 +553,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
         const double factor = pass == 0 ? fpass[0] : (pass == 1 ? fpass[1] : (pass == 2 ? fpass[2] : fpass[3]));
-        if (factor != 1.0) {
-#if IVP_BDF_DIET
-            bdf_change_d_lean<N>(S.d, order, factor, L.kz);
-#else
-            bdf_change_d<N>(S.d, order, factor);
-#endif
-        }
+        if (factor != 1.0) bdf_change_d<N>(S.d, order, factor);
     }
     IVP_PHASE(2);   // change_d
     if (finished) { pack(); S.status = 0; return false; }
@@ -817,18 +751,7 @@ IVP_HD bool bdf_attempt(const IvpKArgs &a, uint32_t j, BdfLane<R::N> &S, Lane<R:
         double factors[3];
         const double errors[3] = {err_m, error_norm, err_p};
         const double expo[3] = {-1.0 / ((double)order + 0.0), -1.0 / ((double)order + 1.0), -1.0 / ((double)order + 2.0)};
-#if IVP_BDF_DIET
-        // the three powers one after the other (same values as ivp_pow3, argument for argument): a third of the live registers
-#pragma unroll 1
-        for (int q = 0; q < 3; ++q) {
-            const double xq = q == 0 ? errors[0] : (q == 1 ? errors[1] : errors[2]);
-            const double eq = q == 0 ? expo[0] : (q == 1 ? expo[1] : expo[2]);
-            const double v = ivp_pow(xq, eq, IVP_KZ_ARG);
-            if (q == 0) factors[0] = v; else if (q == 1) factors[1] = v; else factors[2] = v;
-        }
-#else
         ivp_pow3(errors, expo, factors, IVP_KZ_ARG);
-#endif
         IVP_PHASE(9);   // the three powers
         if (reject) {   // bdf.rs:481-489
             double factor = safety * factors[1];

@@ -110,12 +110,7 @@ extern "C" int emul_solve(int method, int rhs_id, int full, IvpKArgs *args, uint
 }
 
 // bdf_change_d (structured) next to bdf_change_d_generic (the literal restatement) on the same input: d is [8][n] row-major
-extern "C" int emul_change_d3(int n, int order, double factor, const double *d_in, double *d_fast, double *d_generic, double *d_lean);
 extern "C" int emul_change_d(int n, int order, double factor, const double *d_in, double *d_fast, double *d_generic)
-{
-    return emul_change_d3(n, order, factor, d_in, d_fast, d_generic, nullptr);
-}
-extern "C" int emul_change_d3(int n, int order, double factor, const double *d_in, double *d_fast, double *d_generic, double *d_lean)
 {
     using namespace IVP_NS;
     auto run = [&](auto tag) {
@@ -127,14 +122,6 @@ extern "C" int emul_change_d3(int n, int order, double factor, const double *d_i
         if (factor != 1.0) bdf_change_d_generic<N>(b, order > BDF_MAXO ? BDF_MAXO : order, factor);
         for (int k = 0; k < 8; ++k)
             for (int c = 0; c < N; ++c) { d_fast[k * N + c] = a[k][c]; d_generic[k * N + c] = b[k][c]; }
-        if (d_lean) {   // the register-lean form of the IVP_BDF_DIET build
-            double l[8][N];
-            for (int k = 0; k < 8; ++k)
-                for (int c = 0; c < N; ++c) l[k][c] = d_in[k * N + c];
-            bdf_change_d_lean<N>(l, order, factor);
-            for (int k = 0; k < 8; ++k)
-                for (int c = 0; c < N; ++c) d_lean[k * N + c] = l[k][c];
-        }
     };
     switch (n) {
     case 1: run(std::integral_constant<int, 1>{}); return 0;
