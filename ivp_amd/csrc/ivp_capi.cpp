@@ -151,6 +151,7 @@ struct Tune {
     int launches_per_poll_set = 0;   // IVP_TUNE_LAUNCHES_PER_POLL given: taken literally (no extra hand-over pair)
     int lds_lu = 1;                  // large-n BDF: 0 = never keep the factors in LDS
     int defer_eval = 1;              // DOP853 t_eval sampling in a second, sample-parallel kernel (flavour 3): 0 = sample in the stepping kernel
+    int defer_events = 1;            // event roots (no terminal event) in a second kernel, one lane per step with a crossing: 0 = Brent in the stepping kernel
     int bdf_lpw = 0;                 // trajectories per wave of the BDF chunk launches: 0 = auto (spread the active set over the SIMDs)
     Tune()
     {
@@ -160,6 +161,7 @@ struct Tune {
         if (const char *e = getenv("IVP_TUNE_WINDOW")) window = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_LDS_LU")) lds_lu = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_DEFER_EVAL")) defer_eval = (int)strtol(e, nullptr, 10);
+        if (const char *e = getenv("IVP_TUNE_DEFER_EVENTS")) defer_events = (int)strtol(e, nullptr, 10);
         if (const char *e = getenv("IVP_TUNE_BDF_LPW")) bdf_lpw = (int)std::min(64l, std::max(0l, strtol(e, nullptr, 10)));
         if (const char *e = getenv("IVP_TUNE_LAUNCHES_PER_POLL")) { launches_per_poll = (int)std::min(16l, std::max(1l, strtol(e, nullptr, 10))); launches_per_poll_set = 1; }
     }
@@ -390,6 +392,13 @@ int finish_round(ivp_ctx *ctx, int *done)
     }
     P.lanes = ctx->pinned[0];
     if (P.lanes != 0) return enqueue_round(ctx);
+    if (P.a.evd_rec != nullptr && !P.sampled) {
+        // deferred event refinement: the roots of every noted step, one lane each (same hand-over as the sample kernel below)
+        P.sampled = true;
+        LAUNCH_TRY(ctx, pend_launch(ctx, IVP_LAUNCH_EVENTS, P.a, (uint32_t)P.B, false, false));
+        HIP_TRY(ctx, hipEventRecord(P.round_done, P.stream));
+        return IVP_OK;
+    }
     if (P.full == 3 && !P.sampled) {
         // deferred t_eval sampling: every trajectory has finished stepping; its noted steps are evaluated now, one lane each
         // (the solve is complete when THIS kernel is: one more turn of the round-done event)
@@ -506,7 +515,7 @@ void ivp_ctx_destroy(ivp_ctx_t *c)
                       &c->sc_next_idx, &c->sc_n_filled, &c->sc_n_log, &c->sc_n_seg, &c->sc_t_last,
                       &c->bdf_d, &c->bdf_jac, &c->bdf_lu, &c->bdf_piv, &c->sc_njev, &c->sc_nlu, &c->prev_event, &c->sc_n_ev,
                       &c->st_y0, &c->st_params, &c->st_t0, &c->st_t1, &c->st_logoff,
-                      &c->log_pool, &c->log_alloc, &c->def_rec, &c->log_off, &c->log_bsum, &c->st_log_t, &c->st_log_y};
+                      &c->log_pool, &c->log_alloc, &c->def_rec, &c->evd_rec, &c->evd_cnt, &c->log_off, &c->log_bsum, &c->st_log_t, &c->st_log_y};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : c->st_out) b.release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -732,6 +741,27 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
         if (out->n_event_hits) a.n_ev = out->n_event_hits;
         else { HIP_TRY(ctx, ctx->sc_n_ev.reserve(sizeof(uint32_t) * n_events * B)); a.n_ev = (uint32_t *)ctx->sc_n_ev.p; }
         HIP_TRY(ctx, hipMemsetAsync(a.n_ev, 0, sizeof(uint32_t) * n_events * B, s));
+        // Deferred event refinement (rk_core.h so_events_note / so_events_deferred_body): with no terminal event nothing the
+        // integration does depends on the roots, so the stepping kernels only note the steps that hold a crossing and a second
+        // kernel refines them, one lane per noted step.  Explicit methods, thread-per-trajectory / lane-cooperative kernels.
+        bool any_terminal = false;
+        for (int i = 0; i < n_events; ++i) any_terminal = any_terminal || (a.ev_terminal_dev ? opt->ev_terminal_vec[i] : opt->ev_terminal[i < 4 ? i : 3]) != 0;
+        if (!any_terminal && !group && opt->method != IVP_BDF && tune().defer_events != 0) {
+            const uint64_t ncoef = opt->method == IVP_DOPRI5 ? 5 : (opt->method == IVP_DOP853 ? 8 : 4);
+            const uint64_t fields = 4 + 3 * (uint64_t)n_events + (uint64_t)n + ncoef * (uint64_t)n;
+            const uint64_t cap = std::max<uint64_t>((uint64_t)n_events * a.max_events, 1);   // every noted step fills at least one output slot
+            const uint64_t bytes = sizeof(double) * cap * fields * B;
+            size_t free_b = 0, total_b = 0;
+            const bool fits = cap <= 0xFFFFFFFFull && (bytes <= ctx->evd_rec.cap || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= (free_b + ctx->evd_rec.cap) / 4));
+            if (fits) {
+                HIP_TRY(ctx, ctx->evd_rec.reserve((size_t)bytes));
+                HIP_TRY(ctx, ctx->evd_cnt.reserve(sizeof(uint32_t) * B));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->evd_cnt.p, 0, sizeof(uint32_t) * B, s));
+                a.evd_rec = (double *)ctx->evd_rec.p;
+                a.evd_cnt = (uint32_t *)ctx->evd_cnt.p;
+                a.evd_cap = (uint32_t)cap;
+            }
+        }
     }
     if (full) {
         if (want_eval) {

@@ -60,6 +60,7 @@ struct ivp_ctx {
     // the offsets / block sums of the scan, staging for the records of the host-pointer and multi-device forms ----
     ivp_host::DevBuf log_pool, log_alloc, log_off, log_bsum, st_log_t, st_log_y;
     ivp_host::DevBuf def_rec;   // noted steps of the deferred t_eval sampling (kernel flavour 3)
+    ivp_host::DevBuf evd_rec, evd_cnt;   // noted steps of the deferred event refinement (IvpKArgs.evd_rec) and their per-trajectory counts
     struct LogPlan {
         bool want = false;          // the next ivp_batch_submit_device on this context records into the page pool
         uint64_t reserve = 0;       // caller's estimate of the total number of records (0 = automatic)
@@ -99,7 +100,7 @@ struct ivp_ctx {
         uint64_t c = 0;             // chunk launches so far
         bool spec = false;          // the last launch of the round in flight was a speculative cooperative one
         bool paged = false;         // this solve records its accepted steps into the page pool (one-pass step log)
-        bool sampled = false;       // flavour 3: the sample kernel has been enqueued (the solve is done when it is)
+        bool sampled = false;       // flavour 3 / deferred events: the second kernel has been enqueued (the solve is done when it is)
         bool err_checked = false;
         hipStream_t stream = nullptr;
         hipEvent_t round_done = nullptr;

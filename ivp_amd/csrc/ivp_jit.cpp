@@ -29,6 +29,7 @@ namespace {
 struct JitModule {
     hipModule_t mod = nullptr;
     hipFunction_t init = nullptr, chunk = nullptr, coop = nullptr;   // coop: lane-cooperative chunk kernel (rk_coop.h), optional
+    hipFunction_t events = nullptr;   // deferred event refinement (rk_global.h event_kernel_body): full modules of problems with event functions
 };
 
 struct JitRhs {
@@ -119,6 +120,12 @@ std::string build_source(const JitRhs &r, int method, int full_in, bool ctl, boo
                   method, full, method, full,
                   (ctl && (method == IVP_RK23 || method == IVP_DOPRI5 || method == IVP_DOP853)) ? "true" : "false");
     s += buf;
+    if (r.ne > 0 && flavour == 1 && method != IVP_BDF) {
+        std::snprintf(buf, sizeof buf,
+                      "extern \"C\" __global__ __launch_bounds__(IVP_WAVE) void ivp_jit_events(const IvpKArgs a)\n"
+                      "{ ivp_jit::event_kernel_body<%d, ivp_jit::RhsUser>(a); }\n", method);
+        s += buf;
+    }
     return s;
 }
 
@@ -152,6 +159,7 @@ int load_module(JitRhs &r, const std::vector<char> &code, JitModule *out, bool c
         r.log = "kernel lookup failed";
         return IVP_ERR_HIP;
     }
+    if (hipModuleGetFunction(&out->events, out->mod, "ivp_jit_events") != hipSuccess) { out->events = nullptr; (void)hipGetLastError(); }   // only full modules with event functions have it
     return IVP_OK;
 }
 
@@ -287,6 +295,13 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, int f
         grid = (lanes + per_wave - 1) / per_wave;
     }
     hipFunction_t fn = what == IVP_LAUNCH_INIT ? m.init : m.chunk;
+    unsigned grid_y = 1;
+    if (what == IVP_LAUNCH_EVENTS) {   // one lane per noted step: grid.y strides over a trajectory's noted steps
+        if (!m.events) return hipErrorInvalidValue;
+        fn = m.events;
+        grid = (lanes + IVP_WAVE - 1) / IVP_WAVE;
+        grid_y = 4;
+    }
     if (what == IVP_LAUNCH_COOP) {
         if (!m.coop) return hipErrorInvalidValue;
         fn = m.coop;
@@ -295,5 +310,5 @@ hipError_t ivp_jit_launch(void *handle, int what, int method, int fp_mode, int f
     if (grid == 0) return hipSuccess;
     IvpKArgs ka = a;
     void *args[] = {&ka};
-    return hipModuleLaunchKernel(fn, grid, 1, 1, IVP_WAVE, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(fn, grid, grid_y, 1, IVP_WAVE, 1, 1, 0, s, args, nullptr);
 }

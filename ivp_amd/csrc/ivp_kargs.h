@@ -166,6 +166,10 @@ struct IvpKArgs {
     uint32_t log_sub_mask;               // sub-pools in use - 1 (a power of two <= IVP_LOG_SUBPOOLS: few waves, few sub-pools,
                                          // so that no region is left idle while another runs dry)
     unsigned long long *log_alloc;       // [IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE] counters (one per 128-byte line)
+    // ---- deferred event refinement (so_events_note / so_events_deferred_body in rk_core.h; no terminal events) ----
+    double *evd_rec;          // [evd_cap][F][B] noted steps, F = 4 + 3 NE + n + NCoef n (EvdRec); NULL: roots are found in the stepping kernel
+    uint32_t *evd_cnt;        // [B] noted steps of a trajectory
+    uint32_t evd_cap;         // noted steps per trajectory the buffer holds (NE * max_events: each noted step fills an output slot)
 };
 #define IVP_LOG_SLOTS 32u
 #define IVP_LOG_GROUP(np1) ((np1) <= 9 ? 8u : 1u)   /* columns per group of a page, by record length n + 1 */

@@ -1028,9 +1028,162 @@ IVP_HD void so_sample(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double xold,
 }
 
 
+// One root of event function i in the step [xold, x] (solout.rs:214-289): Brent's method on the step interpolant (xtol
+// 2e-12, rtol eps, <= 100 iterations).  g_prev / g_cur are the event values at the two ends; et / ymid receive the event point.
+template <int M, class R, class YP, class CP>
+IVP_HD void so_event_root(int i, double xold, double x, double g_prev, double g_cur, const double *y, const YP &yold, const CP &cont,
+                          double h, double ixold, const double *p, double &et, double (&ymid)[R::N])
+{
+    constexpr int N = R::N, NE = R::NE > 0 ? R::NE : 1;
+    const double XTOL = 2e-12, RTOL = 2.220446049250313e-16;
+    double ea = xold, eb = x, fa = g_prev, fb = g_cur;
+    double gmid[NE];
+    if (fabs(fa) <= XTOL) {
+        et = ea;
+#pragma unroll
+        for (int c = 0; c < N; ++c) ymid[c] = yold[c];
+    } else if (fabs(fb) <= XTOL) {
+        et = eb;
+#pragma unroll
+        for (int c = 0; c < N; ++c) ymid[c] = y[c];
+    } else {
+        double ec = ea, fc = fa, ed = eb - ea, ee = ed;
+#pragma unroll 1
+        for (int it = 0; it < 100; ++it) {
+            if (fb * fc > 0.0) { ec = ea; fc = fa; ed = eb - ea; ee = ed; }
+            if (fabs(fc) < fabs(fb)) { ea = eb; eb = ec; ec = ea; fa = fb; fb = fc; fc = fa; }
+            const double tol1 = 2.0 * RTOL * fabs(eb) + 0.5 * XTOL;
+            const double xm = 0.5 * (ec - eb);
+            if (fabs(xm) <= tol1 || fb == 0.0) break;
+            if (fabs(ee) >= tol1 && fabs(fa) > fabs(fb)) {
+                double sq, pp, qq;
+                if (ea == ec) {
+                    sq = fb / fa;
+                    pp = 2.0 * xm * sq;
+                    qq = 1.0 - sq;
+                } else {
+                    const double q_val = fa / fc, rr = fb / fc;
+                    sq = fb / fa;
+                    pp = sq * (2.0 * xm * q_val * (q_val - rr) - (eb - ea) * (rr - 1.0));
+                    qq = (q_val - 1.0) * (rr - 1.0) * (sq - 1.0);
+                }
+                if (qq > 0.0) pp = -pp; else qq = -qq;
+                if (2.0 * pp < fmin(3.0 * xm * qq - fabs(tol1 * qq), fabs(ee * qq))) { ee = ed; ed = pp / qq; }
+                else { ed = xm; ee = ed; }
+            } else { ed = xm; ee = ed; }
+            ea = eb; fa = fb;
+            if (fabs(ed) > tol1) eb += ed;
+            else eb += xm > 0.0 ? tol1 : -tol1;
+            interpolate<M, N>(eb, ymid, cont, ixold, h);
+            R::events(eb, ymid, gmid, p);
+            double fnew = gmid[0];
+#pragma unroll
+            for (int q = 1; q < NE; ++q) fnew = (q == i) ? gmid[q] : fnew;
+            fb = fnew;
+        }
+        interpolate<M, N>(eb, ymid, cont, ixold, h);
+        et = eb;
+    }
+}
+
+// did event function values g_prev -> g_cur cross zero in the watched direction? (solout.rs:186-199)
+IVP_HD bool so_event_crossed(int dir, double g_prev, double g_cur)
+{
+    if (dir == 0) return (g_prev <= 0.0 && g_cur >= 0.0) || (g_prev >= 0.0 && g_cur <= 0.0);
+    if (dir > 0) return g_prev < 0.0 && g_cur >= 0.0;
+    return g_prev > 0.0 && g_cur <= 0.0;
+}
+
+// DEFERRED event refinement (IvpKArgs.evd_rec != nullptr; the host asks for it only when NO event is terminal, the method
+// is an explicit one and the problem runs in the thread-per-trajectory / lane-cooperative kernels).  A root search in one
+// lane stalls the other 63 of its wavefront (BASELINE C2 with one event function: 0.9 % of the steps hold a crossing, 44 %
+// of the wave-attempts waited for a Brent iteration: 2.9 -> 4.8 ms).  Without terminal events nothing the integration
+// does depends on the roots, so the stepping kernel only NOTES a step with a crossing -- its interpolant, the event values
+// at both ends and the output slot of every crossing (event_hits counts on as before) -- and event_kernel_t finds the
+// roots afterwards, one lane per noted step, with the very same so_event_root.  Record (SoA over the batch like every
+// other array): evd_rec[(q * F + f) * B + j], F = 4 + 3 NE + n + NCoef n fields: xold, x, interpolant anchor, h,
+// slot[NE] (-1: no crossing, or beyond max_events: counted, not stored), g_prev[NE], g_cur[NE], y[n], cont[NCoef n].
+// At most NE * max_events noted steps per trajectory (each fills at least one slot).
+template <int M, int NT, int NE>
+struct EvdRec { enum { SLOT = 4, GPREV = 4 + NE, GCUR = 4 + 2 * NE, Y = 4 + 3 * NE, CONT = 4 + 3 * NE + NT, F = 4 + 3 * NE + NT + NCoef<M>::v * NT }; };
+
+template <int M, class R, class CP>
+IVP_HD void so_events_note(const IvpKArgs &a, uint32_t j, double xold, double x, const double *y, const CP &cont, double h, double ixold,
+                           const double *g_curr)
+{
+    constexpr int N = R::N, NE = R::NE > 0 ? R::NE : 1, NC = NCoef<M>::v * N;
+    using MAP = typename OutMap<R>::type;
+    using F = EvdRec<M, MAP::NT, NE>;
+    const size_t B = a.B;
+    double slot[NE], g_prev[NE];
+    bool store = false;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        g_prev[i] = a.prev_event[(size_t)i * B + j];
+        const int dir = a.ev_direction_dev ? a.ev_direction_dev[i] : a.ev_direction[i < 4 ? i : 3];
+        slot[i] = -1.0;
+        if (so_event_crossed(dir, g_prev[i], g_curr[i])) {
+            const uint32_t k = a.n_ev[(size_t)i * B + j];
+            a.n_ev[(size_t)i * B + j] = k + 1;   // event_hits
+            if (k < a.max_events) { slot[i] = (double)k; store = true; }
+        }
+    }
+    if (store) {
+        const uint32_t q = a.evd_cnt[j];
+        if (q < a.evd_cap) {
+            double *rec = a.evd_rec + (size_t)q * (size_t)F::F * B + j;
+            if (MAP::leader()) {
+                rec[0] = xold; rec[B] = x; rec[2 * B] = ixold; rec[3 * B] = h;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    rec[(size_t)(F::SLOT + i) * B] = slot[i]; rec[(size_t)(F::GPREV + i) * B] = g_prev[i]; rec[(size_t)(F::GCUR + i) * B] = g_curr[i];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (MAP::own(c)) rec[(size_t)(F::Y + MAP::gi(c)) * B] = y[c];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (MAP::own(c % N)) rec[(size_t)(F::CONT + (c / N) * MAP::NT + MAP::gi(c % N)) * B] = cont[c];
+        }
+        a.evd_cnt[j] = q + 1;
+    }
+}
+
+// one noted step (thread-per-trajectory: plain functor R, all n components in this lane)
+template <int M, class R>
+IVP_HD void so_events_deferred_body(const IvpKArgs &a, uint32_t j, uint32_t q)
+{
+    constexpr int N = R::N, P = R::P, NE = R::NE > 0 ? R::NE : 1, NC = NCoef<M>::v * N;
+    using F = EvdRec<M, N, NE>;
+    const size_t B = a.B;
+    const double *rec = a.evd_rec + (size_t)q * (size_t)F::F * B + j;
+    const double xold = rec[0], x = rec[B], ixold = rec[2 * B], h = rec[3 * B];
+    double p[P > 0 ? P : 1], y[N];
+    ContRegs<NC> cont;
+#pragma unroll
+    for (int c = 0; c < P; ++c) p[c] = a.params[c * B + j];
+#pragma unroll
+    for (int c = 0; c < N; ++c) y[c] = rec[(size_t)(F::Y + c) * B];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cont.set(c, rec[(size_t)(F::CONT + c) * B]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const double ks = rec[(size_t)(F::SLOT + i) * B];
+        if (ks >= 0.0) {
+            double et, ymid[N];
+            // the explicit methods pass their coefficient block as yold too (cont[0 .. n) = y at xold; dopri5 / dop853 / rk23 / rk4_attempt)
+            so_event_root<M, R>(i, xold, x, rec[(size_t)(F::GPREV + i) * B], rec[(size_t)(F::GCUR + i) * B], y, cont, cont, h, ixold, p, et, ymid);
+            const size_t k = (size_t)ks;
+            a.t_events[((size_t)i * a.max_events + k) * B + j] = et;
+#pragma unroll
+            for (int c = 0; c < N; ++c) a.y_events[(((size_t)i * a.max_events + k) * N + c) * B + j] = ymid[c];
+        }
+    }
+}
+
 // Event detection (solout.rs:158-331): zero crossings of R::events between the previous and the current accepted
-// point, refined with Brent's method on the step interpolant (xtol 2e-12, rtol eps, <= 100 iterations), processed
-// in chronological order; a terminal event appends its point to the output and interrupts the integration.
+// point, refined with Brent's method on the step interpolant (so_event_root), processed in chronological order; a
+// terminal event appends its point to the output and interrupts the integration.
 template <int M, class R, class YP, class CP>
 IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
                       const double *y, const YP &yold, const CP &cont, double h, double ixold)
@@ -1045,6 +1198,14 @@ IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double
         for (int i = 0; i < NE; ++i) a.prev_event[(size_t)i * B + j] = g_curr[i];
         return false;
     }
+    if constexpr (M != M_BDF) {
+        if (a.evd_rec != nullptr) {
+            so_events_note<M, R>(a, j, xold, x, y, cont, h, ixold, g_curr);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) a.prev_event[(size_t)i * B + j] = g_curr[i];
+            return false;
+        }
+    }
     double det_t[NE], det_y[NE][N];
     int det_i[NE];
     int ndet = 0;
@@ -1052,61 +1213,10 @@ IVP_HD bool so_events(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double
     for (int i = 0; i < NE; ++i) {
         const double g_prev = a.prev_event[(size_t)i * B + j], g_cur = g_curr[i];
         const int dir = a.ev_direction_dev ? a.ev_direction_dev[i] : a.ev_direction[i < 4 ? i : 3];
-        bool crossed;
-        if (dir == 0) crossed = (g_prev <= 0.0 && g_cur >= 0.0) || (g_prev >= 0.0 && g_cur <= 0.0);
-        else if (dir > 0) crossed = g_prev < 0.0 && g_cur >= 0.0;
-        else crossed = g_prev > 0.0 && g_cur <= 0.0;
-        if (crossed) {
-            const double XTOL = 2e-12, RTOL = 2.220446049250313e-16;
-            double ea = xold, eb = x, fa = g_prev, fb = g_cur;
-            double ymid[N], gmid[NE];
+        if (so_event_crossed(dir, g_prev, g_cur)) {
+            double ymid[N];
             double et;
-            if (fabs(fa) <= XTOL) {
-                et = ea;
-#pragma unroll
-                for (int c = 0; c < N; ++c) ymid[c] = yold[c];
-            } else if (fabs(fb) <= XTOL) {
-                et = eb;
-#pragma unroll
-                for (int c = 0; c < N; ++c) ymid[c] = y[c];
-            } else {
-                double ec = ea, fc = fa, ed = eb - ea, ee = ed;
-#pragma unroll 1
-                for (int it = 0; it < 100; ++it) {
-                    if (fb * fc > 0.0) { ec = ea; fc = fa; ed = eb - ea; ee = ed; }
-                    if (fabs(fc) < fabs(fb)) { ea = eb; eb = ec; ec = ea; fa = fb; fb = fc; fc = fa; }
-                    const double tol1 = 2.0 * RTOL * fabs(eb) + 0.5 * XTOL;
-                    const double xm = 0.5 * (ec - eb);
-                    if (fabs(xm) <= tol1 || fb == 0.0) break;
-                    if (fabs(ee) >= tol1 && fabs(fa) > fabs(fb)) {
-                        double sq, pp, qq;
-                        if (ea == ec) {
-                            sq = fb / fa;
-                            pp = 2.0 * xm * sq;
-                            qq = 1.0 - sq;
-                        } else {
-                            const double q_val = fa / fc, rr = fb / fc;
-                            sq = fb / fa;
-                            pp = sq * (2.0 * xm * q_val * (q_val - rr) - (eb - ea) * (rr - 1.0));
-                            qq = (q_val - 1.0) * (rr - 1.0) * (sq - 1.0);
-                        }
-                        if (qq > 0.0) pp = -pp; else qq = -qq;
-                        if (2.0 * pp < fmin(3.0 * xm * qq - fabs(tol1 * qq), fabs(ee * qq))) { ee = ed; ed = pp / qq; }
-                        else { ed = xm; ee = ed; }
-                    } else { ed = xm; ee = ed; }
-                    ea = eb; fa = fb;
-                    if (fabs(ed) > tol1) eb += ed;
-                    else eb += xm > 0.0 ? tol1 : -tol1;
-                    interpolate<M, N>(eb, ymid, cont, ixold, h);
-                    R::events(eb, ymid, gmid, L.p);
-                    double fnew = gmid[0];
-#pragma unroll
-                    for (int q = 1; q < NE; ++q) fnew = (q == i) ? gmid[q] : fnew;
-                    fb = fnew;
-                }
-                interpolate<M, N>(eb, ymid, cont, ixold, h);
-                et = eb;
-            }
+            so_event_root<M, R>(i, xold, x, g_prev, g_cur, y, yold, cont, h, ixold, L.p, et, ymid);
             // append to the detected list (ndet is a run-time count: guarded static slots)
 #pragma unroll
             for (int q = 0; q < NE; ++q)

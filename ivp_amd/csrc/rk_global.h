@@ -49,6 +49,20 @@ __global__ __launch_bounds__(IVP_WAVE) void sample_kernel_t(const IvpKArgs a)
     for (uint32_t k = blockIdx.y; k < nd; k += gridDim.y) dop853_sample_body<R>(a, j, k);
 }
 
+// Deferred event refinement: one lane per noted step, same tiling as the sample kernel (so_events_deferred_body, rk_core.h).
+template <int M, class R>
+__device__ __forceinline__ void event_kernel_body(const IvpKArgs &a)
+{
+    const uint32_t j = blockIdx.x * IVP_WAVE + threadIdx.x;
+    if (j >= a.B) return;
+    if constexpr (R::NE > 0 && M != M_BDF) {
+        const uint32_t nd = min(a.evd_cnt[j], a.evd_cap);
+        for (uint32_t q = blockIdx.y; q < nd; q += gridDim.y) so_events_deferred_body<M, R>(a, j, q);
+    }
+}
+template <int M, class R>
+__global__ __launch_bounds__(IVP_WAVE) void event_kernel_t(const IvpKArgs a) { event_kernel_body<M, R>(a); }
+
 template <int M, class R, int FULL, bool CTL = false>
 __device__ __forceinline__ void chunk_kernel_body(const IvpKArgs &a)
 {

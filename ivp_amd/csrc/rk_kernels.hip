@@ -87,6 +87,15 @@ hipError_t launch_flavour(int what, int full, const IvpKArgs &a, uint32_t lanes,
         }
     }
     if (what == IVP_LAUNCH_SAMPLE) return hipErrorInvalidValue;
+    if (what == IVP_LAUNCH_EVENTS) {   // one lane per noted step: grid.y strides over a trajectory's noted steps
+        if constexpr (R::NE > 0 && !IVP_HOIST) {
+            const dim3 grid((lanes + IVP_WAVE - 1) / IVP_WAVE, 4), block(IVP_WAVE);
+            (void)hipGetLastError();
+            hipLaunchKernelGGL((event_kernel_t<M, R>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     return full ? launch_one<M, R, 1>(what, a, lanes, s) : launch_one<M, R, 0>(what, a, lanes, s);
 }
 

@@ -8,7 +8,9 @@
 static inline int ivp_group_width(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
 
 enum { IVP_LAUNCH_INIT = 0, IVP_LAUNCH_CHUNK = 1, IVP_LAUNCH_COOP = 2 /* hiprtc modules only */,
-       IVP_LAUNCH_SAMPLE = 3 /* flavour 3's second kernel: one lane per noted step (rk_global.h sample_kernel_t; lean builds, DOP853) */ };
+       IVP_LAUNCH_SAMPLE = 3 /* flavour 3's second kernel: one lane per noted step (rk_global.h sample_kernel_t; lean builds, DOP853) */,
+       IVP_LAUNCH_EVENTS = 4 /* deferred event refinement: one lane per noted step (rk_global.h event_kernel_t; problems with event functions,
+                                flavour 1, explicit methods, IvpKArgs.evd_rec != NULL) */ };
 
 // `lanes` = upper bound of trajectories the launch has to cover (grid = ceil(lanes / 64) one-wave blocks).
 // `full` = flavour of the kernel: 0 end state only, 1 the whole device DefaultSolOut, 2 log-only (every accepted step recorded,

@@ -52,6 +52,11 @@ static void run_flavour(int full, const IvpKArgs &a, uint64_t *chunks)
         }
     }
     full ? run_all<M, R, 1>(a, chunks) : run_all<M, R, 0>(a, chunks);
+    if constexpr (R::NE > 0 && M != M_BDF) {   // deferred event refinement (evd_rec set): one "lane" per noted step, as event_kernel_t does
+        if (full && a.evd_rec != nullptr)
+            for (uint32_t j = 0; j < a.B; ++j)
+                for (uint32_t q = 0; q < a.evd_cnt[j] && q < a.evd_cap; ++q) so_events_deferred_body<M, R>(a, j, q);
+    }
 }
 
 template <class R>

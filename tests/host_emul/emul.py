@@ -43,6 +43,7 @@ class KArgs(C.Structure):  # must match ivp_amd/csrc/ivp_kargs.h
         ("window", C.c_uint32),
         ("def_rec", VP), ("def_cap", C.c_uint32),
         ("log_pool", VP), ("log_region", C.c_uint64), ("log_sub_mask", C.c_uint32), ("log_alloc", VP),
+        ("evd_rec", VP), ("evd_cnt", VP), ("evd_cap", C.c_uint32),
     ]
 
 
@@ -80,7 +81,7 @@ def lib(fast=False):
 
 def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-6, max_steps=None, t_eval=None,
                 first_step=None, max_step=None, min_step=None, dense_output=False, max_log=0, chunk=64, fast=False,
-                event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None, flavour_log_only=True, defer_eval=True):
+                event_direction=None, event_terminal=None, max_events=16, settings=None, paged_log=None, flavour_log_only=True, defer_eval=True, defer_events=True):
     """``paged_log=pool_doubles``: the one-pass step log -- records go to wave pages in a pool of that many doubles, chained
     per trajectory (ivp_kargs.h; on the host a "wave" is one lane, so every page has one column); ``res['log_pool']``,
     ``res['log_cur']``, ``res['log_used']`` (doubles) and ``res['log_overflow']`` come back next to ``n_log``
@@ -179,6 +180,13 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
         res["n_ev"] = np.zeros((ne_ev, B), dtype=np.uint32)
         res["t_term"] = np.full(B, np.nan)
         a.t_events, a.y_events, a.n_ev, a.t_term = p(res["t_events"]), p(res["y_events"]), p(res["n_ev"]), p(res["t_term"])
+        # the library's rule (ivp_capi.cpp): no terminal event, explicit method -> the roots are found after the stepping
+        if defer_events and method != "BDF" and not any(int(t or 0) for t in (event_terminal or [])):
+            fields = 4 + 3 * ne_ev + n + NCOEF[m] * n
+            cap = max(ne_ev * max_events, 1)
+            res["evd_rec"] = np.full((cap, fields, B), np.nan)
+            res["evd_cnt"] = np.zeros(B, dtype=np.uint32)
+            a.evd_rec, a.evd_cnt, a.evd_cap = p(res["evd_rec"]), p(res["evd_cnt"]), cap
     chunks = C.c_uint64(0)
     # the library's choice of kernel flavour (ivp_capi.cpp): log-only when every accepted step is recorded and nothing else is
     # asked of the device DefaultSolOut

@@ -240,3 +240,33 @@ def test_div_by_small_constant_is_ieee_division():
     for c in (3, 5):
         assert lib.emul_div_small_const(c, np.ascontiguousarray(x), n) == 0
         assert lib.emul_div_small_const(c, np.ascontiguousarray(structured), structured.size) == 0
+
+
+@pytest.mark.parametrize("method", ["RK23", "DOPRI5", "DOP853", "RK4"])
+def test_deferred_event_refinement_equals_the_inline_search(method):
+    """Without terminal events the stepping bodies only NOTE the steps that hold a crossing (so_events_note) and the roots are
+    found afterwards, one noted step at a time (so_events_deferred_body) -- same so_event_root, same inputs: every event
+    record, every counter and every other output bit for bit as with Brent inside the step; hits beyond max_events are
+    counted but neither stored nor refined."""
+    B = 9
+    rng = np.random.default_rng(12)
+    y0 = np.stack([np.cos(rng.uniform(0, 1, B)), np.sin(rng.uniform(0, 1, B))])
+    kw = dict(method=method, max_log=4096, chunk=5, event_direction=[0], event_terminal=[0])
+    if method != "RK4":
+        kw.update(rtol=1e-7, atol=1e-9)
+    for (t0, t1, max_events) in ((0.0, 20.0, 16), (20.0, 0.0, 3)):
+        a = emul_batch("sho_ev", y0, None, t0, t1, max_events=max_events, defer_events=False, **kw)
+        d = emul_batch("sho_ev", y0, None, t0, t1, max_events=max_events, defer_events=True, **kw)
+        assert "evd_rec" in d and "evd_rec" not in a
+        assert (d["n_ev"] >= 5).all() and np.array_equal(a["n_ev"], d["n_ev"])
+        assert np.array_equal(a["t_events"], d["t_events"], equal_nan=True) and np.array_equal(a["y_events"], d["y_events"], equal_nan=True)
+        assert (d["evd_cnt"] == np.minimum(d["n_ev"][0], max_events)).all()
+        for k in ("y_end", "t_log", "y_log", "n_log", "nfev", "naccpt", "status", "h_next"):
+            assert np.array_equal(a[k], d[k], equal_nan=True), k
+    # three event functions, two of them crossing in the same step now and then
+    y0 = np.array([[4 / 9], [20 / 81]]).repeat(3, axis=1) * np.array([1.0, 1.001, 0.999])
+    kw = dict(method=method, max_log=4096, event_direction=[0, 0, 0], event_terminal=[0, 0, 0])
+    a = emul_batch("rational_ev", y0, None, 8.0, 5.0, defer_events=False, **kw)
+    d = emul_batch("rational_ev", y0, None, 8.0, 5.0, defer_events=True, **kw)
+    assert d["n_ev"].sum() > 0 and np.array_equal(a["n_ev"], d["n_ev"])
+    assert np.array_equal(a["t_events"], d["t_events"], equal_nan=True) and np.array_equal(a["y_events"], d["y_events"], equal_nan=True)
