@@ -240,7 +240,9 @@ typedef struct {
      * ivp_batch_solve_multi_host() and a device array for the device-pointer entry points.  When non-NULL it holds B+1 record
      * offsets; trajectory b's k-th record then lives at t_log[log_offsets[b] + k] and
      * y_log[(log_offsets[b] + k) * n + c] (time-major like Vec<Vec<f64>>), so the log takes sum(n_log) records
-     * instead of max_log x B.  Two passes: a counting solve (options.count_log = 1, only n_log is written), an
+     * instead of max_log x B.  Callers that want the whole log should use ivp_batch_solve_logged*() below: ONE integration
+     * that records as it goes and delivers offsets, t_log and y_log in this very layout (ABI v5).  The two-pass form stays
+     * for callers that manage the offsets themselves: a counting solve (options.count_log = 1, only n_log is written), an
      * exclusive scan of n_log, then the filling solve with these offsets. */
     const uint64_t *log_offsets;
 } ivp_batch_result_t;

@@ -18,6 +18,8 @@ import torch  # noqa: E402
 
 import ivp_amd  # noqa: E402
 from ivp_amd import workloads as W  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_sha import kernel_sources_sha256  # noqa: E402
 
 
 def main():
@@ -56,7 +58,7 @@ def main():
             ts.append((time.perf_counter() - t) * 1e3)
         return float(np.median(ts)), float(np.min(ts)), out
 
-    res = {"workload": a.workload, "fp": a.fp, "B": int(y0.shape[1])}
+    res = {"workload": a.workload, "fp": a.fp, "B": int(y0.shape[1]), "kernel_sources_sha256": kernel_sources_sha256()}
     if a.only in ("all", "end"):
         med, mn, out = timed(lambda prev: ivp_amd.solve_ivp_batch(f, t0, t1d, y0d, pd, opts, ctx, prev), a.solves)
         res["end_state_ms"] = {"median": med, "min": mn}
