@@ -276,7 +276,9 @@ int enqueue_round(ivp_ctx *ctx)
     // Results never depend on how attempts are cut into launches.
     uint32_t window = 0;
     // (not for problems with event functions: the root-finding of a crossing is a long divergent stretch that a second wave
-    // on the SIMD hides; measured on C2 with the x-axis crossing event 4.5 ms with full launches, 5.0 with windows)
+    // on the SIMD hides; measured on C2 with the x-axis crossing event 4.5 ms with full launches, 5.0 with windows.  With
+    // deferred refinement there is no such stretch, but the full DefaultSolOut kernel gains nothing from windows either:
+    // 5 x 0.38 ms against 3 x 0.58 ms, 3.82 against 3.79 ms per solve -- round 4, profiles/EXPERIMENTS.md A6)
     // (and only while this solve has the device to itself: with other solves in flight the SIMDs a ragged round leaves idle
     // are not idle)
     const bool alone = inflight_on(ctx->device).load(std::memory_order_relaxed) <= 1;
@@ -786,7 +788,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
                 for (size_t b = 0; b < B; ++b) cap = std::max<uint64_t>(cap, opt->t_eval_offsets[b + 1] - opt->t_eval_offsets[b]);
             }
             cap = std::max<uint64_t>(cap, 1);
-            HIP_TRY(ctx, ctx->def_rec.reserve(sizeof(double) * (size_t)cap * (size_t)(2 * n + 5) * B));
+            HIP_TRY(ctx, ctx->def_rec.reserve(sizeof(double) * (size_t)cap * (size_t)(n + 4) * B));
             a.def_rec = (double *)ctx->def_rec.p;
             a.def_cap = (uint32_t)cap;
         }

@@ -134,7 +134,7 @@ struct IvpKArgs {
                               // f64 pipe of its SIMD on its own, so a launch of 1563 waves on 1024 SIMDs lasts as long as one of
                               // 2048: the launch loop cuts such a launch down to whole multiples of one wave per SIMD.
     // ---- deferred t_eval sampling (kernel flavour 3: DOP853, so_defer_samples / dop853_sample_body in rk_core.h) ----
-    double *def_rec;          // [def_cap][2 n + 5][B] noted steps: x, h, first / end t_eval index, first output position, y[n], k1[n];
+    double *def_rec;          // [def_cap][n + 4][B] noted steps: x, h, {first, end} t_eval index, first output position, y[n];
                               // a trajectory's count of noted steps lives in n_seg (dense-output segments are not collected in this flavour)
     uint32_t def_cap;         // noted steps per trajectory the buffer holds (one per t_eval point at most)
     // ---- one-pass accepted-step log (so_push_log): records go to WAVE PAGES drawn from a device pool ----

@@ -1301,11 +1301,14 @@ IVP_HD void so_log_accepted(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, 
 // functions, no dense-output collection).  DOP853's interpolant costs three more right-hand-side evaluations per step that is
 // sampled (dop853.rs:474-560); in lock-step a WAVE pays them whenever ANY of its 64 trajectories has a sample in the step --
 // with 128 samples per ~450 steps that is nearly every step (BASELINE C3: 12.8 -> 23.8 ms).  Here the stepping kernel only
-// NOTES a sampled step -- (x, h, y, k1), the t_eval indices it consumes and where its samples go (so_defer_samples) -- and
+// NOTES a sampled step -- (x, h, y), the t_eval indices it consumes and where its samples go (so_defer_samples) -- and
 // a second kernel with one lane per noted step (dop853_sample_body) redoes that step from (x, h, y, k1) with the very same
 // expressions, evaluates the dense stages and the polynomial and writes the samples: the same arithmetic per sampled step
-// as the reference, no union over a wave, every lane busy.  Record layout: def_rec[(k * F + f) * B + j], F = 2 n + 5 fields
-// x, h, first / end t_eval index, first output position, y[n], k1[n]; L.n_seg counts a trajectory's noted steps.
+// as the reference, no union over a wave, every lane busy.  Record layout: def_rec[(k * F + f) * B + j], F = n + 4 fields
+// x, h, {first, end} t_eval index (two u32 in one 8-byte field), first output position, y[n]; L.n_seg counts a trajectory's
+// noted steps.  k1 = f(x, y) is not stored: the stepping kernel's k1 IS R::ode(x, y) -- the last stage of the previous step,
+// dop853.rs:443, or init's f(x0, y0) -- so the sample kernel evaluates it again (same function, same inputs, same bits) and
+// the notes of BASELINE C3 with 128 samples shrink from 9.2 GB to 6.1 GB.
 template <int N, class MAP>
 IVP_HD void so_emit_eval_at(const IvpKArgs &a, uint32_t j, size_t k, int32_t ti, const double *yv)
 {
@@ -1323,7 +1326,7 @@ IVP_HD void so_emit_eval_at(const IvpKArgs &a, uint32_t j, size_t k, int32_t ti,
 }
 template <class R>
 IVP_HD void so_defer_samples(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L, double xold, double x,
-                             const double *yold, const double *k1old, const double *ynew, double h)
+                             const double *yold, const double *ynew, double h)
 {
     constexpr int N = R::N;
     using MAP = typename OutMap<R>::type;
@@ -1348,13 +1351,13 @@ IVP_HD void so_defer_samples(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L,
     if (cnt > 0) {
         if (L.n_seg < a.def_cap) {
             const size_t B = a.B;
-            double *rec = a.def_rec + (size_t)L.n_seg * (size_t)(2 * MAP::NT + 5) * B + j;
+            double *rec = a.def_rec + (size_t)L.n_seg * (size_t)(MAP::NT + 4) * B + j;
             if (MAP::leader()) {
-                rec[0] = xold; rec[B] = h; rec[2 * B] = (double)i0; rec[3 * B] = (double)i; rec[4 * B] = (double)L.n_filled;
+                rec[0] = xold; rec[B] = h; rec[2 * B] = u2d((uint64_t)(uint32_t)i0 | ((uint64_t)(uint32_t)i << 32)); rec[3 * B] = (double)L.n_filled;
             }
 #pragma unroll
             for (int c = 0; c < N; ++c)
-                if (MAP::own(c)) { rec[(size_t)(5 + MAP::gi(c)) * B] = yold[c]; rec[(size_t)(5 + MAP::NT + MAP::gi(c)) * B] = k1old[c]; }
+                if (MAP::own(c)) rec[(size_t)(4 + MAP::gi(c)) * B] = yold[c];
         }
         L.n_seg += 1;
         L.n_filled += cnt;
@@ -1801,15 +1804,17 @@ IVP_HD void dop853_sample_body(const IvpKArgs &a, uint32_t j, uint32_t kd)
     constexpr int N = R::N, P = R::P;
     using namespace dop853_tab;
     const size_t B = a.B;
-    const double *rec = a.def_rec + (size_t)kd * (size_t)(2 * N + 5) * B + j;
+    const double *rec = a.def_rec + (size_t)kd * (size_t)(N + 4) * B + j;
     const double x = rec[0], h = rec[B];
-    const int32_t i0 = (int32_t)rec[2 * B], i1 = (int32_t)rec[3 * B];
-    size_t pos = (size_t)rec[4 * B];
+    const uint64_t idx = d2u(rec[2 * B]);
+    const int32_t i0 = (int32_t)(uint32_t)idx, i1 = (int32_t)(uint32_t)(idx >> 32);
+    size_t pos = (size_t)rec[3 * B];
     double y[N], k1[N], p[P > 0 ? P : 1];
 #pragma unroll
-    for (int c = 0; c < N; ++c) { y[c] = rec[(size_t)(5 + c) * B]; k1[c] = rec[(size_t)(5 + N + c) * B]; }
+    for (int c = 0; c < N; ++c) y[c] = rec[(size_t)(4 + c) * B];
 #pragma unroll
     for (int c = 0; c < P; ++c) p[c] = a.params[c * B + j];
+    R::ode(x, y, k1, p);   // the step's first stage: what the stepping kernel held as k1 (see the record layout above)
     double k2[N], k3[N], k4[N], k5[N], k6[N], k7[N], k8[N], k9[N], k10[N], y1[N];
 { const double cA21 = KC(A21);
 #pragma unroll
@@ -2129,7 +2134,7 @@ IVP_HD bool dop853_attempt(const IvpKArgs &a, uint32_t j, Lane<R::N, R::P> &L)
             }
 }
         }
-        if (FULL == 3) so_defer_samples<R>(a, j, L, x, xph, y, k1, k5, h);   // before y / k1 (= L.y / L.k1) move on
+        if (FULL == 3) so_defer_samples<R>(a, j, L, x, xph, y, k5, h);   // before y (= L.y) moves on
 #pragma unroll
         for (int i = 0; i < N; ++i) { L.k1[i] = k4[i]; L.y[i] = k5[i]; }
         L.x = xph;

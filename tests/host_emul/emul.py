@@ -196,7 +196,7 @@ def solve_batch(rhs, y0, params, t0, t1, *, method="DOPRI5", rtol=1e-3, atol=1e-
     if m == 2 and t_eval is not None and len(np.atleast_1d(t_eval)) > 0 and not dense_output and ne_ev == 0 and defer_eval:
         flavour = 3
         cap = max(len(np.atleast_1d(t_eval)), 1)
-        res["def_rec"] = np.full((cap, 2 * n + 5, B), np.nan)
+        res["def_rec"] = np.full((cap, n + 4, B), np.nan)
         a.def_rec, a.def_cap = p(res["def_rec"]), cap
     rc = L.emul_solve(m, rid, flavour, C.byref(a), C.byref(chunks))
     if rc == -5:
