@@ -830,7 +830,7 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
             if (!ctx->alloc_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->alloc_host, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, hipHostMallocDefault));
             HIP_TRY(ctx, hipMemsetAsync(ctx->log_alloc.p, 0, sizeof(unsigned long long) * IVP_LOG_SUBPOOLS * IVP_LOG_ALLOC_STRIDE, s));
             a.log_pool = (double *)ctx->log_pool.p;
-            a.log_region = (ctx->log_pool.cap / 8) / subs;   // (a region stays below 2^40 doubles: the counters' low field)
+            a.log_region = ((ctx->log_pool.cap / 8) / subs) & ~(unsigned long long)15u;   // whole 128-byte lines (pages are; IVP_LOG_HDR); a region stays below 2^40 doubles: the counters' low field
             a.log_sub_mask = subs - 1u;
             a.log_alloc = (unsigned long long *)ctx->log_alloc.p;
             a.t_log = a.log_pool;   // "mode 2" marker of the device DefaultSolOut (so_sample); the records go to the pages

@@ -172,6 +172,11 @@ struct IvpKArgs {
     uint32_t evd_cap;         // noted steps per trajectory the buffer holds (NE * max_events: each noted step fills an output slot)
 };
 #define IVP_LOG_SLOTS 32u
+/* doubles before a page's first column group: page header + column headers, rounded up to a whole 128-byte line so that every
+ * slot row of a group -- W (n + 1) doubles = 64 (n + 1) bytes at W = 8 -- starts on a 64-byte boundary: a wave's stores of one
+ * attempt then fill whole 64-byte sectors (pages themselves are multiples of 128 bytes from a 128-byte-aligned pool: the
+ * active pages of a big batch, ~50 KB per resident wave, fit no cache, and sectors written in two halves went to HBM twice) */
+#define IVP_LOG_HDR(cols) ((1u + 2u * (cols) + 15u) & ~15u)
 #define IVP_LOG_GROUP(np1) ((np1) <= 9 ? 8u : 1u)   /* columns per group of a page, by record length n + 1 */
 #define IVP_LOG_SUBPOOLS 64u
 #define IVP_LOG_ALLOC_STRIDE 16u

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kGatherThreads) void log_gather_kernel(const double
     const size_t acols = (size_t)((entry >> 2) & 0x3Fu) + 1u;
     const uint32_t agroups = (uint32_t)((acols + W - 1u) / W);
     // (arenas of more than one page are made of IVP_LOG_SLOTS-slot pages: so_log_attempt in rk_core.h)
-    const size_t page_stride = 1u + 2u * acols + (size_t)agroups * (size_t)IVP_LOG_SLOTS * W * np1;
+    const size_t page_stride = IVP_LOG_HDR(acols) + (((size_t)agroups * (size_t)IVP_LOG_SLOTS * W * np1 + 15u) & ~(size_t)15u);   // = ivp_log_page_doubles (rk_core.h)
     const uint32_t lane = threadIdx.x & (IVP_WAVE - 1), wv = threadIdx.x / IVP_WAVE, row = W * np1;
     extern __shared__ double tiles[];
     double *tile = tiles + (size_t)wv * tile_doubles;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kGatherThreads) void log_gather_kernel(const double
         if (p < pages) { cols = ((const uint32_t *)(pool + page))[0]; slots = ((const uint32_t *)(pool + page))[1]; }
         const bool have = cols != 0u && g * W < cols;   // not: a page its wave never opened / a group the page does not have
         const uint32_t c0 = g * W, gc = have ? min(W, cols - c0) : 0u;
-        const double *src = pool + page + 1u + 2u * (size_t)cols + (size_t)g * slots * row;
+        const double *src = pool + page + IVP_LOG_HDR((size_t)cols) + (size_t)g * slots * row;
         // The group in one piece (n <= 8): its loads are issued FIRST -- they depend on the page header only -- and travel
         // while the column headers and the trajectories' offsets are fetched.
         double v[kGroupLoads];

@@ -813,7 +813,7 @@ IVP_HD void so_emit_eval(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, int32_t t
 IVP_HD unsigned long long ivp_log_page_doubles(unsigned long long cols, unsigned long long slots, unsigned long long np1)
 {
     const unsigned long long w = IVP_LOG_GROUP(np1);
-    return 1u + 2u * cols + ((cols + w - 1u) / w) * slots * w * np1;
+    return IVP_LOG_HDR(cols) + ((((cols + w - 1u) / w) * slots * w * np1 + 15u) & ~15ull);
 }
 // so_log_flush: the slots of the current page column that hold a record go to its header (a column nobody recorded into
 // keeps the 0 it was opened with).
@@ -924,7 +924,7 @@ IVP_HD void so_push_log(const IvpKArgs &a, uint32_t j, Lane<N, P> &L, double t, 
             // body + ((g * slots + slot) * W + col % W) * (n + 1): the W records of a group and slot are one contiguous run
             constexpr size_t np1 = MAP::NT + 1, W = IVP_LOG_GROUP(np1);
             const size_t cols = IVP_SEG_COLS(L.log_seg), col = IVP_SEG_COL(L.log_seg), slots = IVP_SEG_SLOTS(L.log_seg);
-            double *rec = a.log_pool + IVP_SEG_BASE(L.log_seg) + 1u + 2u * cols + (((col / W) * slots + (size_t)L.log_slot) * W + (col % W)) * np1;
+            double *rec = a.log_pool + IVP_SEG_BASE(L.log_seg) + IVP_LOG_HDR(cols) + (((col / W) * slots + (size_t)L.log_slot) * W + (col % W)) * np1;
             if (MAP::leader()) rec[0] = t;
 #pragma unroll
             for (int c = 0; c < N; ++c) if (MAP::own(c)) rec[1 + MAP::gi(c)] = yv[c];

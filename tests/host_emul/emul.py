@@ -227,7 +227,8 @@ def gather_pages(res, n):
     words = pool.view(np.uint64)
     np1 = n + 1
     W = 8 if np1 <= 9 else 1
-    page_doubles = lambda cols, slots: 1 + 2 * cols + ((cols + W - 1) // W) * slots * W * np1
+    hdr = lambda cols: (1 + 2 * cols + 15) & ~15   # IVP_LOG_HDR
+    page_doubles = lambda cols, slots: hdr(cols) + ((((cols + W - 1) // W) * slots * W * np1 + 15) & ~15)
     t = np.full(int(off[-1]), np.nan)
     y = np.full((int(off[-1]), n), np.nan)
     filled = np.zeros(int(off[-1]), dtype=bool)
@@ -241,7 +242,7 @@ def gather_pages(res, n):
                 cols, slots = (int(v) for v in pool[page:page + 1].view(np.uint32))
                 if cols == 0:
                     continue
-                body = page + 1 + 2 * cols
+                body = page + hdr(cols)
                 for col in range(cols):
                     j, k0, bits, _ = (int(v) for v in pool[page + 1 + 2 * col:page + 3 + 2 * col].view(np.uint32))
                     r = 0
