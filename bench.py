@@ -87,7 +87,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=100_000, help="trajectories in the whole batch (BASELINE C2 / C4: 100000)")
+    ap.add_argument("--batch", type=int, default=100_000,
+                    help="trajectories in the whole batch (BASELINE C2 / C4: 100000).  With --gpus 8 ONE 100k batch cannot reach the >= 6x strong-"
+                         "scaling target (its slowest trajectory's sequential attempts do not shrink with the shard); the single-GPU prediction "
+                         "(profiles/r04_strong_scaling_prediction.json, DESIGN.md section 7) puts the threshold at 6.4M trajectories and 8M safely "
+                         "above it (6.45x): --gpus 8 --batch 8000000 --max-steps 1000")
+    ap.add_argument("--max-steps", type=int, default=0,
+                    help="Options.max_steps of every solve (0 = None = unlimited, the reference's default and the headline's).  Batches of more than "
+                         "~400k perturbed Arenstorf orbits contain collision orbits (one needs > 200 000 steps) that end with NeedLargerNMax under a budget")
     ap.add_argument("--fp", choices=["strict", "fma", "fast"], default="strict",
                     help="arithmetic mode of the kernels: strict (headline: the reference's IEEE operation sequence) or fma "
                          "(the defined FMA mode, bit-comparable with oracle/liboracle_fma.so; 'fast' is its older name)")
@@ -140,7 +147,7 @@ def main():
     n_state = prob.n
     ctx = ivp_amd.Context(local_rank)
     mk_opts = lambda profile: ivp_amd.Options(method=wl["method"], rtol=wl["rtol"], atol=wl["atol"], fp_mode=fp,
-                                              chunk_attempts=args.chunk, profile=profile)
+                                              chunk_attempts=args.chunk, profile=profile, max_steps=args.max_steps or None)
 
     def barrier_sync():
         if dist is not None:
@@ -305,7 +312,7 @@ def main():
                 "trajectories_total": B,
                 "trajectories_per_gpu": hi - lo,
                 "fp_mode": args.fp,
-                "chunk_attempts": args.chunk or 64,
+                "chunk_attempts": args.chunk or 64, "max_steps": args.max_steps or None,
                 "parallelism": f"dp{world} (independent shards" + (", one RCCL all-gather of the end states per step)" if world > 1 else ")"),
             },
             "wall_ms_to_t_end": ms_per_step,
