@@ -31,7 +31,8 @@ __device__ void events(double t, const double* s, double* g, const double* p) { 
 """
 
 out, method, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
-y0, p, t0, t1 = W.cr3bp_batch(B)
+y0, p, t0, t1 = W.cr3bp_batch(100_000)   # BASELINE C2's batch (other sizes draw other perturbations: 20 000 holds a collision orbit of 1e7 steps)
+y0, p = np.ascontiguousarray(y0[:, :B]), np.ascontiguousarray(p[:, :B])
 dev = torch.device("cuda:0")
 f = ivp_amd.DeviceIVP(SRC, n=6, params=(W.ARENSTORF_MU,), events=[ivp_amd.EventConfig(), ivp_amd.EventConfig().negative()])
 tol = dict(rtol=1e-6, atol=1e-9) if method == "DOPRI5" else dict(rtol=1e-8, atol=1e-10)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("method,B", [("DOPRI5", 20000)])   # (DOP853 works the same way; its hiprtc modules take minutes to build)
+@pytest.mark.parametrize("method,B", [("DOPRI5", 20000), ("DOP853", 3000)])
 def test_deferred_roots_equal_inline_roots_bit_for_bit(tmp_path, method, B):
     outs = []
     for mode in ("0", "1"):
