@@ -4,7 +4,7 @@
 # run this part in the build container, after `make -C ivp_amd/csrc`:
 #   bash tools/phase_clocks_large_n.sh build
 # -- and on the GPU box run one N = 100 system through it; the kernel prints shader-clock cycles per phase:
-#   bash tools/phase_clocks_large_n.sh run [variant]     (variant 2: factors in LDS, 1: in global memory)
+#   bash tools/phase_clocks_large_n.sh run [variant] [decay100|dense64]     (variant 2: factors in LDS, 1: in global memory)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
@@ -16,5 +16,5 @@ if [ "$1" = build ]; then
         -o $R/build_clk/libivp_hip_clk.so -L/opt/rocm/lib -lhiprtc -Wl,-rpath,/opt/rocm/lib
     rm -f $R/build_clk/*.o
 else
-    IVP_AMD_LIB=$R/build_clk/libivp_hip_clk.so python3 $R/tools/time_large_n_one.py 1 ${2:-2} 2>&1 | tail -3
+    IVP_AMD_LIB=$R/build_clk/libivp_hip_clk.so python3 $R/tools/time_large_n_one.py 1 ${2:-2} ${3:-decay100} 2>&1 | tail -3
 fi
