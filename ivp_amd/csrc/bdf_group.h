@@ -191,8 +191,11 @@ struct BdfG {
     template <int V> struct IntC { static constexpr int value = V; };
 
     // lu_decomp (src/matrix/lu.rs:37-125) in place on the column-major matrix a; pivots to piv[0..NT-2].
-    static __device__ __forceinline__ bool lu_decomp(double *a, uint32_t *piv)
+    // `density` (may be NULL): {trailing columns that needed an update, trailing columns looked at}, summed over the pivots of
+    // this factorisation -- the host's choice between LDS-resident and global-memory factors follows it (ivp_capi.cpp)
+    static __device__ __forceinline__ bool lu_decomp(double *a, uint32_t *piv, uint32_t *density = nullptr)
     {
+        uint32_t n_flagged = 0, n_looked = 0;
         if (NT == 1) return a[0] != 0.0;
         __syncthreads();
 #pragma unroll 1
@@ -317,6 +320,29 @@ struct BdfG {
                 const bool need = jj < NT && (tjv != 0.0 || (m != k && d2u(tjv) != d2u(akv)));
                 unsigned long long todo = __ballot(need);
                 if (G < IVP_WAVE) todo = (todo >> wl0()) & ((1ull << (G & 63)) - 1ull);   // this group's columns
+                n_flagged += (uint32_t)__popcll(todo);
+                n_looked += (uint32_t)((NT - j0) < G ? (NT - j0) : G);
+                // DENSE segments (every column of the range flagged: a full Jacobian) go JB columns at a time with no
+                // per-column bookkeeping -- the general loop below spends ~45 instructions and four taken branches per column
+                // on finding its columns one bit at a time (dense 64-state system: 83 % of lu_decomp, tools/phase_clocks_large_n.sh)
+                {
+                    const int ncol = (NT - j0) < G ? (NT - j0) : G;
+                    const unsigned long long all = ncol >= 64 ? ~0ull : ((1ull << ncol) - 1ull);
+                    if (todo == all) {
+                        int done = 0;
+#pragma unroll 1
+                        for (; done + JB <= ncol; done += JB) {
+                            int jc[JB];
+                            bool act[JB];
+#pragma unroll
+                            for (int b = 0; b < JB; ++b) { act[b] = true; jc[b] = j0 + done + b; }
+                            Blk q;
+                            fetch(jc, act, q);
+                            finish(jc, act, q);
+                        }
+                        todo = done >= 64 ? 0ull : (all >> done) << done;   // the last ncol % JB columns: below
+                    }
+                }
 #pragma unroll 1
                 while (__any(todo != 0ull)) {
                     int jc[JB];
@@ -335,6 +361,7 @@ struct BdfG {
             __syncthreads();   // column k+1 is complete before the next pivot search reads it
             IVP_CLK(12);
         }
+        if (density != nullptr && gl() == 0) { atomicAdd(density, n_flagged); atomicAdd(density + 1, n_looked); }
         return a[(size_t)(NT - 1) * NT + (NT - 1)] != 0.0;
     }
 
@@ -726,7 +753,8 @@ __device__ __forceinline__ bool bdf_group_attempt(const IvpKArgs &a, uint32_t j,
         }
         S.d_nlu += 1;
         IVP_CLK(1);
-        if (BG::lu_decomp(lu, piv)) { lu_current = true; S.current_c = c; }
+        // (the first 64 trajectories report how dense their elimination was: a.err_flag[1..2], read by the host every round)
+        if (BG::lu_decomp(lu, piv, j < 64u ? a.err_flag + 1 : nullptr)) { lu_current = true; S.current_c = c; }
         else lu_failed = true;
         __syncthreads();
         IVP_CLK(2);

@@ -254,7 +254,15 @@ int enqueue_round(ivp_ctx *ctx)
     // cooperative kernel then happens after 192 instead of 256 attempts (3.33 -> 3.25 ms); more polls cost ~40 us each
     const bool tail = P.adaptive && (use_coop || (fits_one_wave && !spec_ok));
     int launches_per_sync = tail ? 1 : tune().launches_per_poll;
-    const uint32_t this_chunk = tail ? 1024u : P.chunk_now;
+    uint32_t this_chunk = tail ? 1024u : P.chunk_now;
+    // Large-n BDF batches too big for the "two wavefronts per CU" rule: ONE short launch first (every trajectory factorises in
+    // its first attempt), so that the density of the eliminations is known before the bulk of the work is enqueued (see lds_lu
+    // below; costs one host poll, ~50 us of a solve that takes tens of milliseconds)
+    if (P.lds_lu_ok && P.variant == 0 && !P.lu_probed && (size_t)lanes > 2u * (size_t)ctx->cus) {
+        P.lu_probed = true;
+        launches_per_sync = 1;
+        this_chunk = 2u;
+    }
     // BDF (thread per trajectory): thin waves.  BASELINE C5's 10 000 trajectories are 157 full waves on a chip with 256 CUs.
     // A wave pays for the union of its lanes' control flow on every attempt, and (measured, MI355X) a wave that has its
     // CU to itself runs this branch-heavy kernel fastest: 10.95 ms with 64 lanes per wave (157 waves), 10.5 ms with 40
@@ -320,8 +328,10 @@ int enqueue_round(ivp_ctx *ctx)
         // CU the LDS form is 2-12 % faster (a pivot step waits for LDS, not for L2); beyond that a dense Jacobian still gains
         // 1.2x but a sparse one (whose trailing updates are mostly skipped) loses 1.5x to the lost occupancy -- so the
         // automatic choice follows the active count, launch by launch (current factors travel through global memory
-        // between launches either way); variant 2 forces the LDS form for every launch
-        ka.lds_lu = (P.lds_lu_ok && (P.variant == 2 || (size_t)lanes <= 2u * (size_t)ctx->cus)) ? 1u : 0u;
+        // between launches either way); variant 2 forces the LDS form for every launch.  Round 4: the kernels report how
+        // dense their eliminations are (the two words behind err_flag); once more than half of the trailing columns a pivot
+        // looks at need an update the LDS form wins at any batch size (20 000 dense 64-state systems: 234 ms against 369)
+        ka.lds_lu = (P.lds_lu_ok && (P.variant == 2 || (size_t)lanes <= 2u * (size_t)ctx->cus || P.lu_dense)) ? 1u : 0u;
         if (c == 0) {
             ka.perm_in = nullptr;
             ka.count_in = nullptr;
@@ -353,7 +363,8 @@ int enqueue_round(ivp_ctx *ctx)
         }
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, counts + ((P.c - 1) & 3), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (!P.err_checked || P.paged) HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!P.err_checked || P.paged || P.lds_lu_ok)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + 1, counts + 4, sizeof(uint32_t) * (P.lds_lu_ok ? 3u : 1u), hipMemcpyDeviceToHost, s));
     // one-pass step log: the sub-pools' counters travel with every round's active count, so that the round that finishes the
     // solve also tells the host how many pages there are to gather (ivp_log.cpp) -- no extra round trip
     if (P.paged) HIP_TRY(ctx, hipMemcpyAsync(ctx->alloc_host, ctx->log_alloc.p, sizeof(unsigned long long) * ctx->log_state.subs * IVP_LOG_ALLOC_STRIDE, hipMemcpyDeviceToHost, s));
@@ -393,6 +404,7 @@ int finish_round(ivp_ctx *ctx, int *done)
         }
     }
     P.lanes = ctx->pinned[0];
+    if (P.lds_lu_ok && ctx->pinned[3] >= 64u) P.lu_dense = (uint64_t)ctx->pinned[2] * 2u > (uint64_t)ctx->pinned[3];   // large-n BDF: see enqueue_round
     if (P.lanes != 0) return enqueue_round(ctx);
     if (P.a.evd_rec != nullptr && !P.sampled) {
         // deferred event refinement: the roots of every noted step, one lane each (same hand-over as the sample kernel below)
@@ -888,6 +900,8 @@ int ivp_batch_submit_device(ivp_ctx_t *ctx, const ivp_problem_t *prob, size_t B,
     P.jit = prob->rhs_id == IVP_RHS_JIT;
     P.has_settings = opt->has_settings != 0;
     P.lds_lu_ok = lds_lu_ok;
+    P.lu_dense = false;
+    P.lu_probed = false;
     P.has_events = n_events > 0;
     P.paged = paged;
     // lane-cooperative DOPRI5 / DOP853 kernels (rk_coop.h: eight lanes per trajectory): available for problems with

@@ -93,6 +93,8 @@ struct ivp_ctx {
         int method = 0, fp_mode = 0, variant = 0, profile = 0, n = 0;
         int full = 0;   // kernel flavour (rk_launch.h): 0 end state, 1 whole DefaultSolOut, 2 log-only
         bool group = false, jit = false, coop_ok = false, has_settings = false, adaptive = false, lds_lu_ok = false, has_events = false;
+        bool lu_dense = false;      // large-n BDF: the kernels' eliminations update most trailing columns (LDS factors pay at any batch size)
+        bool lu_probed = false;     // ... and the short first launch that measures it has been enqueued
         uint32_t chunk = 64, lanes = 0;
         uint32_t chunk_now = 64;    // attempts per bulk launch of the next round (adaptive: follows the decay of the active set)
         uint32_t quiet_rounds = 0;  // consecutive rounds that retired (almost) nobody

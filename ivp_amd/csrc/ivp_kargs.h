@@ -109,7 +109,9 @@ struct IvpKArgs {
     double *bdf_lu;           // [N*N][B]   LU of (I - c J)
     uint32_t *bdf_piv;        // [B]        pivot rows, 4 bits each
     uint64_t *njev, *nlu;     // [B]
-    uint32_t *err_flag;       // device word: IVP_ERRFLAG_* bits raised by the init kernel
+    uint32_t *err_flag;       // device word: IVP_ERRFLAG_* bits raised by the init kernel; the two words behind it collect, for the
+                              // first 64 trajectories of a large-n BDF batch, {trailing columns updated, trailing columns looked at} of
+                              // their factorisations (bdf_group.h lu_decomp): how dense the elimination is decides LDS vs global factors
     // ---- profiling ----
     unsigned long long *slot_counter;  // optional: += lanes x attempts the wave executed
     // ---- speculative launch of the lane-cooperative kernel (rk_coop.h) ----
