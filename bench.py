@@ -91,7 +91,7 @@ def main():
                     help="trajectories in the whole batch (BASELINE C2 / C4: 100000).  With --gpus 8 ONE 100k batch cannot reach the >= 6x strong-"
                          "scaling target (its slowest trajectory's sequential attempts do not shrink with the shard); the single-GPU prediction "
                          "(profiles/r04_strong_scaling_prediction.json, DESIGN.md section 7) puts the threshold at 6.4M trajectories and 8M safely "
-                         "above it (6.45x): --gpus 8 --batch 8000000 --max-steps 1000")
+                         "above it (6.4x): --gpus 8 --batch 8000000 --max-steps 1000")
     ap.add_argument("--max-steps", type=int, default=0,
                     help="Options.max_steps of every solve (0 = None = unlimited, the reference's default and the headline's).  Batches of more than "
                          "~400k perturbed Arenstorf orbits contain collision orbits (one needs > 200 000 steps) that end with NeedLargerNMax under a budget")
