@@ -427,3 +427,26 @@ def test_bdf_n100_lds_factors_equal_global_factors_and_the_oracle():
         for chunk in (0, 7):
             got = gpu_batch("linear_decay100", y0, p, t0, t1, variant=variant, chunk=chunk, **o)
             assert_bitexact(got, ref, f"N=100 BDF variant {variant} chunk {chunk}: ")
+
+
+@pytest.mark.parametrize("rhs", ["dense64", "linear_decay100"])
+def test_bdf_large_batches_automatic_factor_placement_changes_no_bit(rhs):
+    """Batches beyond two wavefronts per CU: the launch loop starts with ONE short launch, reads how dense the eliminations
+    are (the counters behind err_flag) and keeps the factors in LDS for a dense Jacobian, in global memory for a sparse one
+    (ivp_capi.cpp, enqueue_round).  Whatever it picks, launch by launch: the bits of variant 1 (global) and variant 2 (LDS), and
+    of the oracle on a sample of the trajectories."""
+    B = 1500
+    if rhs == "dense64":
+        y0, p = _dense64_batch(B)
+        t0, t1, o = 0.0, 0.3, dict(method="BDF", rtol=1e-6, atol=1e-9)
+    else:
+        y0, p, t0, t1 = _decay_batch(B)
+        o = dict(method="BDF", rtol=1e-5, atol=1e-8)
+    runs = {v: gpu_batch(rhs, y0, p, t0, t1, variant=v, **o) for v in (0, 1, 2)}
+    for v in (1, 2):
+        for k in ("y_end", "t_end", "h_next", "status", "nfev", "njev", "nlu", "naccpt", "nrejct"):
+            assert np.array_equal(runs[0][k], runs[v][k]), (rhs, v, k)
+    idx = np.arange(0, B, 250)
+    ref = oracle_batch(rhs, y0[:, idx], None if p is None else p[:, idx], t0, t1 if np.ndim(t1) == 0 else t1[idx], **o)
+    sub = {k: (v[..., idx] if isinstance(v, np.ndarray) and v.shape and v.shape[-1] == B else v) for k, v in runs[0].items()}
+    assert_bitexact(sub, ref, f"{rhs} automatic factor placement: ")
