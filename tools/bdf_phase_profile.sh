@@ -10,8 +10,8 @@ if [ "${1:-build}" = build ]; then
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DIVP_FAST=0 -ffp-contract=off -DIVP_PHASE_PROF \
       -I$R/include -c $C/rk_bdf.hip -o $R/exp_libs/rk_bdf_strict_prof.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $C/rk_strict.o $C/rk_fast.o $C/rk_strict_h.o $C/rk_fast_h.o $C/rk_group_strict.o \
-      $C/rk_group_fast.o $R/exp_libs/rk_bdf_strict_prof.o $C/rk_bdf_fast.o $C/ivp_capi.o $C/ivp_jit.o -o $R/exp_libs/libivp_hip_prof.so \
-      -L/opt/rocm/lib -lhiprtc -Wl,-rpath,/opt/rocm/lib
+      $C/rk_group_fast.o $R/exp_libs/rk_bdf_strict_prof.o $C/rk_bdf_fast.o $C/rk_bdf_strict_occ2.o $C/rk_bdf_fast_occ2.o $C/ivp_capi.o $C/ivp_log.o \
+      $C/log_gather.o $C/ivp_jit.o -o $R/exp_libs/libivp_hip_prof.so -L/opt/rocm/lib -lhiprtc -Wl,-rpath,/opt/rocm/lib
   echo built $R/exp_libs/libivp_hip_prof.so
 else
   python3 -c "import torch"
