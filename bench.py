@@ -265,7 +265,7 @@ def main():
         # VALU issue view of the dominant kernel: the thread-per-trajectory stepping kernel is bound by vector-instruction
         # issue (one wave64 FP64 instruction per 4 cycles per SIMD at best), not by bytes or by counted flops (strict mode
         # spends separate multiply and add instructions, 11 on a division, 18 on a square root).  Instructions per launch
-        # come from the committed SQ-counter profile of this command (profiles/r03_sq_counters_<workload>_<fp>.json,
+        # come from the committed SQ-counter profile of this command (profiles/<PROFILE_ROUND>_sq_counters_<workload>_<fp>.json,
         # SQ_INSTS_VALU, tools/profile_sq.sh), the launch duration is this run's.
         issue = None
         sq_name = f"{PROFILE_ROUND}_sq_counters_{args.workload}_{args.fp}.json"
