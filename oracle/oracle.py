@@ -225,7 +225,7 @@ class OracleSolution:
         return float(self.seg_xold[0]), float(self.seg_xold[-1] + self.seg_h[-1])
 
     def __del__(self):
-        if self._c is not None and self._lib is not None:
+        if self._c is not None and self._lib is not None and C is not None:   # (module globals are gone at interpreter shutdown)
             self._lib.orc_solution_free(C.byref(self._c))
             self._c = None
 
