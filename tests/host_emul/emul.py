@@ -243,6 +243,9 @@ def gather_pages(res, n):
                 if cols == 0:
                     continue
                 body = page + hdr(cols)
+                # whole 128-byte lines: pages from the region's start, bodies within their page (IVP_LOG_HDR): a slot row of a group
+                # then fills whole 64-byte sectors
+                assert (page - sub * region) % 16 == 0 and (body - page) % 16 == 0 and (W * np1 * 8) % 64 == 0 or W == 1
                 for col in range(cols):
                     j, k0, bits, _ = (int(v) for v in pool[page + 1 + 2 * col:page + 3 + 2 * col].view(np.uint32))
                     r = 0
